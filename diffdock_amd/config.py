@@ -1,0 +1,163 @@
+"""Hyper-parameter contract of the score model.
+
+Mirrors the keyword arguments `get_model` passes to `CGModel`
+(reference utils/utils.py:234-276, models/cg_model.py:20-31) plus the noise-schedule
+bounds `t_to_sigma` / `sampling` read from the args namespace
+(utils/diffusion_utils.py:28-32, utils/sampling.py:133-149).
+
+The real DiffDock-L `model_parameters.yml` is fetched at run time by the reference
+(inference.py:124-147) and is not in the repository, so benchmarks use the declared
+preset DDL_SYNTH below.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict, replace
+import argparse
+
+# vocabulary sizes (reference datasets/process_mols.py:59-87)
+LIG_FEATURE_DIMS = (119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2)
+REC_RESIDUE_FEATURE_DIMS = (38,)
+LM_EMBEDDING_DIM = 1280  # 'precomputed' ESM2 embeddings (models/cg_model.py:73-74)
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+    # architecture (names as in CGModel.__init__)
+    ns: int = 16
+    nv: int = 4
+    num_conv_layers: int = 2
+    num_prot_emb_layers: int = 0
+    sh_lmax: int = 2
+    sigma_embed_dim: int = 32
+    distance_embed_dim: int = 32
+    cross_distance_embed_dim: int = 32
+    in_lig_edge_features: int = 4
+    lig_max_radius: float = 5.0
+    rec_max_radius: float = 30.0        # never overridden by get_model
+    cross_max_distance: float = 80.0
+    center_max_distance: float = 30.0   # never overridden by get_model
+    dynamic_max_cross: bool = False
+    use_second_order_repr: bool = False
+    reduce_pseudoscalars: bool = False
+    differentiate_convolutions: bool = True
+    tp_weights_layers: int = 2
+    embed_also_ligand: bool = True
+    batch_norm: bool = True
+    smooth_edges: bool = False
+    odd_parity: bool = False
+    no_torsion: bool = False
+    scale_by_sigma: bool = True
+    fixed_center_conv: bool = False
+    lm_embedding_type: str | None = "precomputed"
+    embedding_scale: float = 1000.0     # sinusoidal timestep embedding scale
+    # noise schedule (args.* in the reference)
+    tr_sigma_min: float = 0.1
+    tr_sigma_max: float = 19.0
+    rot_sigma_min: float = 0.03
+    rot_sigma_max: float = 1.55
+    tor_sigma_min: float = 0.0314
+    tor_sigma_max: float = 3.14
+    crop_beyond: float | None = None
+
+    # ------------------------------------------------------------------ derived
+    @property
+    def lm_embedding_dim(self) -> int:
+        return LM_EMBEDDING_DIM if self.lm_embedding_type == "precomputed" else 0
+
+    @property
+    def faster(self) -> bool:
+        # models/cg_model.py:121,144,165
+        return self.sh_lmax == 1 and not self.use_second_order_repr
+
+    def irrep_seq(self):
+        """models/tensor_layers.py:17-32 (get_irrep_seq)."""
+        ns, nv = self.ns, self.nv
+        last = nv if self.reduce_pseudoscalars else ns
+        if self.use_second_order_repr:
+            return [f"{ns}x0e",
+                    f"{ns}x0e + {nv}x1o + {nv}x2e",
+                    f"{ns}x0e + {nv}x1o + {nv}x2e + {nv}x1e + {nv}x2o",
+                    f"{ns}x0e + {nv}x1o + {nv}x2e + {nv}x1e + {nv}x2o + {last}x0o"]
+        return [f"{ns}x0e",
+                f"{ns}x0e + {nv}x1o",
+                f"{ns}x0e + {nv}x1o + {nv}x1e",
+                f"{ns}x0e + {nv}x1o + {nv}x1e + {last}x0o"]
+
+    def layer_irreps(self, i):
+        """(in, out) irreps strings of layer index i in the emb+conv sequence
+        (models/cg_model.py:110-111,154-155)."""
+        seq = self.irrep_seq()
+        return seq[min(i, len(seq) - 1)], seq[min(i + 1, len(seq) - 1)]
+
+    def conv_groups(self, l) -> int:
+        """edge groups of conv layer l (models/cg_model.py:167)."""
+        if not self.differentiate_convolutions:
+            return 1
+        return 2 if l == self.num_conv_layers - 1 else 4
+
+    def to_namespace(self) -> argparse.Namespace:
+        """Namespace shaped like the reference's args / model_parameters.yml."""
+        d = asdict(self)
+        d.update(max_radius=self.lig_max_radius, no_batch_norm=not self.batch_norm,
+                 no_differentiate_convolutions=not self.differentiate_convolutions,
+                 embedding_type="sinusoidal", all_atoms=False, dropout=0.0,
+                 esm_embeddings_path="precomputed" if self.lm_embedding_type else None)
+        for k in ('fixed_center_conv', 'lm_embedding_type', 'batch_norm', 'differentiate_convolutions',
+                  'lig_max_radius', 'rec_max_radius', 'center_max_distance', 'in_lig_edge_features'):
+            d.pop(k)
+        return argparse.Namespace(**d)
+
+    def replace(self, **kw) -> "ModelConfig":
+        return replace(self, **kw)
+
+
+def config_from_args(args) -> ModelConfig:
+    """Build a ModelConfig from a reference-style args namespace using the same
+    'k in args' fall-backs as get_model (utils/utils.py:174-276)."""
+    def has(k):
+        return hasattr(args, k)
+
+    def get(k, default):
+        return getattr(args, k) if has(k) else default
+
+    lm = None
+    for k in ("moad_esm_embeddings_path", "pdbbind_esm_embeddings_path",
+              "pdbsidechain_esm_embeddings_path", "esm_embeddings_path"):
+        if get(k, None) is not None:
+            lm = "precomputed"
+    if get("all_atoms", False):
+        raise NotImplementedError("all_atoms (AAModel) is not on the built path yet")
+    return ModelConfig(
+        ns=args.ns, nv=args.nv, num_conv_layers=args.num_conv_layers,
+        num_prot_emb_layers=get("num_prot_emb_layers", 0), sh_lmax=get("sh_lmax", 2),
+        sigma_embed_dim=args.sigma_embed_dim, distance_embed_dim=args.distance_embed_dim,
+        cross_distance_embed_dim=args.cross_distance_embed_dim, lig_max_radius=args.max_radius,
+        cross_max_distance=args.cross_max_distance, dynamic_max_cross=args.dynamic_max_cross,
+        use_second_order_repr=args.use_second_order_repr,
+        reduce_pseudoscalars=get("reduce_pseudoscalars", False),
+        differentiate_convolutions=not get("no_differentiate_convolutions", False),
+        tp_weights_layers=get("tp_weights_layers", 2), embed_also_ligand=get("embed_also_ligand", False),
+        batch_norm=not args.no_batch_norm, smooth_edges=get("smooth_edges", False),
+        odd_parity=get("odd_parity", False), no_torsion=args.no_torsion, scale_by_sigma=args.scale_by_sigma,
+        fixed_center_conv=(not args.not_fixed_center_conv) if has("not_fixed_center_conv") else False,
+        lm_embedding_type=lm,
+        embedding_scale=args.embedding_scale if has("embedding_type") else 10000.0,
+        tr_sigma_min=args.tr_sigma_min, tr_sigma_max=args.tr_sigma_max,
+        rot_sigma_min=args.rot_sigma_min, rot_sigma_max=args.rot_sigma_max,
+        tor_sigma_min=args.tor_sigma_min, tor_sigma_max=args.tor_sigma_max,
+        crop_beyond=get("crop_beyond", None))
+
+
+# Declared benchmark preset: FasterTensorProduct conv layers.
+DDL_SYNTH = ModelConfig(
+    ns=48, nv=10, num_conv_layers=6, num_prot_emb_layers=0, sh_lmax=1,
+    sigma_embed_dim=64, distance_embed_dim=64, cross_distance_embed_dim=64,
+    lig_max_radius=5.0, cross_max_distance=80.0, dynamic_max_cross=True,
+    use_second_order_repr=False, reduce_pseudoscalars=False, differentiate_convolutions=True,
+    tp_weights_layers=2, embed_also_ligand=True, batch_norm=True, smooth_edges=False,
+    tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55,
+    tor_sigma_min=0.0314, tor_sigma_max=3.14, crop_beyond=None)
+
+# Small preset for CPU-fast parity tests (same structure, all four irrep stages reached).
+TINY = DDL_SYNTH.replace(ns=8, nv=3, num_conv_layers=4, sigma_embed_dim=16,
+                         distance_embed_dim=16, cross_distance_embed_dim=16)

@@ -1,0 +1,156 @@
+"""Weight ABI of the CG score model = the reference `state_dict` key names and shapes
+(derived from models/cg_model.py:85-255, models/layers.py:10-67,
+models/tensor_layers.py:298-307).  There are no checkpoints in this environment
+(the reference downloads them, inference.py:124-143), so benchmarks and tests use
+random-initialised weights of the declared architecture.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import torch
+
+from .config import ModelConfig, LIG_FEATURE_DIMS, REC_RESIDUE_FEATURE_DIMS
+from .irreps import parse_irreps, irreps_num, sh_irreps, full_tp_irreps, tp_weight_numel
+
+
+def tor_sh_irreps(cfg: ModelConfig) -> str:
+    return full_tp_irreps(sh_irreps(cfg.sh_lmax), "1x2e")
+
+
+def final_conv_out(cfg: ModelConfig) -> str:
+    return "2x1o + 2x1e" if not cfg.odd_parity else "1x1o + 1x1e"
+
+
+def tor_conv_out(cfg: ModelConfig) -> str:
+    return f"{cfg.ns}x0o + {cfg.ns}x0e" if not cfg.odd_parity else f"{cfg.ns}x0o"
+
+
+def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """key -> (shape, kind), kind in {linear_w, linear_b, emb, offset, bn_mean, bn_var,
+    bn_w, bn_b}.  Only tensors that carry model state are listed (e3nn-internal
+    buffers under *.tp.* are not part of the ABI and are ignored by loaders)."""
+    ns, sd = cfg.ns, cfg.sigma_embed_dim
+    spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+
+    def lin(name, fin, fout, bias=True):
+        spec[f"{name}.weight"] = ((fout, fin), "linear_w")
+        if bias:
+            spec[f"{name}.bias"] = ((fout,), "linear_b")
+
+    def mlp(name, fin, hid, fout):  # Sequential(Linear, ReLU, Dropout, Linear)
+        lin(f"{name}.0", fin, hid)
+        lin(f"{name}.3", hid, fout)
+
+    def encoder(name, dims, extra):
+        for i, d in enumerate(dims):
+            spec[f"{name}.atom_embedding_list.{i}.weight"] = ((d, ns), "emb")
+        if extra > 0:
+            lin(f"{name}.additional_features_embedder", extra + ns, ns)
+
+    def bn(name, irreps):
+        n0 = sum(b.mul for b in parse_irreps(irreps) if b.l == 0 and b.p == 1)
+        nf = irreps_num(irreps)
+        spec[f"{name}.running_mean"] = ((n0,), "bn_mean")
+        spec[f"{name}.running_var"] = ((nf,), "bn_var")
+        spec[f"{name}.weight"] = ((nf,), "bn_w")
+        spec[f"{name}.bias"] = ((n0,), "bn_b")
+
+    def conv(name, in_irr, sh, out_irr, n_edge, hidden, groups, faster):
+        W = tp_weight_numel(in_irr, sh, out_irr, faster)
+        for g in range(groups):
+            pre = f"{name}.fc" if groups == 1 else f"{name}.fc.{g}"
+            assert cfg.tp_weights_layers == 2, "FCBlock with extra hidden layers not on the built path"
+            lin(f"{pre}.0", n_edge, hidden)
+            lin(f"{pre}.3", hidden, W)
+        if cfg.batch_norm:
+            bn(f"{name}.batch_norm", out_irr)
+
+    sh = sh_irreps(cfg.sh_lmax)
+    encoder("lig_node_embedding", LIG_FEATURE_DIMS, sd)
+    mlp("lig_edge_embedding", cfg.in_lig_edge_features + sd + cfg.distance_embed_dim, ns, ns)
+    encoder("rec_node_embedding", REC_RESIDUE_FEATURE_DIMS, cfg.lm_embedding_dim)
+    mlp("rec_edge_embedding", cfg.distance_embed_dim, ns, ns)
+    mlp("rec_sigma_embedding", sd, ns, ns)
+    mlp("cross_edge_embedding", sd + cfg.cross_distance_embed_dim, ns, ns)
+    spec["lig_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:lig")
+    spec["rec_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:rec")
+    spec["cross_distance_expansion.offset"] = ((cfg.cross_distance_embed_dim,), "offset:cross")
+    K, L = cfg.num_prot_emb_layers, cfg.num_conv_layers
+    for i in range(K):
+        a, b = cfg.layer_irreps(i)
+        conv(f"rec_emb_layers.{i}", a, sh, b, 3 * ns, 3 * ns, 1, cfg.faster)
+    if cfg.embed_also_ligand:
+        for i in range(K):
+            a, b = cfg.layer_irreps(i)
+            conv(f"lig_emb_layers.{i}", a, sh, b, 3 * ns, 3 * ns, 1, cfg.faster)
+    for l in range(L):
+        a, b = cfg.layer_irreps(K + l)
+        conv(f"conv_layers.{l}", a, sh, b, 3 * ns, 3 * ns, cfg.conv_groups(l), cfg.faster)
+    last_out = cfg.layer_irreps(K + L - 1)[1]
+    spec["center_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:center")
+    mlp("center_edge_embedding", cfg.distance_embed_dim + sd, ns, ns)
+    conv("final_conv", last_out, sh, final_conv_out(cfg), 2 * ns, 2 * ns, 1, False)
+    mlp("tr_final_layer", 1 + sd, ns, 1)     # Sequential(Linear, Dropout, ReLU, Linear)
+    mlp("rot_final_layer", 1 + sd, ns, 1)
+    if not cfg.no_torsion:
+        mlp("final_edge_embedding", cfg.distance_embed_dim, ns, ns)
+        conv("tor_bond_conv", last_out, tor_sh_irreps(cfg), tor_conv_out(cfg), 3 * ns, 3 * ns, 1, False)
+        lin("tor_final_layer.0", 2 * ns if not cfg.odd_parity else ns, ns, bias=False)
+        lin("tor_final_layer.3", ns, 1, bias=False)
+    return spec
+
+
+def gaussian_offsets(cfg: ModelConfig, which: str) -> torch.Tensor:
+    stop = {"lig": cfg.lig_max_radius, "rec": cfg.rec_max_radius, "cross": cfg.cross_max_distance,
+            "center": cfg.center_max_distance}[which]
+    n = cfg.cross_distance_embed_dim if which == "cross" else cfg.distance_embed_dim
+    return torch.linspace(0.0, stop, n)
+
+
+def init_state_dict(cfg: ModelConfig, seed: int = 1234, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Random weights with torch's default init statistics (Linear: U(+-1/sqrt(fan_in)),
+    Embedding: xavier-uniform, models/layers.py:52) and perturbed BatchNorm statistics so
+    the normalisation is not an identity."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = OrderedDict()
+
+    def U(shape, a):
+        return (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1).mul_(a).to(dtype)
+
+    for key, (shape, kind) in state_dict_spec(cfg).items():
+        if kind == "linear_w":
+            sd[key] = U(shape, 1.0 / math.sqrt(shape[1]))
+        elif kind == "linear_b":
+            fan_in = state_dict_spec_fan_in(cfg, key)
+            sd[key] = U(shape, 1.0 / math.sqrt(fan_in))
+        elif kind == "emb":
+            sd[key] = U(shape, math.sqrt(6.0 / (shape[0] + shape[1])))
+        elif kind.startswith("offset"):
+            sd[key] = gaussian_offsets(cfg, kind.split(":")[1]).to(dtype)
+        elif kind == "bn_mean":
+            sd[key] = U(shape, 0.2)
+        elif kind == "bn_var":
+            sd[key] = (U(shape, 0.5) + 1.0)
+        elif kind == "bn_w":
+            sd[key] = (U(shape, 0.5) + 1.0)
+        elif kind == "bn_b":
+            sd[key] = U(shape, 0.2)
+        else:
+            raise KeyError(kind)
+    return sd
+
+
+_FAN_CACHE: Dict[int, Dict[str, int]] = {}
+
+
+def state_dict_spec_fan_in(cfg: ModelConfig, bias_key: str) -> int:
+    spec = state_dict_spec(cfg)
+    return spec[bias_key[:-len("bias")] + "weight"][0][1]
+
+
+def gaussian_coeff(offset: torch.Tensor) -> float:
+    """GaussianSmearing.coeff (models/layers.py:25)."""
+    return -0.5 / float(offset[1] - offset[0]) ** 2

@@ -1,0 +1,147 @@
+/* ddmi.h -- C ABI of the MI355X-native DiffDock score-model sampling path (libddmi.so).
+ *
+ * The reference (gcorso/DiffDock @ 2024_10_08) is 100 % Python and has no FFI; its
+ * boundary for this path is the Python duck type
+ *     model = get_model(args, device, t_to_sigma, no_parallel=True)   utils/utils.py:172
+ *     tr, rot, tor = model(batch)[:3]                                 utils/sampling.py:116
+ *     pos = modify_conformer_batch(pos, batch, tr, rot, tor, mask)    utils/sampling.py:189
+ *     data_list, conf = sampling(data_list, model, steps, ...)        utils/sampling.py:69
+ * Each entry point below names the reference interface it replaces.  The ctypes binding a
+ * maintainer would add is shown in INTEGRATION.md (diffdock_amd/lib.py is that binding).
+ *
+ * Conventions: all tensor pointers are DEVICE pointers (fp32 / int32 / uint8) unless a
+ * parameter is documented as host; they are borrowed for the duration of the call
+ * (weights, tables and the static complex description are copied).  Work is enqueued on the
+ * caller's HIP stream (pass torch.cuda.current_stream().cuda_stream; NULL = default
+ * stream).  Every function returns 0 on success or a negative ddmi_status; the message is
+ * available from ddmi_last_error() (thread-local).  A model handle is bound to one device
+ * and must not be used from two threads at once; distinct handles are independent.
+ */
+#ifndef DDMI_H
+#define DDMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ddmi_model ddmi_model;
+typedef void* ddmi_stream; /* hipStream_t */
+
+enum ddmi_status {
+  DDMI_OK = 0,
+  DDMI_ERR_ARG = -1,     /* bad argument / inconsistent shapes            */
+  DDMI_ERR_STATE = -2,   /* call order (weights / tables / complex unset) */
+  DDMI_ERR_HIP = -3,     /* HIP runtime error                             */
+  DDMI_ERR_KEY = -4,     /* unknown / missing state_dict key              */
+  DDMI_ERR_CAPACITY = -5 /* workspace or neighbour capacity exceeded      */
+};
+
+/* Hyper-parameters: the keyword arguments get_model passes to CGModel
+ * (utils/utils.py:234-276, models/cg_model.py:20-31) and the sigma bounds t_to_sigma reads
+ * (utils/diffusion_utils.py:28-32).  Booleans are 0/1. */
+typedef struct ddmi_config {
+  int32_t ns, nv, num_conv_layers, num_prot_emb_layers, sh_lmax;
+  int32_t sigma_embed_dim, distance_embed_dim, cross_distance_embed_dim, in_lig_edge_features;
+  int32_t lm_embedding_dim; /* 1280 for 'precomputed' ESM2 features, else 0 */
+  float lig_max_radius, rec_max_radius, cross_max_distance, center_max_distance;
+  int32_t dynamic_max_cross, use_second_order_repr, reduce_pseudoscalars, differentiate_convolutions;
+  int32_t embed_also_ligand, batch_norm, smooth_edges, odd_parity, no_torsion, scale_by_sigma;
+  int32_t fixed_center_conv;
+  float embedding_scale;
+  float tr_sigma_min, tr_sigma_max, rot_sigma_min, rot_sigma_max, tor_sigma_min, tor_sigma_max;
+} ddmi_config;
+
+/* Static description of one collated batch of complexes = the fields of the PyG Batch the
+ * path reads.  Node indices inside edge arrays are batch-global, as PyG
+ * collation produces them.  lig_ptr / rec_ptr are HOST arrays [num_graphs+1] of cumulative
+ * node counts.  The conformer fields describe ONE graph and are required only by
+ * ddmi_modify_conformer / ddmi_sample, which (like the reference's modify_conformer_batch,
+ * utils/diffusion_utils.py:60-64) assume all graphs in the batch are copies of one complex. */
+typedef struct ddmi_complex {
+  int32_t num_graphs, n_lig, n_rec, n_bond_edges, n_rec_edges, n_tor;
+  const int32_t* lig_ptr;        /* host [B+1] */
+  const int32_t* rec_ptr;        /* host [B+1] */
+  const int32_t* lig_x;          /* [n_lig,16] categorical atom features            */
+  const int32_t* bond_index;     /* [2,n_bond_edges] ('ligand','lig_bond','ligand') */
+  const float* bond_attr;        /* [n_bond_edges, in_lig_edge_features]            */
+  const uint8_t* edge_mask;      /* [n_bond_edges] rotatable directed bonds         */
+  const float* rec_x;            /* [n_rec, 1+lm_embedding_dim]                     */
+  const float* rec_pos;          /* [n_rec,3]                                       */
+  const int32_t* rec_edge_index; /* [2,n_rec_edges] ('receptor','rec_contact','receptor') */
+  const uint8_t* mask_rotate;    /* [n_tor/B, n_lig/B] or NULL                      */
+} ddmi_complex;
+
+/* Reverse-diffusion loop parameters = the arguments of sampling() (utils/sampling.py:69-72).
+ * Schedules are HOST arrays [inference_steps].  If z_* are NULL the Gaussian draws come
+ * from a counter-based generator keyed by (seed, sample_ids[b], step, component), so a run
+ * sharded over ranks reproduces the single-rank trajectories sample by sample. */
+typedef struct ddmi_sample_cfg {
+  int32_t inference_steps;
+  const double* tr_schedule;
+  const double* rot_schedule;
+  const double* tor_schedule;
+  int32_t ode, no_random, no_final_step_noise;
+  double temp_sampling[3], temp_psi[3], temp_sigma_data[3];
+  uint64_t seed;
+  const int64_t* sample_ids; /* host [B] or NULL (= 0..B-1) */
+  const float* z_tr;         /* device [steps,B,3] or NULL  */
+  const float* z_rot;        /* device [steps,B,3] or NULL  */
+  const float* z_tor;        /* device [steps,n_tor] or NULL */
+} ddmi_sample_cfg;
+
+/* get_model(args, device, ...) -- utils/utils.py:172.  device = HIP device ordinal. */
+int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out);
+void ddmi_destroy(ddmi_model* m);
+const char* ddmi_last_error(void);
+
+/* model.load_state_dict(sd, strict=True) -- inference.py:202-203.  One call per tensor with
+ * the reference's state_dict key, HOST fp32 data; then ddmi_commit_weights
+ * checks that every expected key was provided, pre-packs and uploads. */
+int ddmi_set_weight(ddmi_model* m, const char* key, const float* host_data, const int64_t* shape, int ndim);
+int ddmi_commit_weights(ddmi_model* m);
+/* Number of state_dict keys the configured architecture expects, and the i-th key / shape. */
+int ddmi_num_weights(ddmi_model* m);
+int ddmi_weight_spec(ddmi_model* m, int i, const char** key, int64_t shape[4], int* ndim);
+
+/* Score-norm tables the reference builds at import: kind 0 = so3._exp_score_norms
+ * (utils/so3.py:59, 2000 entries), kind 1 = torus.score_norm_ (utils/torus.py:72-76, 5001
+ * entries).  HOST float64. */
+int ddmi_set_table(ddmi_model* m, int kind, const double* host_data, int64_t n);
+/* Frequencies of the sinusoidal timestep embedding (utils/diffusion_utils.py:99-104),
+ * HOST fp32 [sigma_embed_dim/2]; optional -- computed in-library when not supplied. */
+int ddmi_set_time_frequencies(ddmi_model* m, const float* host_freq, int64_t n);
+
+/* batch.to(device) + the receptor-side caching of CGModel.embedding (models/cg_model.py:273-295). */
+int ddmi_set_complex(ddmi_model* m, const ddmi_complex* c, ddmi_stream stream);
+
+/* tr, rot, tor = model(batch)[:3] -- models/cg_model.py:308-424.
+ * lig_pos [n_lig,3]; t_* [B] = batch.complex_t[...]; outputs tr [B,3], rot [B,3], tor [n_tor]. */
+int ddmi_forward(ddmi_model* m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor,
+                 float* tr_out, float* rot_out, float* tor_out, ddmi_stream stream);
+
+/* modify_conformer_batch -- utils/diffusion_utils.py:60-78.  pos [n_lig,3] updated in place;
+ * tr_update [B,3], rot_update [B,3], tor_update [n_tor] or NULL. */
+int ddmi_modify_conformer(ddmi_model* m, float* lig_pos, const float* tr_update, const float* rot_update,
+                          const float* tor_update, ddmi_stream stream);
+
+/* The hot loop of sampling() -- utils/sampling.py:96-191 -- for one collated batch, entirely
+ * on the device (no host synchronisation).  lig_pos [n_lig,3] is updated in place. */
+int ddmi_sample(ddmi_model* m, float* lig_pos, const ddmi_sample_cfg* cfg, ddmi_stream stream);
+
+/* Introspection for tests and profiling: copy a named internal buffer to the host.
+ * ddmi_debug_shape returns the element count and up to 4 dims; names are listed in DESIGN.md. */
+int ddmi_debug_shape(ddmi_model* m, const char* name, int64_t shape[4], int* ndim, int* is_int);
+int ddmi_debug_read(ddmi_model* m, const char* name, void* host_dst, size_t bytes, ddmi_stream stream);
+/* Real-basis Wigner-3j tensor used for weight pre-packing (host double [(2l1+1)(2l2+1)(2l3+1)]). */
+int ddmi_wigner_3j(int l1, int l2, int l3, double* host_out);
+/* Name / duration table of the kernels launched by the last ddmi_forward when timing is on. */
+int ddmi_set_kernel_timing(ddmi_model* m, int enabled);
+int ddmi_kernel_timings(ddmi_model* m, int i, const char** name, double* ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDMI_H */

@@ -1,0 +1,255 @@
+"""Oracle restatement of models/cg_model.py CGModel.forward (score mode, eval).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Functional over a reference-keyed
+state_dict; `data` is a PyG-like hetero batch (diffdock_amd.hetero.HeteroBatch or a real
+torch_geometric Batch -- attribute access only).
+
+Line map (reference models/cg_model.py):
+  forward                 :308-424     embedding / ligand_embedding  :257-306
+  build_lig_conv_graph    :467-497     build_rec_conv_graph          :499-514
+  build_cross_conv_graph  :539-562     build_center_conv_graph       :610-623
+  build_bond_conv_graph   :625-639     get_edge_weight               :459-465
+Score-norm lookups: utils/so3.py:89-93, utils/torus.py:79-83 (tables are inputs).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .conformer import sinusoidal_embedding, t_to_sigma
+from .e3nn_lite import Irreps, FullTensorProduct, spherical_harmonics
+from .graph_ops import radius, radius_graph
+from .layers import TPConv, atom_encoder, gaussian_smearing, mlp2
+
+SO3_MIN_EPS, SO3_MAX_EPS, SO3_N_EPS = 0.0005, 4, 2000
+TORUS_SIGMA_MIN, TORUS_SIGMA_MAX, TORUS_SIGMA_N = 3e-3, 2, 5000
+
+
+def so3_score_norm(table, eps_t):
+    eps = eps_t.detach().cpu().float().numpy()
+    idx = (np.log10(eps) - np.log10(SO3_MIN_EPS)) / (np.log10(SO3_MAX_EPS) - np.log10(SO3_MIN_EPS)) * SO3_N_EPS
+    idx = np.clip(np.around(idx).astype(int), a_min=0, a_max=SO3_N_EPS - 1)
+    return torch.from_numpy(np.asarray(table)[idx]).float()
+
+
+def torus_score_norm(table, sigma_t):
+    sigma = sigma_t.detach().cpu().float().numpy()
+    s = np.log(sigma / np.pi)
+    s = (s - np.log(TORUS_SIGMA_MIN)) / (np.log(TORUS_SIGMA_MAX) - np.log(TORUS_SIGMA_MIN)) * TORUS_SIGMA_N
+    idx = np.round(np.clip(s, 0, TORUS_SIGMA_N)).astype(int)
+    return np.asarray(table)[idx]
+
+
+class CGModelOracle:
+    def __init__(self, cfg, state_dict, so3_table, torus_table, dtype=torch.float32):
+        self.cfg, self.dtype = cfg, dtype
+        self.sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in state_dict.items()}
+        self.so3_table, self.torus_table = so3_table, torus_table
+        c, sd = cfg, self.sd
+        self.sh_irreps = Irreps.spherical_harmonics(c.sh_lmax)
+        K, L = c.num_prot_emb_layers, c.num_conv_layers
+        mk = lambda name, i, groups: TPConv(sd, name, *self._io(i), residual=True, batch_norm=c.batch_norm,
+                                            faster=c.faster, edge_groups=groups)
+        self.rec_emb_layers = [mk(f"rec_emb_layers.{i}", i, 1) for i in range(K)]
+        self.lig_emb_layers = [mk(f"lig_emb_layers.{i}", i, 1) for i in range(K)] if c.embed_also_ligand else []
+        self.conv_layers = [mk(f"conv_layers.{l}", K + l, c.conv_groups(l)) for l in range(L)]
+        last_out = c.layer_irreps(K + L - 1)[1]
+        self.final_conv = TPConv(sd, "final_conv", last_out, self.sh_irreps,
+                                 "2x1o + 2x1e" if not c.odd_parity else "1x1o + 1x1e",
+                                 residual=False, batch_norm=c.batch_norm)
+        if not c.no_torsion:
+            self.final_tp_tor = FullTensorProduct(self.sh_irreps, "2e")
+            self.tor_bond_conv = TPConv(sd, "tor_bond_conv", last_out, self.final_tp_tor.irreps_out,
+                                        f"{c.ns}x0o + {c.ns}x0e" if not c.odd_parity else f"{c.ns}x0o",
+                                        residual=False, batch_norm=c.batch_norm)
+
+    def _io(self, i):
+        a, b = self.cfg.layer_irreps(i)
+        return a, self.sh_irreps, b
+
+    # ------------------------------------------------------------------ helpers
+    def _temb(self, t):
+        return sinusoidal_embedding(self.cfg.embedding_scale * t, self.cfg.sigma_embed_dim).to(self.dtype)
+
+    def _sh(self, vec, irreps=None):
+        return spherical_harmonics(irreps or self.sh_irreps, vec, normalize=True, normalization="component")
+
+    def _edge_weight(self, vec, max_norm):
+        if self.cfg.smooth_edges:
+            nn = torch.clip(vec.norm(dim=-1) * math.pi / max_norm, max=math.pi)
+            return 0.5 * (torch.cos(nn) + 1.0).unsqueeze(-1)
+        return 1.0
+
+    # ------------------------------------------------------------------ graph builders
+    def build_lig_conv_graph(self, data):
+        c, sd, lig = self.cfg, self.sd, data["ligand"]
+        pos = lig.pos.to(self.dtype)
+        lig.node_sigma_emb = self._temb(lig.node_t["tr"])
+        radius_edges = radius_graph(pos, c.lig_max_radius, lig.batch)
+        bond = data["ligand", "ligand"]
+        edge_index = torch.cat([bond.edge_index, radius_edges], 1).long()
+        edge_attr = torch.cat([bond.edge_attr.to(self.dtype),
+                               torch.zeros(radius_edges.shape[-1], c.in_lig_edge_features, dtype=self.dtype)], 0)
+        edge_attr = torch.cat([edge_attr, lig.node_sigma_emb[edge_index[0]]], 1)
+        node_attr = torch.cat([lig.x.to(self.dtype), lig.node_sigma_emb], 1)
+        src, dst = edge_index
+        vec = pos[dst] - pos[src]
+        edge_attr = torch.cat([edge_attr, gaussian_smearing(sd["lig_distance_expansion.offset"], vec.norm(dim=-1))], 1)
+        return node_attr, edge_index, edge_attr, self._sh(vec), self._edge_weight(vec, c.lig_max_radius)
+
+    def build_rec_conv_graph(self, data):
+        c, sd, rec = self.cfg, self.sd, data["receptor"]
+        pos = rec.pos.to(self.dtype)
+        src, dst = data["receptor", "receptor"].edge_index
+        vec = pos[dst] - pos[src]
+        edge_attr = gaussian_smearing(sd["rec_distance_expansion.offset"], vec.norm(dim=-1))
+        return rec.x.to(self.dtype), edge_attr, self._sh(vec), self._edge_weight(vec, c.rec_max_radius)
+
+    def build_cross_conv_graph(self, data, cutoff):
+        sd, lig, rec = self.sd, data["ligand"], data["receptor"]
+        lpos, rpos = lig.pos.to(self.dtype), rec.pos.to(self.dtype)
+        if torch.is_tensor(cutoff):
+            edge_index = radius(rpos / cutoff[rec.batch], lpos / cutoff[lig.batch], 1,
+                                rec.batch, lig.batch, max_num_neighbors=10000)
+        else:
+            edge_index = radius(rpos, lpos, cutoff, rec.batch, lig.batch, max_num_neighbors=10000)
+        src, dst = edge_index
+        vec = rpos[dst] - lpos[src]
+        edge_attr = torch.cat([lig.node_sigma_emb[src],
+                               gaussian_smearing(sd["cross_distance_expansion.offset"], vec.norm(dim=-1))], 1)
+        cutoff_d = cutoff[lig.batch[src]].squeeze() if torch.is_tensor(cutoff) else cutoff
+        return edge_index, edge_attr, self._sh(vec), self._sh(-vec), self._edge_weight(vec, cutoff_d)
+
+    def build_center_conv_graph(self, data):
+        sd, lig = self.sd, data["ligand"]
+        pos = lig.pos.to(self.dtype)
+        edge_index = torch.stack([lig.batch, torch.arange(len(lig.batch))], 0)
+        center = torch.zeros(data.num_graphs, 3, dtype=self.dtype)
+        center.index_add_(0, lig.batch, pos)
+        center = center / torch.bincount(lig.batch).unsqueeze(1)
+        vec = pos[edge_index[1]] - center[edge_index[0]]
+        edge_attr = gaussian_smearing(sd["center_distance_expansion.offset"], vec.norm(dim=-1))
+        edge_attr = torch.cat([edge_attr, lig.node_sigma_emb[edge_index[1]]], 1)
+        return edge_index, edge_attr, self._sh(vec)
+
+    def build_bond_conv_graph(self, data):
+        c, sd, lig = self.cfg, self.sd, data["ligand"]
+        pos = lig.pos.to(self.dtype)
+        bonds = data["ligand", "ligand"].edge_index[:, lig.edge_mask].long()
+        bond_pos = (pos[bonds[0]] + pos[bonds[1]]) / 2
+        edge_index = radius(pos, bond_pos, c.lig_max_radius, batch_x=lig.batch, batch_y=lig.batch[bonds[0]])
+        vec = pos[edge_index[1]] - bond_pos[edge_index[0]]
+        edge_attr = gaussian_smearing(sd["lig_distance_expansion.offset"], vec.norm(dim=-1))
+        edge_attr = mlp2(sd, "final_edge_embedding", edge_attr)
+        return bonds, edge_index, edge_attr, self._sh(vec), self._edge_weight(vec, c.lig_max_radius)
+
+    # ------------------------------------------------------------------ embeddings
+    def ligand_embedding(self, data):
+        ns, sd = self.cfg.ns, self.sd
+        node_attr, edge_index, edge_attr, edge_sh, ew = self.build_lig_conv_graph(data)
+        node_attr = atom_encoder(sd, "lig_node_embedding", node_attr, 16)
+        edge_attr = mlp2(sd, "lig_edge_embedding", edge_attr)
+        for layer in self.lig_emb_layers:
+            ea = torch.cat([edge_attr, node_attr[edge_index[0], :ns], node_attr[edge_index[1], :ns]], -1)
+            node_attr = layer(node_attr, edge_index, ea, edge_sh, edge_weight=ew)
+        return node_attr, edge_index, edge_attr, edge_sh, ew
+
+    def embedding(self, data):
+        ns, sd, rec = self.cfg.ns, self.sd, data["receptor"]
+        rr = data["receptor", "receptor"]
+        node_attr, edge_attr, edge_sh, ew = self.build_rec_conv_graph(data)
+        node_attr = atom_encoder(sd, "rec_node_embedding", node_attr, 1)
+        edge_attr = mlp2(sd, "rec_edge_embedding", edge_attr)
+        for layer in self.rec_emb_layers:
+            ea = torch.cat([edge_attr, node_attr[rr.edge_index[0], :ns], node_attr[rr.edge_index[1], :ns]], -1)
+            node_attr = layer(node_attr, rr.edge_index, ea, edge_sh, edge_weight=ew)
+        sig = mlp2(sd, "rec_sigma_embedding", self._temb(data.complex_t["tr"]))
+        node_attr = node_attr.clone()
+        node_attr[:, :ns] = node_attr[:, :ns] + sig[rec.batch]
+        edge_attr = edge_attr + sig[rec.batch[rr.edge_index[0]]]
+        return self.ligand_embedding(data) + (node_attr, rr.edge_index, edge_attr, edge_sh, ew)
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, data, return_intermediates=False):
+        c, sd, ns = self.cfg, self.sd, self.cfg.ns
+        lig = data["ligand"]
+        tr_sigma, rot_sigma, tor_sigma = t_to_sigma(c, *[data.complex_t[k] for k in ("tr", "rot", "tor")])
+        (lig_node_attr, lig_edge_index, lig_edge_attr, lig_edge_sh, lig_ew,
+         rec_node_attr, rec_edge_index, rec_edge_attr, rec_edge_sh, rec_ew) = self.embedding(data)
+
+        cutoff = (tr_sigma * 3 + 20).unsqueeze(1).to(self.dtype) if c.dynamic_max_cross else c.cross_max_distance
+        lr_edge_index, lr_edge_attr, lr_edge_sh, rev_lr_edge_sh, lr_ew = self.build_cross_conv_graph(data, cutoff)
+        lr_edge_attr = mlp2(sd, "cross_edge_embedding", lr_edge_attr)
+
+        n_lig = len(lig_node_attr)
+        node_attr = torch.cat([lig_node_attr, rec_node_attr], 0)
+        lr_edge_index = lr_edge_index.clone()
+        lr_edge_index[1] = lr_edge_index[1] + n_lig
+        edge_index = torch.cat([lig_edge_index, lr_edge_index, rec_edge_index + n_lig,
+                                torch.flip(lr_edge_index, dims=[0])], 1)
+        edge_attr = torch.cat([lig_edge_attr, lr_edge_attr, rec_edge_attr, lr_edge_attr], 0)
+        edge_sh = torch.cat([lig_edge_sh, lr_edge_sh, rec_edge_sh, rev_lr_edge_sh], 0)
+        if torch.is_tensor(lig_ew):
+            edge_weight = torch.cat([lig_ew, lr_ew, rec_ew, lr_ew], 0)
+        else:
+            edge_weight = torch.ones(edge_index.shape[1], 1, dtype=self.dtype)
+        s1 = lig_edge_index.shape[1]
+        s2 = s1 + lr_edge_index.shape[1]
+        s3 = s2 + rec_edge_index.shape[1]
+        inter = {"edge_counts": (s1, s2 - s1, s3 - s2), "node_attr0": node_attr.clone()} if return_intermediates else None
+
+        L = len(self.conv_layers)
+        for l, layer in enumerate(self.conv_layers):
+            if l < L - 1:
+                ea = torch.cat([edge_attr, node_attr[edge_index[0], :ns], node_attr[edge_index[1], :ns]], -1)
+                if c.differentiate_convolutions:
+                    ea = [ea[:s1], ea[s1:s2], ea[s2:s3], ea[s3:]]
+                node_attr = layer(node_attr, edge_index, ea, edge_sh, edge_weight=edge_weight)
+            else:
+                ea = torch.cat([edge_attr[:s2], node_attr[edge_index[0, :s2], :ns], node_attr[edge_index[1, :s2], :ns]], -1)
+                if c.differentiate_convolutions:
+                    ea = [ea[:s1], ea[s1:s2]]
+                node_attr = layer(node_attr, edge_index[:, :s2], ea, edge_sh[:s2], edge_weight=edge_weight[:s2])
+            if inter is not None:
+                inter[f"node_attr{l + 1}"] = node_attr.clone()
+        lig_node_attr = node_attr[:n_lig]
+
+        cei, cea, csh = self.build_center_conv_graph(data)
+        cea = mlp2(sd, "center_edge_embedding", cea)
+        cea = torch.cat([cea, lig_node_attr[cei[1 if c.fixed_center_conv else 0], :ns]], -1)
+        global_pred = self.final_conv(lig_node_attr, cei, cea, csh, out_nodes=data.num_graphs)
+        tr_pred = global_pred[:, :3] + (global_pred[:, 6:9] if not c.odd_parity else 0)
+        rot_pred = global_pred[:, 3:6] + (global_pred[:, 9:] if not c.odd_parity else 0)
+        graph_sigma_emb = self._temb(data.complex_t["tr"])
+        tr_norm = torch.linalg.vector_norm(tr_pred, dim=1).unsqueeze(1)
+        tr_pred = tr_pred / tr_norm * mlp2(sd, "tr_final_layer", torch.cat([tr_norm, graph_sigma_emb], 1))
+        rot_norm = torch.linalg.vector_norm(rot_pred, dim=1).unsqueeze(1)
+        rot_pred = rot_pred / rot_norm * mlp2(sd, "rot_final_layer", torch.cat([rot_norm, graph_sigma_emb], 1))
+        if c.scale_by_sigma:
+            tr_pred = tr_pred / tr_sigma.unsqueeze(1).to(self.dtype)
+            rot_pred = rot_pred * so3_score_norm(self.so3_table, rot_sigma).unsqueeze(1).to(self.dtype)
+        if inter is not None:
+            inter["global_pred"] = global_pred
+
+        if c.no_torsion or int(lig.edge_mask.sum()) == 0:
+            out = (tr_pred, rot_pred, torch.empty(0, dtype=self.dtype), None)
+            return out + (inter,) if return_intermediates else out
+
+        pos = lig.pos.to(self.dtype)
+        tor_bonds, tei, tea, tsh, tew = self.build_bond_conv_graph(data)
+        bond_vec = pos[tor_bonds[1]] - pos[tor_bonds[0]]
+        bond_attr = lig_node_attr[tor_bonds[0]] + lig_node_attr[tor_bonds[1]]
+        bonds_sh = self._sh(bond_vec, "2e")
+        tsh = self.final_tp_tor(tsh, bonds_sh[tei[0]])
+        tea = torch.cat([tea, lig_node_attr[tei[1], :ns], bond_attr[tei[0], :ns]], -1)
+        tor_pred = self.tor_bond_conv(lig_node_attr, tei, tea, tsh, out_nodes=int(lig.edge_mask.sum()),
+                                      reduce="mean", edge_weight=tew)
+        if inter is not None:
+            inter["tor_conv"] = tor_pred
+        tor_pred = torch.tanh(tor_pred @ sd["tor_final_layer.0.weight"].T) @ sd["tor_final_layer.3.weight"].T
+        tor_pred = tor_pred.squeeze(1)
+        edge_sigma = tor_sigma[lig.batch][data["ligand", "ligand"].edge_index[0]][lig.edge_mask]
+        if c.scale_by_sigma:
+            tor_pred = tor_pred * torch.sqrt(torch.tensor(torus_score_norm(self.torus_table, edge_sigma)).float()).to(self.dtype)
+        out = (tr_pred, rot_pred, tor_pred, None)
+        return out + (inter,) if return_intermediates else out

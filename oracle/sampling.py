@@ -1,0 +1,127 @@
+"""Oracle restatement of the reverse-diffusion loop, utils/sampling.py:69-240.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Differences from the reference,
+all input-side: (a) the Gaussian draws z_tr / z_rot / z_tor are injected (the reference
+consumes the global torch RNG, sampling.py:140-154), (b) confidence model, visualisation
+and crop_beyond (sampling.py:104-109, a "next" row) are not restated.
+Per-step update formulas: sampling.py:133-186; pose update: oracle/conformer.py.
+"""
+import numpy as np
+import torch
+
+from diffdock_amd.hetero import HeteroBatch, set_time  # data containers only
+from .conformer import modify_conformer_batch, t_to_sigma, get_t_schedule
+
+
+def _is_iterable(x):
+    try:
+        iter(x)
+        return True
+    except TypeError:
+        return False
+
+
+def perturbations(cfg, t_idx, inference_steps, schedules, scores, noise, ode=False, no_random=False,
+                  no_final_step_noise=False, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5):
+    """One step of utils/sampling.py:97-186: returns (tr_perturb, rot_perturb, tor_perturb)."""
+    tr_schedule, rot_schedule, tor_schedule = schedules
+    tr_score, rot_score, tor_score = scores
+    t_tr, t_rot, t_tor = tr_schedule[t_idx], rot_schedule[t_idx], tor_schedule[t_idx]
+    last = t_idx == inference_steps - 1
+    dt_tr = tr_schedule[t_idx] - tr_schedule[t_idx + 1] if not last else tr_schedule[t_idx]
+    dt_rot = rot_schedule[t_idx] - rot_schedule[t_idx + 1] if not last else rot_schedule[t_idx]
+    dt_tor = tor_schedule[t_idx] - tor_schedule[t_idx + 1] if not last else tor_schedule[t_idx]
+    tr_sigma, rot_sigma, tor_sigma = t_to_sigma(cfg, t_tr, t_rot, t_tor)
+    tr_g = tr_sigma * torch.sqrt(torch.tensor(2 * np.log(cfg.tr_sigma_max / cfg.tr_sigma_min)))
+    rot_g = rot_sigma * torch.sqrt(torch.tensor(2 * np.log(cfg.rot_sigma_max / cfg.rot_sigma_min)))
+    zero = no_random or (no_final_step_noise and last)
+    z_tr, z_rot, z_tor = noise
+    tr_z = torch.zeros_like(tr_score) if zero else z_tr
+    rot_z = torch.zeros_like(rot_score) if zero else z_rot
+    if ode:
+        tr_perturb = 0.5 * tr_g ** 2 * dt_tr * tr_score
+        rot_perturb = 0.5 * rot_score * dt_rot * rot_g ** 2
+    else:
+        tr_perturb = tr_g ** 2 * dt_tr * tr_score + tr_g * np.sqrt(dt_tr) * tr_z
+        rot_perturb = rot_score * dt_rot * rot_g ** 2 + rot_g * np.sqrt(dt_rot) * rot_z
+    tor_perturb = None
+    if not cfg.no_torsion:
+        tor_g = tor_sigma * torch.sqrt(torch.tensor(2 * np.log(cfg.tor_sigma_max / cfg.tor_sigma_min)))
+        tor_z = torch.zeros_like(tor_score) if zero else z_tor
+        if ode:
+            tor_perturb = 0.5 * tor_g ** 2 * dt_tor * tor_score
+        else:
+            tor_perturb = tor_g ** 2 * dt_tor * tor_score + tor_g * np.sqrt(dt_tor) * tor_z
+    ts = list(temp_sampling) if _is_iterable(temp_sampling) else [temp_sampling] * 3
+    tp = list(temp_psi) if _is_iterable(temp_psi) else [temp_psi] * 3
+    td = list(temp_sigma_data) if _is_iterable(temp_sigma_data) else [temp_sigma_data] * 3
+    if ts[0] != 1.0:
+        sd_ = np.exp(td[0] * np.log(cfg.tr_sigma_max) + (1 - td[0]) * np.log(cfg.tr_sigma_min))
+        lam = (sd_ + tr_sigma) / (sd_ + tr_sigma / ts[0])
+        tr_perturb = tr_g ** 2 * dt_tr * (lam + ts[0] * tp[0] / 2) * tr_score + tr_g * np.sqrt(dt_tr * (1 + tp[0])) * tr_z
+    if ts[1] != 1.0:
+        sd_ = np.exp(td[1] * np.log(cfg.rot_sigma_max) + (1 - td[1]) * np.log(cfg.rot_sigma_min))
+        lam = (sd_ + rot_sigma) / (sd_ + rot_sigma / ts[1])
+        rot_perturb = rot_g ** 2 * dt_rot * (lam + ts[1] * tp[1] / 2) * rot_score + rot_g * np.sqrt(dt_rot * (1 + tp[1])) * rot_z
+    if ts[2] != 1.0 and not cfg.no_torsion:
+        sd_ = np.exp(td[2] * np.log(cfg.tor_sigma_max) + (1 - td[2]) * np.log(cfg.tor_sigma_min))
+        lam = (sd_ + tor_sigma) / (sd_ + tor_sigma / ts[2])
+        tor_perturb = tor_g ** 2 * dt_tor * (lam + ts[2] * tp[2] / 2) * tor_score + tor_g * np.sqrt(dt_tor * (1 + tp[2])) * tor_z
+    return tr_perturb, rot_perturb, tor_perturb
+
+
+def nan_guard(tr_score, rot_score, tor_score):
+    """utils/sampling.py:117-131."""
+    mean_scores = torch.mean(tr_score, dim=-1)
+    if torch.sum(torch.isnan(mean_scores)) > 0:
+        for s in (tr_score, rot_score, tor_score):
+            eps = 0.01 * torch.nanmean(s.abs())
+            s.nan_to_num_(nan=eps, posinf=eps, neginf=-eps)
+    return tr_score, rot_score, tor_score
+
+
+def rot_edges_of(batch, B):
+    M = batch["ligand", "ligand"].num_edges // B
+    ei = batch["ligand", "ligand"].edge_index[:, :M]
+    em = batch["ligand"].edge_mask[:M]
+    return ei.T[em]
+
+
+def sampling(data_list, model, inference_steps, cfg, noise, schedules=None, batch_size=32, ode=False,
+             no_random=False, no_final_step_noise=False, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5,
+             record=None):
+    """noise = (z_tr [steps,N,3], z_rot [steps,N,3], z_tor [steps,N*R]) for ALL N samples in
+    data_list order.  Returns data_list with updated ligand positions."""
+    N = len(data_list)
+    if schedules is None:
+        s = get_t_schedule(inference_steps)
+        schedules = (s, s, s)
+    mask_rotate = torch.from_numpy(np.asarray(data_list[0]["ligand"].mask_rotate[0]))
+    R = mask_rotate.shape[0]
+    z_tr, z_rot, z_tor = noise
+    with torch.no_grad():
+        for lo in range(0, N, batch_size):
+            chunk = data_list[lo:lo + batch_size]
+            batch = HeteroBatch.from_data_list(chunk)
+            b = batch.num_graphs
+            n = batch["ligand"].pos.shape[0] // b
+            rot_edges = rot_edges_of(batch, b)
+            for t_idx in range(inference_steps):
+                t_tr, t_rot, t_tor = (s[t_idx] for s in schedules)
+                set_time(batch, t_tr, t_rot, t_tor, b)
+                tr_score, rot_score, tor_score = model(batch)[:3]
+                tr_score, rot_score, tor_score = nan_guard(tr_score, rot_score, tor_score)
+                zs = (z_tr[t_idx, lo:lo + b], z_rot[t_idx, lo:lo + b],
+                      z_tor[t_idx, lo * R:(lo + b) * R] if R > 0 else tor_score)
+                trp, rotp, torp = perturbations(cfg, t_idx, inference_steps, schedules,
+                                                (tr_score, rot_score, tor_score), zs, ode, no_random,
+                                                no_final_step_noise, temp_sampling, temp_psi, temp_sigma_data)
+                if record is not None:
+                    record.append(dict(t_idx=t_idx, lo=lo, pos_in=batch["ligand"].pos.clone(), tr=tr_score.clone(),
+                                       rot=rot_score.clone(), tor=tor_score.clone()))
+                batch["ligand"].pos = modify_conformer_batch(
+                    batch["ligand"].pos, b, rot_edges, mask_rotate, trp.float(), rotp.float(),
+                    torp.float() if (torp is not None and R > 0) else None).float()
+            for i in range(b):
+                data_list[lo + i]["ligand"].pos = batch["ligand"].pos[i * n:(i + 1) * n]
+    return data_list

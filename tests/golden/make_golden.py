@@ -1,0 +1,230 @@
+"""Generate tests/golden/*.pt by EXECUTING the reference's own python.
+
+Run in THIS container from the repo root (the reference is absent on the GPU box):
+    python tests/golden/make_golden.py
+
+The reference (gcorso/DiffDock @ /root/reference) cannot be imported as is: its
+third-party deps e3nn / torch_scatter / torch_cluster / torch_geometric / rdkit / esm /
+prody / Bio are not installed.  This script registers stand-ins for exactly those
+third-party modules (e3nn + torch_cluster + torch_scatter -> oracle/e3nn_lite.py and
+oracle/graph_ops.py, i.e. the restated third-party arithmetic; torch_geometric ->
+diffdock_amd/hetero.py containers; rdkit/esm/prody/Bio -> MagicMock, never called) and
+then runs the reference's OWN files unmodified:
+
+    models/cg_model.py, models/tensor_layers.py, models/layers.py, utils/utils.py
+    (get_model), utils/diffusion_utils.py, utils/torsion.py, utils/geometry.py,
+    utils/sampling.py, utils/so3.py, utils/torus.py
+
+One reference defect is patched: FasterTensorProduct has `out_irreps` but
+tp_scatter_multigroup reads `tp.irreps_out` (models/tensor_layers.py:194), so
+sh_lmax=1 + differentiate_convolutions crashes in the reference; an alias property is
+added so that combination can be pinned too.
+
+Fixtures hold inputs, weights, injected noise and the reference outputs, so the parity
+tests need neither /root/reference nor this script.
+"""
+import argparse
+import copy
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def install_stubs():
+    from oracle import e3nn_lite, graph_ops
+    from diffdock_amd import hetero
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    o3 = mod("e3nn.o3", Irreps=e3nn_lite.Irreps, Irrep=e3nn_lite.Irrep,
+             spherical_harmonics=e3nn_lite.spherical_harmonics,
+             FullyConnectedTensorProduct=e3nn_lite.FullyConnectedTensorProduct,
+             FullTensorProduct=e3nn_lite.FullTensorProduct,
+             TensorProduct=MagicMock(), Linear=MagicMock(), wigner_3j=e3nn_lite.wigner_3j)
+    enn = mod("e3nn.nn", BatchNorm=e3nn_lite.BatchNorm)
+    mod("e3nn", o3=o3, nn=enn)
+    mod("torch_scatter", scatter=graph_ops.scatter, scatter_mean=graph_ops.scatter_mean)
+    mod("torch_cluster", radius=graph_ops.radius, radius_graph=graph_ops.radius_graph, knn_graph=MagicMock())
+
+    def subgraph(subset, edge_index, relabel_nodes=False, **kw):
+        keep = subset[edge_index[0]] & subset[edge_index[1]]
+        ei = edge_index[:, keep]
+        if relabel_nodes:
+            remap = torch.cumsum(subset.long(), 0) - 1
+            ei = remap[ei]
+        return ei, None
+
+    tg = mod("torch_geometric")
+    tg.data = mod("torch_geometric.data", Batch=hetero.HeteroBatch, Data=MagicMock(), HeteroData=hetero.HeteroData,
+                  Dataset=object)
+    tg.loader = mod("torch_geometric.loader", DataLoader=hetero.DataLoader, DataListLoader=MagicMock())
+    tg.utils = mod("torch_geometric.utils", subgraph=subgraph, degree=MagicMock(), to_networkx=MagicMock())
+    tg.nn = mod("torch_geometric.nn")
+    tg.nn.data_parallel = mod("torch_geometric.nn.data_parallel", DataParallel=MagicMock())
+    for name in ["rdkit", "rdkit.Chem", "rdkit.Chem.rdchem", "rdkit.Geometry", "rdkit.Chem.AllChem",
+                 "rdkit.Chem.rdMolTransforms", "rdkit.RDLogger", "esm", "esm.pretrained", "prody", "Bio", "Bio.PDB",
+                 "spyrmsd"]:
+        sys.modules[name] = MagicMock()
+    sys.path.insert(0, REF)
+
+
+def build_case(cfg, n_res, n_lig, n_samples, seed, t):
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    g = make_complex(seed=seed, n_res=n_res, n_lig=n_lig)
+    data_list = make_pose_list(g, n_samples, tr_sigma_max=cfg.tr_sigma_max, seed=seed + 100)
+    sd = init_state_dict(cfg, seed=1234 + seed)
+    return g, data_list, sd
+
+
+def graph_to_dict(g):
+    return {"rec_x": g["receptor"].x, "rec_pos": g["receptor"].pos,
+            "rec_edge_index": g["receptor", "receptor"].edge_index,
+            "lig_x": g["ligand"].x, "lig_pos": g["ligand"].pos, "edge_mask": g["ligand"].edge_mask,
+            "mask_rotate": torch.from_numpy(np.asarray(g["ligand"].mask_rotate[0])),
+            "bond_index": g["ligand", "ligand"].edge_index, "bond_attr": g["ligand", "ligand"].edge_attr}
+
+
+def main():
+    scratch = os.path.join(ROOT, ".scratch", "tables")
+    os.makedirs(scratch, exist_ok=True)
+    os.chdir(scratch)           # utils/so3.py, utils/torus.py cache .npy in the CWD
+    install_stubs()
+    np.random.seed(0)           # utils/torus.py:72-76 Monte-Carlo at import
+    from utils import so3, torus
+    # the committed table fixtures must be the ones the reference modules hold right now
+    assert np.array_equal(np.load(os.path.join(HERE, "so3_exp_score_norms.npy")), so3._exp_score_norms)
+    assert np.array_equal(np.load(os.path.join(HERE, "torus_score_norm.npy")), torus.score_norm_)
+
+    from functools import partial
+    from models import tensor_layers
+    tensor_layers.FasterTensorProduct.irreps_out = property(lambda self: self.out_irreps)  # reference defect, see header
+    from utils.utils import get_model, crop_beyond
+    from utils.diffusion_utils import t_to_sigma as t_to_sigma_compl, get_t_schedule, set_time
+    from utils import sampling as ref_sampling
+    from diffdock_amd.config import TINY
+    from diffdock_amd.hetero import HeteroBatch
+    from diffdock_amd.weights import state_dict_spec
+
+    cases = {
+        "tiny_l1": dict(cfg=TINY, n_res=40, n_lig=12, n_samples=3, seed=0, t=0.7),
+        "tiny_l2": dict(cfg=TINY.replace(sh_lmax=2), n_res=36, n_lig=14, n_samples=2, seed=1, t=0.35),
+        "tiny_l1_1group_emb": dict(cfg=TINY.replace(differentiate_convolutions=False, num_prot_emb_layers=2,
+                                                      num_conv_layers=3, smooth_edges=True),
+                                   n_res=30, n_lig=10, n_samples=2, seed=2, t=0.9),
+        "tiny_l2_fixedcenter": dict(cfg=TINY.replace(sh_lmax=2, fixed_center_conv=True, dynamic_max_cross=False,
+                                                      cross_max_distance=30.0, reduce_pseudoscalars=True),
+                                    n_res=32, n_lig=11, n_samples=2, seed=3, t=0.5),
+    }
+    for name, c in cases.items():
+        cfg = c["cfg"]
+        args = cfg.to_namespace()
+        if cfg.fixed_center_conv:
+            args.not_fixed_center_conv = False
+        t_to_sigma = partial(t_to_sigma_compl, args=args)
+        model = get_model(args, torch.device("cpu"), t_to_sigma=t_to_sigma, no_parallel=True)
+        g, data_list, sd = build_case(cfg, c["n_res"], c["n_lig"], c["n_samples"], c["seed"], c["t"])
+        ref_keys = {k for k in model.state_dict().keys()}
+        assert ref_keys == set(state_dict_spec(cfg).keys()), (sorted(ref_keys ^ set(state_dict_spec(cfg).keys())))
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+
+        # ---- single forward at time t, with per-layer node tables via hooks
+        batch = HeteroBatch.from_data_list(copy.deepcopy(data_list))
+        B = batch.num_graphs
+        set_time(batch, None, c["t"], c["t"], c["t"], B, False, torch.device("cpu"))
+        layer_out = []
+        hooks = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone())) for l in model.conv_layers]
+        with torch.no_grad():
+            tr, rot, tor, _ = model(batch)
+        for h in hooks:
+            h.remove()
+        fixture = {"cfg": cfg.__dict__.copy(), "graph": graph_to_dict(g),
+                   "poses": torch.stack([d["ligand"].pos for d in data_list]), "t": c["t"],
+                   "state_dict": {k: v.clone() for k, v in sd.items()},
+                   "forward": {"tr": tr, "rot": rot, "tor": tor, "conv_out": layer_out}}
+
+        # ---- reference sampling() with recorded Gaussian draws
+        steps = 4
+        draws = []
+        real_normal = torch.normal
+
+        def rec_normal(*a, **kw):
+            z = real_normal(*a, **kw)
+            draws.append(z.clone())
+            return z
+        torch.manual_seed(7)
+        ref_sampling.torch.normal = rec_normal
+        sched = get_t_schedule("expbeta", steps)
+        dl = copy.deepcopy(data_list)
+        temp = dict(temp_sampling=[1.17, 2.06, 7.04], temp_psi=[0.73, 0.90, 0.59], temp_sigma_data=[0.93, 0.75, 0.69]) \
+            if name == "tiny_l1" else {}
+        try:
+            out_list, _ = ref_sampling.sampling(dl, model, steps, sched, sched, sched, torch.device("cpu"), t_to_sigma, args,
+                                                batch_size=B, no_final_step_noise=True, **temp)
+        finally:
+            ref_sampling.torch.normal = real_normal
+        fixture["sampling"] = {"steps": steps, "temp": temp, "draws": draws,
+                               "final_pos": torch.stack([d["ligand"].pos for d in out_list])}
+        torch.save(fixture, os.path.join(HERE, f"{name}.pt"))
+        print(name, "tr", tr[0].tolist(), "tor", tor[:3].tolist(), "n_draws", len(draws))
+
+    # ---- crop_beyond (utils/utils.py:388-413) on one complex
+    from diffdock_amd.synth import make_complex, make_pose_list
+    g = make_complex(seed=5, n_res=60, n_lig=10)
+    d = make_pose_list(g, 1, seed=11)[0]
+    dd = copy.deepcopy(d)
+    crop_beyond(dd, 18.0, False)
+    torch.save({"graph": graph_to_dict(d), "cutoff": 18.0, "rec_pos": dd["receptor"].pos,
+                "rec_edge_index": dd["receptor", "receptor"].edge_index}, os.path.join(HERE, "crop_beyond.pt"))
+
+    # ---- geometry / torsion / FasterTensorProduct unit fixtures straight from the reference
+    from utils.geometry import axis_angle_to_matrix, rigid_transform_Kabsch_3D_torch_batch
+    from utils.diffusion_utils import modify_conformer_batch, sinusoidal_embedding
+    from models.layers import GaussianSmearing
+    gen = torch.Generator().manual_seed(3)
+    aa = torch.randn(16, 3, generator=gen)
+    aa[0] = 0
+    aa[1] = 1e-7
+    A = torch.randn(5, 9, 3, generator=gen)
+    Bm = torch.randn(5, 9, 3, generator=gen)
+    R, tt = rigid_transform_Kabsch_3D_torch_batch(A, Bm)
+    dl = make_pose_list(g, 4, seed=12)
+    batch = HeteroBatch.from_data_list(copy.deepcopy(dl))
+    nb = batch.num_graphs
+    Rr = int(batch["ligand"].edge_mask.sum()) // nb
+    tru, rou, tou = torch.randn(nb, 3, generator=gen), torch.randn(nb, 3, generator=gen) * 0.3, torch.randn(nb * Rr, generator=gen)
+    mask_rotate = torch.from_numpy(dl[0]["ligand"].mask_rotate[0])
+    newpos = modify_conformer_batch(batch["ligand"].pos, batch, tru, rou, tou, mask_rotate)
+    ftp = tensor_layers.FasterTensorProduct("8x0e + 3x1o + 3x1e + 8x0o", "1x0e+1x1o", "8x0e + 3x1o + 3x1e + 8x0o")
+    x = torch.randn(7, 8 + 9 + 9 + 8, generator=gen)
+    sh = torch.randn(7, 4, generator=gen)
+    w = torch.randn(7, ftp.weight_numel, generator=gen)
+    ts = torch.tensor([0.0, 0.05, 0.5, 1.0])
+    gs = GaussianSmearing(0.0, 5.0, 16)
+    dist = torch.rand(9, generator=gen) * 6
+    torch.save({"axis_angle": aa, "rot_mats": axis_angle_to_matrix(aa), "kabsch_A": A, "kabsch_B": Bm, "kabsch_R": R,
+                "kabsch_t": tt, "mc_graph": graph_to_dict(g), "mc_pos_in": batch["ligand"].pos.clone(), "mc_tr": tru,
+                "mc_rot": rou, "mc_tor": tou, "mc_pos_out": newpos,
+                "ftp_x": x, "ftp_sh": sh, "ftp_w": w, "ftp_out": ftp(x, sh, w),
+                "sin_t": ts, "sin_emb": sinusoidal_embedding(1000.0 * ts, 16),
+                "gs_dist": dist, "gs_out": gs(dist), "t_schedule_20": torch.from_numpy(get_t_schedule("expbeta", 20))},
+               os.path.join(HERE, "units.pt"))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

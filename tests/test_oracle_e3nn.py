@@ -1,0 +1,175 @@
+"""Pins for the restated third-party (e3nn) arithmetic in oracle/e3nn_lite.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import e3nn_lite as e3
+from oracle.layers import faster_tensor_product, faster_weight_numel
+
+torch.manual_seed(0)
+
+
+def rand_rot(gen):
+    q = torch.randn(4, generator=gen, dtype=torch.float64)
+    q = q / q.norm()
+    w, x, y, z = q
+    return torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)]),
+                        torch.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)]),
+                        torch.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)])])
+
+
+def test_w3j_known_values():
+    """Constants hard-coded in the reference's FasterTensorProduct (tensor_layers.py:78-90)."""
+    eye = torch.eye(3, dtype=torch.float64)
+    assert torch.allclose(e3.wigner_3j(0, 0, 0), torch.ones(1, 1, 1, dtype=torch.float64))
+    assert torch.allclose(e3.wigner_3j(1, 1, 0)[:, :, 0], eye / math.sqrt(3))
+    assert torch.allclose(e3.wigner_3j(0, 1, 1)[0], eye / math.sqrt(3))
+    assert torch.allclose(e3.wigner_3j(1, 0, 1)[:, 0, :], eye / math.sqrt(3))
+    eps = torch.zeros(3, 3, 3, dtype=torch.float64)
+    eps[0, 1, 2] = eps[1, 2, 0] = eps[2, 0, 1] = 1
+    eps[0, 2, 1] = eps[2, 1, 0] = eps[1, 0, 2] = -1
+    assert torch.allclose(e3.wigner_3j(1, 1, 1), eps / math.sqrt(6))
+
+
+def test_su2_cg_matches_sympy():
+    from sympy.physics.wigner import clebsch_gordan
+    for (j1, j2, j3) in [(1, 1, 2), (1, 2, 1), (2, 2, 2), (1, 2, 3), (2, 1, 1)]:
+        for m1 in range(-j1, j1 + 1):
+            for m2 in range(-j2, j2 + 1):
+                m3 = m1 + m2
+                if abs(m3) <= j3:
+                    assert abs(e3._su2_cg_coeff(j1, m1, j2, m2, j3, m3) - float(clebsch_gordan(j1, j2, j3, m1, m2, m3))) < 1e-12
+
+
+@pytest.mark.parametrize("ls", [(1, 1, 2), (1, 2, 1), (2, 1, 1), (1, 2, 3), (2, 2, 2), (1, 2, 2)])
+def test_w3j_equivariant_and_sh_consistent(ls):
+    """w3j is an invariant tensor under the Wigner-D matrices induced by the l=1 (x,y,z)
+    representation; D_l is recovered from the SH themselves (Y_l(Rv) = D_l Y_l(v))."""
+    gen = torch.Generator().manual_seed(1)
+    R = rand_rot(gen)
+
+    def D(l):
+        if l == 0:
+            return torch.ones(1, 1, dtype=torch.float64)
+        if l == 1:
+            return R
+        v = torch.randn(40, 3, generator=gen, dtype=torch.float64)
+        if l == 2:
+            Y, YR = e3.spherical_harmonics([2], v), e3.spherical_harmonics([2], v @ R.T)
+            return torch.linalg.lstsq(Y, YR).solution.T
+        # l=3 via coupling 1 x 2 -> 3
+        C = e3.wigner_3j(1, 2, 3)
+        Y = torch.einsum("ni,nj,ijk->nk", e3.spherical_harmonics([1], v), e3.spherical_harmonics([2], v), C)
+        YR = torch.einsum("ni,nj,ijk->nk", e3.spherical_harmonics([1], v @ R.T), e3.spherical_harmonics([2], v @ R.T), C)
+        return torch.linalg.lstsq(Y, YR).solution.T
+    l1, l2, l3 = ls
+    C = e3.wigner_3j(l1, l2, l3)
+    C2 = torch.einsum("ai,bj,ck,ijk->abc", D(l1), D(l2), D(l3), C)
+    assert torch.allclose(C, C2, atol=1e-9)
+
+
+def test_sh_l2_is_positive_multiple_of_coupled_l1():
+    v = torch.randn(10, 3, dtype=torch.float64)
+    y1 = e3.spherical_harmonics([1], v)
+    y2 = e3.spherical_harmonics([2], v)
+    c = torch.einsum("ni,nj,ijk->nk", y1, y1, e3.wigner_3j(1, 1, 2))
+    ratio = (c * y2).sum() / (y2 * y2).sum()
+    assert ratio > 0 and torch.allclose(c, ratio * y2, atol=1e-12)
+    assert torch.allclose((y2 ** 2).sum(-1), torch.full((10,), 5.0, dtype=torch.float64))  # component norm
+
+
+def test_faster_tp_equals_fctp_after_slot_remap():
+    """FullyConnectedTensorProduct == FasterTensorProduct for l<=1."""
+    ns, nv = 6, 3
+    irr = f"{ns}x0e + {nv}x1o + {nv}x1e + {ns}x0o"
+    sh_irr = "1x0e + 1x1o"
+    tp = e3.FullyConnectedTensorProduct(irr, sh_irr, irr)
+    E = 5
+    x = torch.randn(E, 2 * ns + 6 * nv, dtype=torch.float64)
+    sh = e3.spherical_harmonics(e3.Irreps(sh_irr), torch.randn(E, 3, dtype=torch.float64))
+    wf = torch.randn(E, faster_weight_numel(irr, irr), dtype=torch.float64)
+    assert tp.weight_numel == wf.shape[1]
+    # remap Faster's per-output-type [fan_in, mul_out] matrices onto FCTP's slots
+    im = {"0e": ns, "1o": nv, "1e": nv, "0o": ns}
+    terms = {"0e": ("0e", "1o"), "1o": ("0e", "1o", "1e"), "1e": ("1o", "1e", "0o"), "0o": ("1e", "0o")}
+    off, fw = 0, {}
+    for t in ("0e", "1o", "1e", "0o"):
+        fan = sum(im[s] for s in terms[t])
+        mat = wf[:, off:off + fan * im[t]].reshape(E, fan, im[t])
+        off += fan * im[t]
+        r = 0
+        for s in terms[t]:
+            fw[(s, t)] = mat[:, r:r + im[s]]
+            r += im[s]
+    w = torch.zeros(E, tp.weight_numel, dtype=torch.float64)
+    o = 0
+    for (i1, i2, io), (m1, m2, mo) in zip(tp.instructions, tp.slot_shapes):
+        s, t = str(tp.irreps_in1[i1].ir), str(tp.irreps_out[io].ir)
+        w[:, o:o + m1 * m2 * mo] = fw[(s, t)].reshape(E, -1)
+        o += m1 * m2 * mo
+    a = faster_tensor_product(irr, irr, x, sh, wf)
+    b = tp(x, sh, w)
+    assert torch.allclose(a, b, atol=1e-12), (a - b).abs().max()
+
+
+def test_fctp_equivariance_lmax2():
+    gen = torch.Generator().manual_seed(2)
+    R = rand_rot(gen)
+    irr = "4x0e + 2x1o + 2x1e + 4x0o"
+    shi = e3.Irreps.spherical_harmonics(2)
+    tp = e3.FullyConnectedTensorProduct(irr, shi, irr)
+    E = 6
+    x = torch.randn(E, 4 + 6 + 6 + 4, generator=gen, dtype=torch.float64)
+    v = torch.randn(E, 3, generator=gen, dtype=torch.float64)
+    w = torch.randn(E, tp.weight_numel, generator=gen, dtype=torch.float64)
+
+    def rot_feat(f):
+        f = f.clone()
+        f[:, 4:10] = (f[:, 4:10].reshape(E, 2, 3) @ R.T).reshape(E, 6)
+        f[:, 10:16] = (f[:, 10:16].reshape(E, 2, 3) @ R.T).reshape(E, 6)
+        return f
+    a = tp(rot_feat(x), e3.spherical_harmonics(shi, v @ R.T), w)
+    b = rot_feat(tp(x, e3.spherical_harmonics(shi, v), w))
+    assert torch.allclose(a, b, atol=1e-10)
+    # parity: improper rotation flips 1o and 0o blocks
+    P = -torch.eye(3, dtype=torch.float64)
+    xm = x.clone()
+    xm[:, 4:10] *= -1
+    xm[:, 16:] *= -1
+    am = tp(xm, e3.spherical_harmonics(shi, v @ P.T), w)
+    bm = tp(x, e3.spherical_harmonics(shi, v), w)
+    bm[:, 4:10] *= -1
+    bm[:, 16:] *= -1
+    assert torch.allclose(am, bm, atol=1e-10)
+
+
+def test_full_tensor_product_irreps_and_norm():
+    ftp = e3.FullTensorProduct(e3.Irreps.spherical_harmonics(1), "2e")
+    assert str(ftp.irreps_out) == "1x1o+1x2o+1x2e+1x3o"
+    ftp2 = e3.FullTensorProduct(e3.Irreps.spherical_harmonics(2), "2e")
+    assert ftp2.irreps_out.dim == 45
+    v = torch.randn(8, 3, dtype=torch.float64)
+    b = torch.randn(8, 3, dtype=torch.float64)
+    out = ftp(e3.spherical_harmonics(e3.Irreps.spherical_harmonics(1), v), e3.spherical_harmonics("2e", b))
+    assert out.shape == (8, 20)
+    # the 0e (x) 2e -> 2e block is sqrt(5) * w3j(0,2,2) * Y2 = Y2
+    assert torch.allclose(out[:, 8:13], e3.spherical_harmonics("2e", b), atol=1e-12)
+
+
+def test_batch_norm_closed_form():
+    irr = e3.Irreps("3x0e + 2x1o + 2x0o")
+    x = torch.randn(5, 3 + 6 + 2, dtype=torch.float64)
+    rm, rv = torch.randn(3, dtype=torch.float64), torch.rand(7, dtype=torch.float64) + 0.5
+    w, b = torch.randn(7, dtype=torch.float64), torch.randn(3, dtype=torch.float64)
+    y = e3.batch_norm_eval(irr, x, rm, rv, w, b)
+    s = w / torch.sqrt(rv + 1e-5)
+    assert torch.allclose(y[:, :3], (x[:, :3] - rm) * s[:3] + b)
+    assert torch.allclose(y[:, 3:9], x[:, 3:9] * s[3:5].repeat_interleave(3))
+    assert torch.allclose(y[:, 9:], x[:, 9:] * s[5:])   # 0o: no mean, no bias
+
+
+def test_irreps_sort_order():
+    irr, p, inv = e3.Irreps("1x2e + 1x1o + 1x2o + 1x3o").sort()
+    assert str(irr) == "1x1o+1x2o+1x2e+1x3o"
