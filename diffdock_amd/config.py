@@ -159,5 +159,7 @@ DDL_SYNTH = ModelConfig(
     tor_sigma_min=0.0314, tor_sigma_max=3.14, crop_beyond=None)
 
 # Small preset for CPU-fast parity tests (same structure, all four irrep stages reached).
-TINY = DDL_SYNTH.replace(ns=8, nv=3, num_conv_layers=4, sigma_embed_dim=16,
-                         distance_embed_dim=16, cross_distance_embed_dim=16)
+# tr_sigma_max is lowered so that an UNTRAINED score model does not fling the ligand out of
+# cross-graph range during multi-step sampling tests.
+TINY = DDL_SYNTH.replace(ns=8, nv=3, num_conv_layers=4, sigma_embed_dim=16, distance_embed_dim=16,
+                         cross_distance_embed_dim=16, tr_sigma_max=5.0)

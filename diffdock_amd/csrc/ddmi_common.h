@@ -1,0 +1,63 @@
+// Shared host/device helpers for libddmi (gfx950).  Built with hipcc --offload-arch=gfx950;
+// the CPU test-suite builds the same sources against tests/hipemu (DDMI_HIPEMU).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/ddmi.h"
+
+#ifdef DDMI_HIPEMU
+typedef f32x4_emu f32x4;
+typedef f32x16_emu f32x16;
+#define DDMI_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(hipemu_dyn_smem())
+#else
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define DDMI_DYN_SMEM(type, name)                                        \
+  extern __shared__ __attribute__((aligned(16))) unsigned char ddmi_dyn_smem_[]; \
+  type* name = reinterpret_cast<type*>(ddmi_dyn_smem_)
+#endif
+
+namespace ddmi {
+
+constexpr int WAVE = 64;
+constexpr int XS = 160;  // row stride (floats) of node feature tables, >= largest irreps dim, 16B-aligned rows
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define DDMI_CHECK_HIP(expr)                                                                     \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      throw ::ddmi::Error(DDMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+#define DDMI_REQUIRE(cond, code, msg)                      \
+  do {                                                     \
+    if (!(cond)) throw ::ddmi::Error((code), (msg));       \
+  } while (0)
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+// wave-wide sum (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+}  // namespace ddmi

@@ -288,7 +288,7 @@ class FullyConnectedTensorProduct(torch.nn.Module):
             C = wigner_3j(a.ir.l, b.ir.l, o.ir.l, dtype=x1.dtype)
             xx = torch.einsum("eui,evj,ijk->euvk", X1, X2, C)
             outs[io] = outs[io] + c * torch.einsum("euvw,euvk->ewk", W, xx)
-        return torch.cat([o.reshape(E, -1) for o in outs], -1)
+        return torch.cat([o.reshape(E, mi.dim) for o, mi in zip(outs, self.irreps_out)], -1)
 
 
 class FullTensorProduct(torch.nn.Module):
@@ -317,7 +317,7 @@ class FullTensorProduct(torch.nn.Module):
             X1 = x1[:, s1[i1]].reshape(E, a.mul, a.ir.dim)
             X2 = x2[:, s2[i2]].reshape(E, b.mul, b.ir.dim)
             C = wigner_3j(a.ir.l, b.ir.l, o.ir.l, dtype=x1.dtype) * math.sqrt(o.ir.dim)
-            out[:, so[io]] = torch.einsum("eui,evj,ijk->euvk", X1, X2, C).reshape(E, -1)
+            out[:, so[io]] = torch.einsum("eui,evj,ijk->euvk", X1, X2, C).reshape(E, o.dim)
         return out
 
 
@@ -357,5 +357,5 @@ def batch_norm_eval(irreps, x, running_mean, running_var, weight, bias, eps=1e-5
             f = f + bias[im:im + mi.mul].reshape(1, -1, 1)
             im += mi.mul
         iv += mi.mul
-        out.append(f.reshape(N, -1))
+        out.append(f.reshape(N, mi.mul * d))
     return torch.cat(out, -1)

@@ -55,7 +55,7 @@ def faster_tensor_product(in_irreps, out_irreps, x, sh, weight):
     for mi, sl in zip(in_irreps, in_irreps.slices()):
         v = x[..., sl]
         if mi.ir.l == 1:
-            v = v.reshape(v.shape[0], -1, 3)
+            v = v.reshape(v.shape[0], mi.mul, 3)
         ind[str(mi.ir)] = v
         im[str(mi.ir)] = mi.mul
     for mi in out_irreps:
@@ -81,7 +81,7 @@ def faster_tensor_product(in_irreps, out_irreps, x, sh, weight):
     wd, start = {}, 0
     for t in _F_TYPES:
         a, b = shapes[t]
-        wd[t] = weight[:, start:start + a * b].reshape(-1, a, b) / math.sqrt(a) if a > 0 else None
+        wd[t] = weight[:, start:start + a * b].reshape(weight.shape[0], a, b) / math.sqrt(a) if a > 0 else None
         start += a * b
     outd = {}
     for t in _F_TYPES:
@@ -92,7 +92,7 @@ def faster_tensor_product(in_irreps, out_irreps, x, sh, weight):
             outd[t] = torch.einsum("eu,euw->ew", z, wd[t])
         else:
             z = torch.cat(terms[t], -2)                      # [E, fan, 3]
-            outd[t] = torch.einsum("eum,euw->ewm", z, wd[t]).reshape(z.shape[0], -1)
+            outd[t] = torch.einsum("eum,euw->ewm", z, wd[t]).reshape(z.shape[0], 3 * om[t])
     return torch.cat([outd[str(mi.ir)] for mi in out_irreps], -1)
 
 

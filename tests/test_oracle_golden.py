@@ -1,0 +1,67 @@
+"""The oracle against fixtures produced by EXECUTING the reference's python
+(tests/golden/make_golden.py).  These pin the restated wiring of CGModel.forward,
+TensorProductConvLayer / tp_scatter_*, FasterTensorProduct, the pose update and the
+reverse-diffusion loop."""
+import numpy as np
+import pytest
+import torch
+
+from diffdock_amd.hetero import HeteroBatch, set_time
+from oracle import conformer as oc
+from oracle.cg_model import CGModelOracle
+from oracle.layers import faster_tensor_product, gaussian_smearing
+from oracle.sampling import sampling
+from util import fixture_case, load_fixture, rel_err, split_draws, tables, graph_from_dict
+
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference(name):
+    fx, cfg, data_list = fixture_case(name)
+    so3_t, tor_t = tables()
+    model = CGModelOracle(cfg, fx["state_dict"], so3_t, tor_t)
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    tr, rot, tor, _, inter = model(batch, return_intermediates=True)
+    ref = fx["forward"]
+    for l, ref_nodes in enumerate(ref["conv_out"]):
+        mine = inter[f"node_attr{l + 1}"]
+        assert rel_err(mine, ref_nodes) < 2e-5, (l, rel_err(mine, ref_nodes))
+    assert rel_err(tr, ref["tr"]) < 2e-5
+    assert rel_err(rot, ref["rot"]) < 2e-5
+    assert rel_err(tor, ref["tor"]) < 2e-5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sampling_matches_reference(name):
+    fx, cfg, data_list = fixture_case(name)
+    so3_t, tor_t = tables()
+    model = CGModelOracle(cfg, fx["state_dict"], so3_t, tor_t)
+    s = fx["sampling"]
+    B = len(data_list)
+    R = int(data_list[0]["ligand"].edge_mask.sum())
+    noise = split_draws(s["draws"], s["steps"], B, R)
+    out = sampling(data_list, model, s["steps"], cfg, noise, batch_size=B, no_final_step_noise=True, **s["temp"])
+    final = torch.stack([d["ligand"].pos for d in out])
+    # 4 chaotic steps in fp32: compare in Angstrom against the reference trajectory end-points
+    assert (final - s["final_pos"]).abs().max() < 2e-3, (final - s["final_pos"]).abs().max()
+
+
+def test_unit_fixtures():
+    u = load_fixture("units")
+    assert torch.allclose(oc.axis_angle_to_matrix(u["axis_angle"]), u["rot_mats"], atol=1e-6)
+    R, t = oc.kabsch_batch(u["kabsch_A"], u["kabsch_B"])
+    assert torch.allclose(R, u["kabsch_R"], atol=1e-5) and torch.allclose(t, u["kabsch_t"], atol=1e-5)
+    g = graph_from_dict(u["mc_graph"])
+    B = u["mc_tr"].shape[0]
+    ei = g["ligand", "ligand"].edge_index
+    rot_edges = ei.T[g["ligand"].edge_mask]
+    out = oc.modify_conformer_batch(u["mc_pos_in"], B, rot_edges, torch.from_numpy(g["ligand"].mask_rotate[0]),
+                                    u["mc_tr"], u["mc_rot"], u["mc_tor"])
+    assert torch.allclose(out, u["mc_pos_out"], atol=2e-5), (out - u["mc_pos_out"]).abs().max()
+    irr = "8x0e + 3x1o + 3x1e + 8x0o"
+    assert torch.allclose(faster_tensor_product(irr, irr, u["ftp_x"], u["ftp_sh"], u["ftp_w"]), u["ftp_out"], atol=1e-5)
+    assert torch.allclose(oc.sinusoidal_embedding(1000.0 * u["sin_t"], 16), u["sin_emb"], atol=1e-6)
+    assert torch.allclose(gaussian_smearing(torch.linspace(0, 5, 16), u["gs_dist"]), u["gs_out"], atol=1e-7)
+    assert np.allclose(oc.get_t_schedule(20), u["t_schedule_20"].numpy())
