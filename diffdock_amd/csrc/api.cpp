@@ -1,0 +1,164 @@
+// extern "C" surface of libddmi.so (include/ddmi.h).
+#include <cstring>
+
+#include "model.h"
+
+using namespace ddmi;
+
+struct ddmi_model { Model m; };
+
+static thread_local std::string g_err;
+
+template <class F> static int guard(F&& f) {
+  try { f(); return DDMI_OK; }
+  catch (const Error& e) { g_err = e.what(); return e.code; }
+  catch (const std::exception& e) { g_err = e.what(); return DDMI_ERR_ARG; }
+}
+
+extern "C" {
+
+const char* ddmi_last_error(void) { return g_err.c_str(); }
+
+int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
+  return guard([&] {
+    DDMI_REQUIRE(cfg && out, DDMI_ERR_ARG, "null argument");
+    DDMI_CHECK_HIP(hipSetDevice(device));
+    auto* h = new ddmi_model();
+    h->m.cfg = *cfg;
+    h->m.device = device;
+    try { build_weight_spec(h->m); } catch (...) { delete h; throw; }
+    *out = h;
+  });
+}
+
+void ddmi_destroy(ddmi_model* h) { delete h; }
+
+int ddmi_num_weights(ddmi_model* h) { return h ? (int)h->m.spec.size() : DDMI_ERR_ARG; }
+
+int ddmi_weight_spec(ddmi_model* h, int i, const char** key, int64_t shape[4], int* ndim) {
+  return guard([&] {
+    DDMI_REQUIRE(h && i >= 0 && i < (int)h->m.spec.size(), DDMI_ERR_ARG, "bad index");
+    *key = h->m.spec[i].first.c_str();
+    *ndim = (int)h->m.spec[i].second.size();
+    for (int d = 0; d < *ndim; ++d) shape[d] = h->m.spec[i].second[d];
+  });
+}
+
+int ddmi_set_weight(ddmi_model* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  return guard([&] {
+    DDMI_REQUIRE(h && key && shape && ndim >= 1 && ndim <= 4, DDMI_ERR_ARG, "bad argument");
+    int64_t numel = 1;
+    for (int d = 0; d < ndim; ++d) numel *= shape[d];
+    DDMI_REQUIRE(data || numel == 0, DDMI_ERR_ARG, "null data");
+    Model& m = h->m;
+    bool known = false;
+    for (auto& kv : m.spec) if (kv.first == key) {
+      known = true;
+      DDMI_REQUIRE((int)kv.second.size() == ndim && std::equal(shape, shape + ndim, kv.second.begin()), DDMI_ERR_KEY,
+                   std::string("shape mismatch for ") + key);
+    }
+    DDMI_REQUIRE(known, DDMI_ERR_KEY, std::string("unexpected state_dict key: ") + key);
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    if (numel) t.data.assign(data, data + numel);
+    m.host_w[key] = std::move(t);
+    m.committed = false;
+  });
+}
+
+int ddmi_commit_weights(ddmi_model* h) {
+  return guard([&] { DDMI_REQUIRE(h, DDMI_ERR_ARG, "null model"); DDMI_CHECK_HIP(hipSetDevice(h->m.device)); commit_weights(h->m); });
+}
+
+int ddmi_set_table(ddmi_model* h, int kind, const double* data, int64_t n) {
+  return guard([&] {
+    DDMI_REQUIRE(h && data && n > 1 && (kind == 0 || kind == 1), DDMI_ERR_ARG, "bad table");
+    DDMI_CHECK_HIP(hipSetDevice(h->m.device));
+    std::vector<float> f(data, data + n);  // the reference casts the looked-up values with .float()
+    float* p = h->m.tpool.upload(f);
+    if (kind == 0) { h->m.so3_table = p; h->m.so3_n = (int)n; }
+    else { h->m.torus_table = p; h->m.torus_n = (int)n; }
+  });
+}
+
+int ddmi_set_time_frequencies(ddmi_model* h, const float* freq, int64_t n) {
+  return guard([&] {
+    DDMI_REQUIRE(h && freq && n == h->m.cfg.sigma_embed_dim / 2, DDMI_ERR_ARG, "need sigma_embed_dim/2 frequencies");
+    DDMI_REQUIRE(!h->m.committed, DDMI_ERR_STATE, "set frequencies before ddmi_commit_weights");
+    h->m.time_freq_host.assign(freq, freq + n);
+  });
+}
+
+int ddmi_set_complex(ddmi_model* h, const ddmi_complex* c, ddmi_stream s) {
+  return guard([&] {
+    DDMI_REQUIRE(h && c, DDMI_ERR_ARG, "null argument");
+    DDMI_CHECK_HIP(hipSetDevice(h->m.device));
+    set_complex(h->m, *c, (hipStream_t)s);
+  });
+}
+
+int ddmi_forward(ddmi_model* h, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor,
+                 float* tr_out, float* rot_out, float* tor_out, ddmi_stream s) {
+  return guard([&] {
+    DDMI_REQUIRE(h && lig_pos && t_tr && t_rot && t_tor && tr_out && rot_out, DDMI_ERR_ARG, "null argument");
+    DDMI_CHECK_HIP(hipSetDevice(h->m.device));
+    forward(h->m, lig_pos, t_tr, t_rot, t_tor, tr_out, rot_out, tor_out, (hipStream_t)s);
+  });
+}
+
+int ddmi_modify_conformer(ddmi_model* h, float* lig_pos, const float* tr, const float* rot, const float* tor, ddmi_stream s) {
+  return guard([&] {
+    DDMI_REQUIRE(h && lig_pos && tr && rot, DDMI_ERR_ARG, "null argument");
+    DDMI_CHECK_HIP(hipSetDevice(h->m.device));
+    modify_conformer(h->m, lig_pos, tr, rot, tor, (hipStream_t)s);
+  });
+}
+
+int ddmi_sample(ddmi_model* h, float* lig_pos, const ddmi_sample_cfg* cfg, ddmi_stream s) {
+  return guard([&] {
+    DDMI_REQUIRE(h && lig_pos && cfg, DDMI_ERR_ARG, "null argument");
+    DDMI_CHECK_HIP(hipSetDevice(h->m.device));
+    sample(h->m, lig_pos, *cfg, (hipStream_t)s);
+  });
+}
+
+int ddmi_debug_shape(ddmi_model* h, const char* name, int64_t shape[4], int* ndim, int* is_int) {
+  return guard([&] {
+    DDMI_REQUIRE(h && name, DDMI_ERR_ARG, "null argument");
+    auto it = h->m.debug.find(name);
+    DDMI_REQUIRE(it != h->m.debug.end(), DDMI_ERR_KEY, std::string("unknown debug buffer: ") + name);
+    *ndim = (int)it->second.shape.size();
+    for (int d = 0; d < *ndim && d < 4; ++d) shape[d] = it->second.shape[d];
+    *is_int = it->second.is_int;
+  });
+}
+
+int ddmi_debug_read(ddmi_model* h, const char* name, void* dst, size_t bytes, ddmi_stream s) {
+  return guard([&] {
+    DDMI_REQUIRE(h && name && dst, DDMI_ERR_ARG, "null argument");
+    auto it = h->m.debug.find(name);
+    DDMI_REQUIRE(it != h->m.debug.end(), DDMI_ERR_KEY, std::string("unknown debug buffer: ") + name);
+    size_t n = 4;
+    for (auto d : it->second.shape) n *= (size_t)d;
+    DDMI_REQUIRE(bytes <= n, DDMI_ERR_ARG, "read past the end of the buffer");
+    DDMI_CHECK_HIP(hipStreamSynchronize((hipStream_t)s));
+    DDMI_CHECK_HIP(hipMemcpy(dst, it->second.ptr, bytes, hipMemcpyDeviceToHost));
+  });
+}
+
+int ddmi_wigner_3j(int l1, int l2, int l3, double* out) {
+  return guard([&] {
+    DDMI_REQUIRE(out && l1 >= 0 && l2 >= 0 && l3 >= std::abs(l1 - l2) && l3 <= l1 + l2, DDMI_ERR_ARG, "bad l");
+    auto w = wigner_3j(l1, l2, l3);
+    std::memcpy(out, w.data(), w.size() * sizeof(double));
+  });
+}
+
+int ddmi_set_kernel_timing(ddmi_model* h, int enabled) { if (!h) return DDMI_ERR_ARG; h->m.timing = enabled != 0; return DDMI_OK; }
+int ddmi_kernel_timings(ddmi_model* h, int i, const char** name, double* ms, int64_t* launches) {
+  if (!h || i < 0 || i >= (int)h->m.phases.size()) return DDMI_ERR_ARG;
+  *name = h->m.phases[i].name.c_str(); *ms = h->m.phases[i].ms; *launches = h->m.phases[i].launches;
+  return DDMI_OK;
+}
+
+}  // extern "C"

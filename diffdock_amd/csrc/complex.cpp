@@ -1,0 +1,543 @@
+// Orchestration of the score-model forward pass and the reverse-diffusion loop for one
+// collated batch (reference CGModel.forward models/cg_model.py:308-424, sampling()
+// utils/sampling.py:96-191).  Everything is enqueued on the caller's stream; the only host
+// synchronisation is inside set_complex (one-time topology read-back).
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "model.h"
+
+namespace ddmi {
+
+struct Model::Cx {
+  int B = 0, nL = 0, nR = 0, N = 0, Eb = 0, Err = 0, nT = 0;
+  int maxNl = 0, maxNr = 0, Ell_cap = 0, Elr_cap = 0, tor_cap = 32, Et = 0, lig_cap = 33;
+  bool uniform = false; int Nl_one = 0, R_one = 0;
+  std::vector<int> lig_ptr_h, rec_ptr_h;
+  // static
+  int *lig_batch, *rec_batch, *lig_ptr, *rec_ptr, *lig_x;
+  int *bond_src, *bond_dst, *bond_grank, *bond_trank, *bg, *bt; float* bond_attr;
+  int *tor_u, *tor_v, *tor_batch, *tor_eu, *tor_ev, *rot_u, *rot_v; unsigned char* mask_rotate = nullptr;
+  float* rec_pos; int *rr_src, *rr_dst, *rr_batch; float *rr_dist, *rr_nvec, *rr_ew, *rec_edge_base;
+  int *rr_goff, *rr_tgt, *rr_tslot, *rr_arow, *rr_toff;
+  float* rec_node_base; int rec_base_dim = 0;
+  // per forward
+  float *temb, *hidB, *rec_sig, *ligsig, *ll_gvec, *cross_gvec, *center_gvec, *tr_sig, *rot_sig, *cutoff, *rr_rowbias;
+  float* embsum;
+  std::vector<float*> X;
+  int *adjrank, *cnt_g, *cnt_t, *goff_ll, *toff_ll, *ll_tgt, *ll_tslot, *ll_featidx, *ll_batch;
+  float *ll_dist, *ll_nvec, *ll_ew, *ll_ea;
+  int *pairrank, *cnt_l, *cnt_r, *offs_l, *offs_r, *g1_tgt, *g1_tslot, *g3_tgt, *g3_tslot, *pbatch;
+  float *pdist, *pnvec, *pew, *cross_ea;
+  float *HE, *P, *Q, *Y; float* msg[4];
+  ReduceGroup *rg_all, *rg_lig, *rg_ll, *rg_rr;
+  // read-outs
+  float *c_dist, *c_nvec, *c_ea, *c_attr, *c_hid, *c_W, *c_sh, *c_out, *gp;
+  int* c_xrow;
+  int *t_cnt, *t_atom; float *t_dist, *t_nvec, *t_ew, *t_bond_nvec, *t_ea, *t_attr, *t_hid, *t_W, *t_sh, *t_out, *t_feat;
+  // sampler
+  float *s_tr, *s_rot, *s_tor, *s_t = nullptr; long long* s_ids = nullptr; size_t s_t_cap = 0;
+};
+
+namespace {
+
+typedef Model::Cx Cx;
+
+template <class T> T* dalloc(Model& m, const char* name, std::vector<int64_t> shape, bool zero = false) {
+  size_t n = 1;
+  for (auto d : shape) n *= (size_t)std::max<int64_t>(d, 0);
+  T* p = m.cpool.alloc<T>(n ? n : 1);
+  if (zero) DDMI_CHECK_HIP(hipMemset(p, 0, (n ? n : 1) * sizeof(T)));
+  if (name) m.debug[name] = DebugEntry{p, shape, !std::is_same<T, float>::value};
+  return p;
+}
+template <class T> T* dup(Model& m, const char* name, const std::vector<T>& v) {
+  T* p = m.cpool.upload(v);
+  if (name) m.debug[name] = DebugEntry{p, {(int64_t)v.size()}, !std::is_same<T, float>::value};
+  return p;
+}
+
+void gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+          int act, hipStream_t s, const int* m_dev = nullptr, const float* rowbias = nullptr, const int* ridx = nullptr,
+          int ldrb = 0) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act;
+  g.m_dev = m_dev; g.rowbias = rowbias; g.ridx = ridx; g.ldrb = ldrb;
+  launch_gemm(g, s);
+}
+
+struct RunGroup {
+  int gbase, gcount, tbase, tcount;
+  const int *goff, *tgt, *tslot, *arow;
+  const float* ea; int ea_rows; const int* ea_rows_dev;
+  const float* sig; const int* sig_idx;   // optional per-graph vector [B][ns] added to every edge attr row
+  const float *nvec, *ew; float sgn;
+  float* msg;
+};
+
+// One TensorProductConvLayer in the node-contracted form (k_conv.hip).
+void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, const ReduceGroup* rg_dev, int n_rg,
+              const float* Xin, float* Xout, int nbase, int ncount, hipStream_t s) {
+  Cx& c = *m.cx;
+  const int ns = m.ns, H = L.H;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    const RunGroup& g = groups[gi];
+    const int wg = std::min<int>((int)gi, L.G - 1);
+    const float* W1 = L.W1[wg];
+    const float* rb = nullptr;
+    if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]
+      gemm(g.sig, ns, W1, L.n_edge, nullptr, c.rr_rowbias, H, c.B, H, ns, 0, s);
+      rb = c.rr_rowbias;
+    }
+    gemm(g.ea, ns, W1, L.n_edge, nullptr, c.HE, H, g.ea_rows, H, ns, 0, s, g.ea_rows_dev, rb, g.sig_idx, H);
+    gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, c.P, H, g.tcount, H, ns, 0, s);
+    gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], c.Q, H, g.gcount, H, ns, 0, s);
+    launch_node_contract(Xin, g.gbase, g.gcount, L.wpack[wg], L.pcs, L.n_pc, L.max_mul_out, L.HK, L.HKp, L.NTs, c.Y, s);
+    EdgeConvArgs a{};
+    a.gcount = g.gcount; a.goff = g.goff; a.tgt = g.tgt; a.tslot = g.tslot; a.arow = g.arow; a.tbase = g.tbase;
+    a.HE = c.HE; a.P = c.P; a.Q = c.Q; a.Y = c.Y; a.nvec = g.nvec; a.ew = g.ew; a.sgn = g.sgn;
+    a.H = H; a.HKp = L.HKp; a.NT = L.NT; a.NTs = L.NTs; a.sh_lmax = m.cfg.sh_lmax;
+    a.paths = L.paths; a.ctab = L.ctab; a.items = L.items; a.n_items = L.n_items; a.msg = g.msg;
+    launch_edge_conv(a, s);
+  }
+  launch_reduce_bn(rg_dev, n_rg, nbase, ncount, L.D_in, L.D_out, L.has_bn ? L.bn_mean : nullptr,
+                   L.has_bn ? L.bn_scale : nullptr, L.has_bn ? L.bn_bias : nullptr, L.residual ? 1 : 0, Xin, Xout, XS, s);
+}
+
+// final_conv / tor_bond_conv: per-edge weights, then the table-driven tensor product.
+void run_direct_conv(Model& m, const ConvW& L, const float* attr, int E, float* hid, float* Wt, const int* xrow,
+                     const float* X, const float* sh, const float* ew, const int* valid_cnt, int cap, float* out_rows,
+                     hipStream_t s) {
+  gemm(attr, L.n_edge, L.W1[0], L.n_edge, L.b1[0], hid, L.H, E, L.H, L.n_edge, 1, s);
+  gemm(hid, L.H, L.W2[0], L.H, L.b2[0], Wt, L.Wn, E, L.Wn, L.H, 0, s);
+  TpApplyArgs a{};
+  a.E = E; a.valid_cnt = valid_cnt; a.cap = cap; a.Wt = Wt; a.ldw = L.Wn; a.X = X; a.xrow = xrow; a.sh = sh;
+  a.lds_ = L.sh_dim; a.ew = ew; a.paths = L.paths; a.ctab = L.ctab; a.items = L.items; a.n_items = L.n_items;
+  a.out = out_rows; a.ldo = L.D_out;
+  launch_tp_apply(a, s);
+}
+
+EdgeMlpArgs mlp_args(const Mlp2W& w, int ns, int E, const int* e_dev, const float* dist, const float* offsets, int D,
+                     float coeff, int g_col, const float* gvec, const int* gidx, float* out) {
+  EdgeMlpArgs a;
+  a.E = E; a.e_dev = e_dev; a.dist = dist; a.offsets = offsets; a.D = D; a.coeff = coeff;
+  a.W0g = w.W0 + g_col; a.ldw0g = w.in; a.gvec = gvec; a.gidx = gidx; a.W1 = w.W3; a.b1 = w.b3; a.ns = ns;
+  a.out = out; a.ldo = ns;
+  return a;
+}
+
+}  // namespace
+
+// =============================================================================== set_complex
+void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
+  DDMI_REQUIRE(m.committed, DDMI_ERR_STATE, "ddmi_commit_weights must precede ddmi_set_complex");
+  DDMI_REQUIRE(cc.num_graphs > 0 && cc.n_lig > 0 && cc.n_rec > 0, DDMI_ERR_ARG, "empty batch");
+  DDMI_REQUIRE(cc.lig_ptr && cc.rec_ptr && cc.lig_x && cc.rec_x && cc.rec_pos && cc.rec_edge_index, DDMI_ERR_ARG,
+               "null pointer in ddmi_complex");
+  DDMI_REQUIRE(cc.n_bond_edges == 0 || (cc.bond_index && cc.bond_attr && cc.edge_mask), DDMI_ERR_ARG, "null bond arrays");
+  m.has_complex = false;
+  m.cpool.release();
+  m.debug.clear();
+  m.cx = std::make_shared<Cx>();
+  Cx& c = *m.cx;
+  const ddmi_config& cfg = m.cfg;
+  const int ns = m.ns, sd = m.sd, H = m.H;
+  c.B = cc.num_graphs; c.nL = cc.n_lig; c.nR = cc.n_rec; c.N = c.nL + c.nR; c.Eb = cc.n_bond_edges; c.Err = cc.n_rec_edges;
+  c.nT = cfg.no_torsion ? 0 : cc.n_tor;
+  c.lig_ptr_h.assign(cc.lig_ptr, cc.lig_ptr + c.B + 1);
+  c.rec_ptr_h.assign(cc.rec_ptr, cc.rec_ptr + c.B + 1);
+  DDMI_REQUIRE(c.lig_ptr_h[0] == 0 && c.lig_ptr_h[c.B] == c.nL && c.rec_ptr_h[0] == 0 && c.rec_ptr_h[c.B] == c.nR,
+               DDMI_ERR_ARG, "lig_ptr / rec_ptr do not span the node arrays");
+  DDMI_CHECK_HIP(hipStreamSynchronize(s));
+  // ---- topology read-back (one-time)
+  std::vector<int> bond_index(2 * (size_t)c.Eb), rr_index(2 * (size_t)c.Err);
+  std::vector<unsigned char> edge_mask(c.Eb);
+  if (c.Eb) {
+    DDMI_CHECK_HIP(hipMemcpy(bond_index.data(), cc.bond_index, bond_index.size() * 4, hipMemcpyDeviceToHost));
+    DDMI_CHECK_HIP(hipMemcpy(edge_mask.data(), cc.edge_mask, edge_mask.size(), hipMemcpyDeviceToHost));
+  }
+  DDMI_CHECK_HIP(hipMemcpy(rr_index.data(), cc.rec_edge_index, rr_index.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<int> lig_batch(c.nL), rec_batch(c.nR);
+  c.Elr_cap = 0;
+  c.uniform = true;
+  for (int b = 0; b < c.B; ++b) {
+    const int nl = c.lig_ptr_h[b + 1] - c.lig_ptr_h[b], nr = c.rec_ptr_h[b + 1] - c.rec_ptr_h[b];
+    DDMI_REQUIRE(nl > 0 && nr > 0, DDMI_ERR_ARG, "graph without ligand or receptor nodes");
+    c.maxNl = std::max(c.maxNl, nl); c.maxNr = std::max(c.maxNr, nr);
+    c.Elr_cap += nl * nr;
+    if (nl != c.lig_ptr_h[1]) c.uniform = false;
+    for (int i = c.lig_ptr_h[b]; i < c.lig_ptr_h[b + 1]; ++i) lig_batch[i] = b;
+    for (int i = c.rec_ptr_h[b]; i < c.rec_ptr_h[b + 1]; ++i) rec_batch[i] = b;
+  }
+  c.Ell_cap = c.Eb + c.lig_cap * c.nL;
+  // bonds: ranks inside the gather (edge_index[1]) and target (edge_index[0]) lists
+  std::vector<int> bsrc(c.Eb), bdst(c.Eb), bgr(c.Eb), btr(c.Eb), bg(c.nL, 0), bt(c.nL, 0);
+  for (int k = 0; k < c.Eb; ++k) {
+    bsrc[k] = bond_index[k]; bdst[k] = bond_index[c.Eb + k];
+    DDMI_REQUIRE(bsrc[k] >= 0 && bsrc[k] < c.nL && bdst[k] >= 0 && bdst[k] < c.nL, DDMI_ERR_ARG, "bond index out of range");
+    bgr[k] = bg[bdst[k]]++;
+    btr[k] = bt[bsrc[k]]++;
+  }
+  std::vector<int> tor_u, tor_v, tor_b;
+  for (int k = 0; k < c.Eb && !cfg.no_torsion; ++k)
+    if (edge_mask[k]) { tor_u.push_back(bsrc[k]); tor_v.push_back(bdst[k]); tor_b.push_back(lig_batch[bsrc[k]]); }
+  DDMI_REQUIRE((int)tor_u.size() == c.nT, DDMI_ERR_ARG, "n_tor does not equal edge_mask.sum()");
+  c.Et = c.nT * c.tor_cap;
+  std::vector<int> tor_eu(c.Et), tor_ev(c.Et);
+  for (int t = 0; t < c.nT; ++t)
+    for (int r = 0; r < c.tor_cap; ++r) { tor_eu[t * c.tor_cap + r] = tor_u[t]; tor_ev[t * c.tor_cap + r] = tor_v[t]; }
+  // receptor contact graph: gather = edge_index[1], target = edge_index[0]
+  std::vector<int> rr_src(c.Err), rr_dst(c.Err), rr_batch(c.Err), goff(c.nR + 1, 0), toff(c.nR + 1, 0);
+  for (int k = 0; k < c.Err; ++k) {
+    rr_src[k] = rr_index[k]; rr_dst[k] = rr_index[c.Err + k];
+    DDMI_REQUIRE(rr_src[k] >= 0 && rr_src[k] < c.nR && rr_dst[k] >= 0 && rr_dst[k] < c.nR, DDMI_ERR_ARG, "receptor edge out of range");
+    rr_batch[k] = rec_batch[rr_src[k]];
+    goff[rr_dst[k] + 1]++; toff[rr_src[k] + 1]++;
+  }
+  for (int i = 0; i < c.nR; ++i) { goff[i + 1] += goff[i]; toff[i + 1] += toff[i]; }
+  std::vector<int> rr_arow(c.Err), rr_tgt(c.Err), rr_tslot(c.Err), cur(goff.begin(), goff.end() - 1), tcur(toff.begin(), toff.end() - 1);
+  for (int k = 0; k < c.Err; ++k) rr_arow[cur[rr_dst[k]]++] = k;
+  for (int e = 0; e < c.Err; ++e) {
+    const int k = rr_arow[e];
+    rr_tgt[e] = c.nL + rr_src[k];
+    rr_tslot[e] = tcur[rr_src[k]]++;
+  }
+  // ---- uploads
+  c.lig_batch = dup(m, "lig_batch", lig_batch); c.rec_batch = dup(m, "rec_batch", rec_batch);
+  c.lig_ptr = dup(m, nullptr, c.lig_ptr_h); c.rec_ptr = dup(m, nullptr, c.rec_ptr_h);
+  c.lig_x = dalloc<int>(m, nullptr, {c.nL * 16});
+  DDMI_CHECK_HIP(hipMemcpy(c.lig_x, cc.lig_x, (size_t)c.nL * 16 * 4, hipMemcpyDeviceToDevice));
+  c.bond_src = dup(m, nullptr, bsrc); c.bond_dst = dup(m, nullptr, bdst); c.bond_grank = dup(m, nullptr, bgr);
+  c.bond_trank = dup(m, nullptr, btr); c.bg = dup(m, nullptr, bg); c.bt = dup(m, nullptr, bt);
+  c.bond_attr = dalloc<float>(m, nullptr, {c.Eb * m.nf});
+  if (c.Eb) DDMI_CHECK_HIP(hipMemcpy(c.bond_attr, cc.bond_attr, (size_t)c.Eb * m.nf * 4, hipMemcpyDeviceToDevice));
+  c.tor_u = dup(m, "tor_u", tor_u); c.tor_v = dup(m, "tor_v", tor_v); c.tor_batch = dup(m, nullptr, tor_b);
+  c.tor_eu = dup(m, nullptr, tor_eu); c.tor_ev = dup(m, nullptr, tor_ev);
+  if (c.uniform && c.nT % c.B == 0) {
+    c.Nl_one = c.nL / c.B; c.R_one = c.nT / c.B;
+    std::vector<int> ru(tor_u.begin(), tor_u.begin() + c.R_one), rv(tor_v.begin(), tor_v.begin() + c.R_one);
+    c.rot_u = dup(m, nullptr, ru); c.rot_v = dup(m, nullptr, rv);
+    if (cc.mask_rotate && c.R_one > 0) {
+      c.mask_rotate = dalloc<unsigned char>(m, nullptr, {c.R_one * c.Nl_one});
+      DDMI_CHECK_HIP(hipMemcpy(c.mask_rotate, cc.mask_rotate, (size_t)c.R_one * c.Nl_one, hipMemcpyDeviceToDevice));
+    }
+  }
+  c.rec_pos = dalloc<float>(m, nullptr, {c.nR * 3});
+  DDMI_CHECK_HIP(hipMemcpy(c.rec_pos, cc.rec_pos, (size_t)c.nR * 12, hipMemcpyDeviceToDevice));
+  c.rr_src = dup(m, nullptr, rr_src); c.rr_dst = dup(m, nullptr, rr_dst); c.rr_batch = dup(m, nullptr, rr_batch);
+  c.rr_goff = dup(m, "rr_goff", goff); c.rr_toff = dup(m, "rr_toff", toff); c.rr_arow = dup(m, nullptr, rr_arow);
+  c.rr_tgt = dup(m, nullptr, rr_tgt); c.rr_tslot = dup(m, nullptr, rr_tslot);
+  // ---- workspace
+  const int B = c.B, nL = c.nL, nR = c.nR, N = c.N;
+  c.rr_dist = dalloc<float>(m, nullptr, {c.Err}); c.rr_nvec = dalloc<float>(m, nullptr, {c.Err, 3});
+  c.rr_ew = cfg.smooth_edges ? dalloc<float>(m, nullptr, {c.Err}) : nullptr;
+  c.rec_edge_base = dalloc<float>(m, "rec_edge_base", {c.Err, ns});
+  c.rec_node_base = dalloc<float>(m, "rec_node_base", {nR, XS}, true);
+  c.temb = dalloc<float>(m, "temb", {B, sd}); c.hidB = dalloc<float>(m, nullptr, {B, std::max(ns, H)});
+  c.rec_sig = dalloc<float>(m, "rec_sig", {B, ns}); c.ligsig = dalloc<float>(m, nullptr, {B, ns});
+  c.ll_gvec = dalloc<float>(m, nullptr, {B, ns}); c.cross_gvec = dalloc<float>(m, nullptr, {B, ns});
+  c.center_gvec = dalloc<float>(m, nullptr, {B, ns}); c.tr_sig = dalloc<float>(m, nullptr, {B, ns});
+  c.rot_sig = dalloc<float>(m, nullptr, {B, ns}); c.cutoff = dalloc<float>(m, "cross_cutoff", {B});
+  c.rr_rowbias = dalloc<float>(m, nullptr, {B, H});
+  c.embsum = dalloc<float>(m, nullptr, {nL, ns});
+  const int n_layers = (int)m.conv_layers.size(), K = (int)m.lig_emb_layers.size();
+  for (int l = 0; l <= n_layers + K; ++l) {
+    static const char* names[] = {"x0", "x1", "x2", "x3", "x4", "x5", "x6", "x7", "x8", "x9", "x10", "x11", "x12"};
+    c.X.push_back(dalloc<float>(m, l < 13 ? names[l] : nullptr, {N, XS}, true));
+  }
+  c.adjrank = dalloc<int>(m, nullptr, {nL, c.maxNl}); c.cnt_g = dalloc<int>(m, nullptr, {nL}); c.cnt_t = dalloc<int>(m, nullptr, {nL});
+  c.goff_ll = dalloc<int>(m, "goff_ll", {nL + 1}); c.toff_ll = dalloc<int>(m, "toff_ll", {nL + 1});
+  c.ll_tgt = dalloc<int>(m, "ll_tgt", {c.Ell_cap}); c.ll_tslot = dalloc<int>(m, nullptr, {c.Ell_cap});
+  c.ll_featidx = dalloc<int>(m, nullptr, {c.Ell_cap}); c.ll_batch = dalloc<int>(m, nullptr, {c.Ell_cap});
+  c.ll_dist = dalloc<float>(m, "ll_dist", {c.Ell_cap}); c.ll_nvec = dalloc<float>(m, nullptr, {c.Ell_cap, 3});
+  c.ll_ew = cfg.smooth_edges ? dalloc<float>(m, nullptr, {c.Ell_cap}) : nullptr;
+  c.ll_ea = dalloc<float>(m, "ll_ea", {c.Ell_cap, ns});
+  c.pairrank = dalloc<int>(m, nullptr, {nL, c.maxNr}); c.cnt_l = dalloc<int>(m, nullptr, {nL}); c.cnt_r = dalloc<int>(m, nullptr, {nR});
+  c.offs_l = dalloc<int>(m, "offs_l", {nL + 1}); c.offs_r = dalloc<int>(m, "offs_r", {nR + 1});
+  c.g1_tgt = dalloc<int>(m, nullptr, {c.Elr_cap}); c.g1_tslot = dalloc<int>(m, nullptr, {c.Elr_cap});
+  c.g3_tgt = dalloc<int>(m, nullptr, {c.Elr_cap}); c.g3_tslot = dalloc<int>(m, nullptr, {c.Elr_cap});
+  c.pbatch = dalloc<int>(m, nullptr, {c.Elr_cap}); c.pdist = dalloc<float>(m, "cross_dist", {c.Elr_cap});
+  c.pnvec = dalloc<float>(m, nullptr, {c.Elr_cap, 3}); c.pew = cfg.smooth_edges ? dalloc<float>(m, nullptr, {c.Elr_cap}) : nullptr;
+  c.cross_ea = dalloc<float>(m, "cross_ea", {c.Elr_cap, ns});
+  const int max_rows = std::max(std::max(c.Ell_cap, c.Elr_cap), c.Err);
+  c.HE = dalloc<float>(m, nullptr, {max_rows, H}); c.P = dalloc<float>(m, nullptr, {N, H}); c.Q = dalloc<float>(m, nullptr, {N, H});
+  int HKp = 0, NTs = 0;
+  auto upd = [&](const ConvW& L) { HKp = std::max(HKp, L.HKp); NTs = std::max(NTs, L.NTs); };
+  for (auto& L : m.conv_layers) upd(L);
+  for (auto& L : m.lig_emb_layers) upd(L);
+  for (auto& L : m.rec_emb_layers) upd(L);
+  c.Y = dalloc<float>(m, nullptr, {std::max(nL, nR), HKp, NTs}, true);
+  const int ecap[4] = {c.Ell_cap, c.Elr_cap, c.Err, c.Elr_cap};
+  for (int g = 0; g < 4; ++g) c.msg[g] = dalloc<float>(m, nullptr, {ecap[g], XS});
+  {
+    std::vector<ReduceGroup> rg = {{c.toff_ll, c.msg[0], 0, nL}, {c.offs_l, c.msg[1], 0, nL},
+                                   {c.rr_toff, c.msg[2], nL, nR}, {c.offs_r, c.msg[3], nL, nR}};
+    c.rg_all = m.cpool.upload(rg);
+    std::vector<ReduceGroup> rl(rg.begin(), rg.begin() + 2);
+    c.rg_lig = m.cpool.upload(rl);
+    std::vector<ReduceGroup> r0(rg.begin(), rg.begin() + 1);
+    c.rg_ll = m.cpool.upload(r0);
+    std::vector<ReduceGroup> r2 = {{c.rr_toff, c.msg[2], 0, nR}};  // receptor-only embedding layers index nodes from 0
+    c.rg_rr = m.cpool.upload(r2);
+  }
+  const ConvW& F = m.final_conv;
+  c.c_dist = dalloc<float>(m, nullptr, {nL}); c.c_nvec = dalloc<float>(m, nullptr, {nL, 3});
+  c.c_ea = dalloc<float>(m, nullptr, {nL, ns}); c.c_attr = dalloc<float>(m, nullptr, {nL, F.n_edge});
+  c.c_hid = dalloc<float>(m, nullptr, {nL, F.H}); c.c_W = dalloc<float>(m, nullptr, {nL, F.Wn});
+  c.c_sh = dalloc<float>(m, nullptr, {nL, F.sh_dim}); c.c_out = dalloc<float>(m, nullptr, {nL, F.D_out});
+  c.gp = dalloc<float>(m, "global_pred", {B, F.D_out});
+  {
+    std::vector<int> xr(nL);
+    std::iota(xr.begin(), xr.end(), 0);
+    c.c_xrow = m.cpool.upload(xr);
+  }
+  if (c.nT > 0) {
+    const ConvW& T = m.tor_conv;
+    c.t_cnt = dalloc<int>(m, "tor_cnt", {c.nT}); c.t_atom = dalloc<int>(m, nullptr, {c.Et});
+    c.t_dist = dalloc<float>(m, nullptr, {c.Et}); c.t_nvec = dalloc<float>(m, nullptr, {c.Et, 3});
+    c.t_ew = cfg.smooth_edges ? dalloc<float>(m, nullptr, {c.Et}) : nullptr;
+    c.t_bond_nvec = dalloc<float>(m, nullptr, {c.nT, 3}); c.t_ea = dalloc<float>(m, nullptr, {c.Et, ns});
+    c.t_attr = dalloc<float>(m, nullptr, {c.Et, T.n_edge}); c.t_hid = dalloc<float>(m, nullptr, {c.Et, T.H});
+    c.t_W = dalloc<float>(m, nullptr, {c.Et, T.Wn}); c.t_sh = dalloc<float>(m, nullptr, {c.Et, T.sh_dim});
+    c.t_out = dalloc<float>(m, nullptr, {c.Et, T.D_out}); c.t_feat = dalloc<float>(m, "tor_feat", {c.nT, T.D_out});
+  }
+  c.s_tr = dalloc<float>(m, nullptr, {B, 3}); c.s_rot = dalloc<float>(m, nullptr, {B, 3});
+  c.s_tor = dalloc<float>(m, nullptr, {std::max(c.nT, 1)});
+  c.s_t = nullptr; c.s_ids = nullptr;
+
+  // ---- receptor-side constants (CGModel.embedding caches these on the data object, cg_model.py:273-295)
+  launch_rec_edge_geom(c.rec_pos, c.rr_src, c.rr_dst, c.Err, cfg.smooth_edges ? cfg.rec_max_radius : 0.f, c.rr_dist, c.rr_nvec,
+                       c.rr_ew, s);
+  launch_edge_mlp(mlp_args(m.rec_edge, ns, c.Err, nullptr, c.rr_dist, m.off_rec, m.D, m.coeff_rec, 0, m.rec_edge.b0, nullptr,
+                           c.rec_edge_base), s);
+  if (m.lm > 0) {
+    float* cat = dalloc<float>(m, nullptr, {nR, ns + m.lm});
+    launch_concat_rec_input(cc.rec_x, 1 + m.lm, m.rec_emb, ns, m.lm, nR, cat, s);
+    gemm(cat, ns + m.lm, m.rec_enc_W, ns + m.lm, m.rec_enc_b, c.rec_node_base, XS, nR, ns, ns + m.lm, 0, s);
+  } else {
+    float* cat = dalloc<float>(m, nullptr, {nR, ns});
+    launch_concat_rec_input(cc.rec_x, 1, m.rec_emb, ns, 0, nR, cat, s);
+    launch_add_rowvec(c.rec_node_base, XS, cat, ns, nullptr, 0, nullptr, nR, ns, 0, s);
+  }
+  c.rec_base_dim = ns;
+  if (!m.rec_emb_layers.empty()) {
+    // rec_emb_layers run on the sigma-free receptor graph (cg_model.py:288-290), node ids local to the receptor
+    std::vector<int> tgt_local(c.Err);
+    for (int e = 0; e < c.Err; ++e) tgt_local[e] = rr_tgt[e] - c.nL;
+    int* tl = m.cpool.upload(tgt_local);
+    float* xa = dalloc<float>(m, nullptr, {nR, XS}, true);
+    float* xin = c.rec_node_base;
+    for (size_t i = 0; i < m.rec_emb_layers.size(); ++i) {
+      const ConvW& L = m.rec_emb_layers[i];
+      RunGroup g{0, nR, 0, nR, c.rr_goff, tl, c.rr_tslot, c.rr_arow, c.rec_edge_base, c.Err, nullptr, nullptr, nullptr,
+                 c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
+      float* xout = (xin == c.rec_node_base) ? xa : c.rec_node_base;
+      run_conv(m, L, {g}, c.rg_rr, 1, xin, xout, 0, nR, s);
+      xin = xout;
+      c.rec_base_dim = L.D_out;
+    }
+    if (xin != c.rec_node_base)
+      DDMI_CHECK_HIP(hipMemcpyAsync(c.rec_node_base, xin, (size_t)nR * XS * 4, hipMemcpyDeviceToDevice, s));
+  }
+  DDMI_CHECK_HIP(hipStreamSynchronize(s));
+  m.has_complex = true;
+}
+
+// =================================================================================== forward
+void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor, float* tr_out,
+             float* rot_out, float* tor_out, hipStream_t s) {
+  DDMI_REQUIRE(m.has_complex, DDMI_ERR_STATE, "ddmi_set_complex must precede ddmi_forward");
+  DDMI_REQUIRE(!m.cfg.scale_by_sigma || (m.so3_table && (m.cfg.no_torsion || m.torus_table)), DDMI_ERR_STATE,
+               "score-norm tables not set (ddmi_set_table)");
+  Cx& c = *m.cx;
+  const ddmi_config& cfg = m.cfg;
+  const int ns = m.ns, sd = m.sd, B = c.B, nL = c.nL, nR = c.nR;
+  // ---- per-graph time terms
+  launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, c.temb, s);
+  gemm(c.temb, sd, m.rec_sigma.W0, sd, m.rec_sigma.b0, c.hidB, ns, B, ns, sd, 1, s);
+  gemm(c.hidB, ns, m.rec_sigma.W3, ns, m.rec_sigma.b3, c.rec_sig, ns, B, ns, ns, 0, s);
+  gemm(c.temb, sd, m.lig_enc.W0 + ns, ns + sd, m.lig_enc.b0, c.ligsig, ns, B, ns, sd, 0, s);
+  gemm(c.temb, sd, m.lig_edge.W0 + m.nf, m.lig_edge.in, m.lig_edge.b0, c.ll_gvec, ns, B, ns, sd, 0, s);
+  gemm(c.temb, sd, m.cross_edge.W0, m.cross_edge.in, m.cross_edge.b0, c.cross_gvec, ns, B, ns, sd, 0, s);
+  gemm(c.temb, sd, m.center_edge.W0 + m.D, m.center_edge.in, m.center_edge.b0, c.center_gvec, ns, B, ns, sd, 0, s);
+  gemm(c.temb, sd, m.tr_final.W0 + 1, 1 + sd, m.tr_final.b0, c.tr_sig, ns, B, ns, sd, 0, s);
+  gemm(c.temb, sd, m.rot_final.W0 + 1, 1 + sd, m.rot_final.b0, c.rot_sig, ns, B, ns, sd, 0, s);
+  // ---- node tables: ligand rows [0,nL), receptor rows [nL, nL+nR)
+  float* X0 = c.X[0];
+  launch_lig_node_embed(c.lig_x, nL, m.lig_emb, m.lig_emb_off, 16, ns, c.embsum, s);
+  gemm(c.embsum, ns, m.lig_enc.W0, ns + sd, nullptr, X0, XS, nL, ns, ns, 0, s, nullptr, c.ligsig, c.lig_batch, ns);
+  // ---- ligand graph (bonds + radius graph)
+  launch_lig_radius(lig_pos, c.lig_batch, c.lig_ptr, nL, c.maxNl, cfg.lig_max_radius, c.lig_cap, c.adjrank, c.cnt_g, s);
+  launch_ll_count(c.adjrank, c.lig_batch, c.lig_ptr, nL, c.maxNl, c.bg, c.bt, c.cnt_g, c.cnt_t, s);
+  launch_exclusive_scan(c.cnt_g, c.goff_ll, nL, s);
+  launch_exclusive_scan(c.cnt_t, c.toff_ll, nL, s);
+  launch_ll_fill(lig_pos, c.lig_batch, c.lig_ptr, nL, c.maxNl, c.adjrank, c.goff_ll, c.toff_ll, c.bg, c.bt, c.Eb, c.bond_src,
+                 c.bond_dst, c.bond_grank, c.bond_trank, cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.ll_tgt, c.ll_tslot,
+                 c.ll_featidx, c.ll_batch, c.ll_dist, c.ll_nvec, c.ll_ew, s);
+  {
+    EdgeMlpArgs a = mlp_args(m.lig_edge, ns, c.Ell_cap, c.goff_ll + nL, c.ll_dist, m.off_lig, m.D, m.coeff_lig, m.nf + sd,
+                             c.ll_gvec, c.ll_batch, c.ll_ea);
+    a.feat = c.bond_attr; a.featidx = c.ll_featidx; a.nfeat = m.nf; a.W0f = m.lig_edge.W0; a.ldw0f = m.lig_edge.in;
+    launch_edge_mlp(a, s);
+  }
+  const RunGroup g_ll{0, nL, 0, nL, c.goff_ll, c.ll_tgt, c.ll_tslot, nullptr, c.ll_ea, c.Ell_cap, c.goff_ll + nL, nullptr,
+                      nullptr, c.ll_nvec, c.ll_ew, 1.f, c.msg[0]};
+  int xi = 0;
+  for (size_t i = 0; i < m.lig_emb_layers.size(); ++i, ++xi)
+    run_conv(m, m.lig_emb_layers[i], {g_ll}, c.rg_ll, 1, c.X[xi], c.X[xi + 1], 0, nL, s);
+  // receptor rows of the current table: cached embedding + sigma term on the scalars (cg_model.py:298-301)
+  launch_add_rowvec(c.X[xi] + (size_t)nL * XS, XS, c.rec_node_base, XS, c.rec_sig, ns, c.rec_batch, nR, c.rec_base_dim, ns, s);
+  // ---- cross graph
+  const float* cut_dev = nullptr;
+  if (cfg.dynamic_max_cross) {  // cutoff_b = 3 * tr_sigma_b + 20 (cg_model.py:321-322)
+    launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, s);
+    cut_dev = c.cutoff;
+  }
+  launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
+                     cfg.cross_max_distance, c.pairrank, c.cnt_l, c.cnt_r, s);
+  launch_exclusive_scan(c.cnt_l, c.offs_l, nL, s);
+  launch_exclusive_scan(c.cnt_r, c.offs_r, nR, s);
+  launch_cross_fill(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, c.pairrank, c.offs_l, c.offs_r,
+                    cut_dev, cfg.cross_max_distance, cfg.smooth_edges, c.g1_tgt, c.g1_tslot, c.g3_tgt, c.g3_tslot, c.pbatch,
+                    c.pdist, c.pnvec, c.pew, s);
+  launch_edge_mlp(mlp_args(m.cross_edge, ns, c.Elr_cap, c.offs_l + nL, c.pdist, m.off_cross, m.Dc, m.coeff_cross, sd,
+                           c.cross_gvec, c.pbatch, c.cross_ea), s);
+  // ---- interaction layers over [ll ; lig<-rec ; rec-rec ; rec<-lig]  (cg_model.py:329-349)
+  const RunGroup g_lr{nL, nR, 0, nL, c.offs_r, c.g1_tgt, c.g1_tslot, c.g1_tslot, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
+                      nullptr, c.pnvec, c.pew, 1.f, c.msg[1]};
+  const RunGroup g_rr{nL, nR, nL, nR, c.rr_goff, c.rr_tgt, c.rr_tslot, c.rr_arow, c.rec_edge_base, c.Err, nullptr, c.rec_sig,
+                      c.rr_batch, c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
+  const RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
+                      nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
+  const int Lc = (int)m.conv_layers.size();
+  for (int l = 0; l < Lc; ++l, ++xi) {
+    if (l < Lc - 1) run_conv(m, m.conv_layers[l], {g_ll, g_lr, g_rr, g_rl}, c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s);
+    else run_conv(m, m.conv_layers[l], {g_ll, g_lr}, c.rg_lig, 2, c.X[xi], c.X[xi + 1], 0, nL, s);
+  }
+  const float* XL = c.X[xi];
+  // ---- translation / rotation heads (cg_model.py:368-395)
+  const ConvW& F = m.final_conv;
+  launch_center_edges(lig_pos, c.lig_batch, c.lig_ptr, B, nL, c.c_dist, c.c_nvec, s);
+  launch_edge_mlp(mlp_args(m.center_edge, ns, nL, nullptr, c.c_dist, m.off_center, m.D, m.coeff_center, 0, c.center_gvec,
+                           c.lig_batch, c.c_ea), s);
+  launch_gather_cols(c.c_attr, F.n_edge, 0, c.c_ea, ns, nullptr, nL, ns, nullptr, s);
+  // fixed_center_conv: scalars of the atom; otherwise the reference indexes the ligand table by GRAPH id (cg_model.py:371-374)
+  launch_gather_cols(c.c_attr, F.n_edge, ns, XL, XS, cfg.fixed_center_conv ? c.c_xrow : c.lig_batch, nL, ns, nullptr, s);
+  launch_sh_rows(c.c_nvec, 1.f, nL, cfg.sh_lmax, c.c_sh, F.sh_dim, s);
+  run_direct_conv(m, F, c.c_attr, nL, c.c_hid, c.c_W, c.c_xrow, XL, c.c_sh, nullptr, nullptr, 0, c.c_out, s);
+  launch_segment_mean_bn(c.c_out, F.D_out, c.lig_ptr, nullptr, 0, B, F.D_out, F.has_bn ? F.bn_mean : nullptr,
+                         F.has_bn ? F.bn_scale : nullptr, F.has_bn ? F.bn_bias : nullptr, c.gp, F.D_out, s);
+  {
+    ScoreHeadArgs a{};
+    a.B = B; a.gp = c.gp; a.odd_parity = cfg.odd_parity; a.scale_by_sigma = cfg.scale_by_sigma; a.ns = ns; a.ldw0 = 1 + sd;
+    a.tr_w0n = m.tr_final.W0; a.tr_sig = c.tr_sig; a.tr_w3 = m.tr_final.W3; a.tr_b3 = m.tr_final.b3;
+    a.rot_w0n = m.rot_final.W0; a.rot_sig = c.rot_sig; a.rot_w3 = m.rot_final.W3; a.rot_b3 = m.rot_final.b3;
+    a.t_tr = t_tr; a.t_rot = t_rot; a.tr_smin = cfg.tr_sigma_min; a.tr_smax = cfg.tr_sigma_max;
+    a.rot_smin = cfg.rot_sigma_min; a.rot_smax = cfg.rot_sigma_max; a.so3_table = m.so3_table; a.so3_n = m.so3_n;
+    a.tr_out = tr_out; a.rot_out = rot_out;
+    launch_score_heads(a, s);
+  }
+  // ---- torsion head (cg_model.py:404-423)
+  if (c.nT > 0 && tor_out) {
+    const ConvW& T = m.tor_conv;
+    launch_tor_radius(lig_pos, c.lig_ptr, c.tor_u, c.tor_v, c.tor_batch, c.nT, cfg.lig_max_radius, c.tor_cap,
+                      cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.t_cnt, c.t_atom, c.t_dist, c.t_nvec, c.t_ew, c.t_bond_nvec, s);
+    launch_edge_mlp(mlp_args(m.final_edge, ns, c.Et, nullptr, c.t_dist, m.off_lig, m.D, m.coeff_lig, 0, m.final_edge.b0,
+                             nullptr, c.t_ea), s);
+    launch_gather_cols(c.t_attr, T.n_edge, 0, c.t_ea, ns, nullptr, c.Et, ns, nullptr, s);
+    launch_gather_cols(c.t_attr, T.n_edge, ns, XL, XS, c.t_atom, c.Et, ns, nullptr, s);
+    launch_gather_cols(c.t_attr, T.n_edge, 2 * ns, XL, XS, c.tor_eu, c.Et, ns, c.tor_ev, s);
+    launch_tor_sh(c.t_nvec, c.t_bond_nvec, c.nT, c.tor_cap, cfg.sh_lmax, m.tor_T, m.tor_ds, m.tor_dts, c.t_sh, s);
+    run_direct_conv(m, T, c.t_attr, c.Et, c.t_hid, c.t_W, c.t_atom, XL, c.t_sh, c.t_ew, c.t_cnt, c.tor_cap, c.t_out, s);
+    launch_segment_mean_bn(c.t_out, T.D_out, nullptr, c.t_cnt, c.tor_cap, c.nT, T.D_out, T.has_bn ? T.bn_mean : nullptr,
+                           T.has_bn ? T.bn_scale : nullptr, T.has_bn ? T.bn_bias : nullptr, c.t_feat, T.D_out, s);
+    TorHeadArgs a{};
+    a.nT = c.nT; a.ns = ns; a.in_dim = T.D_out; a.feat = c.t_feat; a.W0 = m.tor_W0; a.W3 = m.tor_W3;
+    a.tor_batch = c.tor_batch; a.t_tor = t_tor; a.smin = cfg.tor_sigma_min; a.smax = cfg.tor_sigma_max;
+    a.scale_by_sigma = cfg.scale_by_sigma; a.torus_table = m.torus_table; a.torus_n = m.torus_n; a.out = tor_out;
+    launch_tor_head(a, s);
+  }
+}
+
+// ========================================================================= conformer / sampling
+void modify_conformer(Model& m, float* lig_pos, const float* tr, const float* rot, const float* tor, hipStream_t s) {
+  DDMI_REQUIRE(m.has_complex, DDMI_ERR_STATE, "ddmi_set_complex must precede ddmi_modify_conformer");
+  Cx& c = *m.cx;
+  DDMI_REQUIRE(c.uniform && c.Nl_one > 0, DDMI_ERR_STATE,
+               "modify_conformer needs a batch of copies of one complex (utils/diffusion_utils.py:60-64)");
+  const bool torsion = tor != nullptr && c.R_one > 0;
+  DDMI_REQUIRE(!torsion || c.mask_rotate, DDMI_ERR_STATE, "mask_rotate was not provided to ddmi_set_complex");
+  launch_modify_conformer(lig_pos, c.B, c.Nl_one, torsion ? c.R_one : 0, c.rot_u, c.rot_v, c.mask_rotate, tr, rot,
+                          torsion ? tor : nullptr, s);
+}
+
+void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) {
+  DDMI_REQUIRE(m.has_complex, DDMI_ERR_STATE, "ddmi_set_complex must precede ddmi_sample");
+  DDMI_REQUIRE(sc.inference_steps > 0 && sc.tr_schedule && sc.rot_schedule && sc.tor_schedule, DDMI_ERR_ARG, "bad schedule");
+  Cx& c = *m.cx;
+  const ddmi_config& cfg = m.cfg;
+  const int steps = sc.inference_steps, B = c.B;
+  const bool torsion = !cfg.no_torsion && c.nT > 0;
+  // per-step time values for all graphs, uploaded once
+  std::vector<float> tvals((size_t)steps * 3 * B);
+  for (int k = 0; k < steps; ++k)
+    for (int b = 0; b < B; ++b) {
+      tvals[((size_t)k * 3 + 0) * B + b] = (float)sc.tr_schedule[k];
+      tvals[((size_t)k * 3 + 1) * B + b] = (float)sc.rot_schedule[k];
+      tvals[((size_t)k * 3 + 2) * B + b] = (float)sc.tor_schedule[k];
+    }
+  if (c.s_t_cap < tvals.size()) { c.s_t = m.cpool.alloc<float>(tvals.size()); c.s_t_cap = tvals.size(); }
+  float* t_dev = c.s_t;
+  DDMI_CHECK_HIP(hipMemcpyAsync(t_dev, tvals.data(), tvals.size() * 4, hipMemcpyHostToDevice, s));
+  long long* ids_dev = nullptr;
+  if (sc.sample_ids) {
+    if (!c.s_ids) c.s_ids = m.cpool.alloc<long long>(B);
+    DDMI_CHECK_HIP(hipMemcpyAsync(c.s_ids, sc.sample_ids, (size_t)B * 8, hipMemcpyHostToDevice, s));
+    ids_dev = c.s_ids;
+  }
+  DDMI_CHECK_HIP(hipStreamSynchronize(s));  // tvals is a stack-lifetime host buffer
+  for (int k = 0; k < steps; ++k) {
+    const bool last = k == steps - 1;
+    const double t_tr = sc.tr_schedule[k], t_rot = sc.rot_schedule[k], t_tor = sc.tor_schedule[k];
+    const double dt_tr = last ? t_tr : t_tr - sc.tr_schedule[k + 1];
+    const double dt_rot = last ? t_rot : t_rot - sc.rot_schedule[k + 1];
+    const double dt_tor = last ? t_tor : t_tor - sc.tor_schedule[k + 1];
+    const double s_tr = std::pow((double)cfg.tr_sigma_min, 1 - t_tr) * std::pow((double)cfg.tr_sigma_max, t_tr);
+    const double s_rot = std::pow((double)cfg.rot_sigma_min, 1 - t_rot) * std::pow((double)cfg.rot_sigma_max, t_rot);
+    const double s_tor = std::pow((double)cfg.tor_sigma_min, 1 - t_tor) * std::pow((double)cfg.tor_sigma_max, t_tor);
+    const float* tk = t_dev + (size_t)k * 3 * B;
+    forward(m, lig_pos, tk, tk + B, tk + 2 * B, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
+    const bool zero_noise = sc.no_random || (sc.no_final_step_noise && last) || sc.ode;
+    auto coeffs = [&](double sigma, double smin, double smax, double dt, int i, float& cs, float& cz) {
+      const double g = sigma * std::sqrt(2.0 * std::log(smax / smin));
+      double a = sc.ode ? 0.5 * g * g * dt : g * g * dt;
+      double z = g * std::sqrt(dt);
+      if (sc.temp_sampling[i] != 1.0) {
+        const double T = sc.temp_sampling[i], psi = sc.temp_psi[i], sdat = sc.temp_sigma_data[i];
+        const double sigma_data = std::exp(sdat * std::log(smax) + (1 - sdat) * std::log(smin));
+        const double lambda = (sigma_data + sigma) / (sigma_data + sigma / T);
+        a = g * g * dt * (lambda + T * psi / 2);
+        z = g * std::sqrt(dt * (1 + psi));
+      }
+      cs = (float)a;
+      cz = zero_noise ? 0.f : (float)z;
+    };
+    PerturbArgs p{};
+    p.B = B; p.R = torsion ? c.nT / B : 0; p.tr = c.s_tr; p.rot = c.s_rot; p.tor = c.s_tor;
+    coeffs(s_tr, cfg.tr_sigma_min, cfg.tr_sigma_max, dt_tr, 0, p.c_tr_s, p.c_tr_z);
+    coeffs(s_rot, cfg.rot_sigma_min, cfg.rot_sigma_max, dt_rot, 1, p.c_rot_s, p.c_rot_z);
+    coeffs(s_tor, cfg.tor_sigma_min, cfg.tor_sigma_max, dt_tor, 2, p.c_tor_s, p.c_tor_z);
+    if (!zero_noise) {
+      p.z_tr = sc.z_tr ? sc.z_tr + (size_t)k * B * 3 : nullptr;
+      p.z_rot = sc.z_rot ? sc.z_rot + (size_t)k * B * 3 : nullptr;
+      p.z_tor = sc.z_tor ? sc.z_tor + (size_t)k * c.nT : nullptr;
+      p.use_rng = 1;
+    }
+    p.seed = sc.seed; p.sample_ids = ids_dev; p.step = k;
+    launch_perturb(p, s);
+    modify_conformer(m, lig_pos, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
+  }
+}
+
+}  // namespace ddmi

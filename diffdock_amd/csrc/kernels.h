@@ -1,0 +1,166 @@
+// Launch wrappers of the gfx950 kernels (definitions in k_*.hip).  All pointers are device
+// pointers; `stream` is the caller's HIP stream.
+#pragma once
+#include "ddmi_common.h"
+
+namespace ddmi {
+
+// ---------------------------------------------------------------- k_gemm.hip
+// C[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + rowbias[ridx[m]][N]); row-major, fp32, f32 MFMA.
+// m_dev (optional) = device int with the live row count (<= M): row tiles past it exit.
+struct GemmArgs {
+  const float* A = nullptr; int lda = 0;
+  const float* W = nullptr; int ldw = 0;
+  const float* bias = nullptr;
+  const float* rowbias = nullptr; const int* ridx = nullptr; int ldrb = 0;
+  float* C = nullptr; int ldc = 0;
+  int M = 0, N = 0, K = 0;
+  const int* m_dev = nullptr;
+  int act = 0;  // 0 none, 1 relu, 2 tanh
+};
+void launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- k_conv.hip
+struct PathComp {   // one (path, input component i) slab of the node pre-contraction
+  int x_off;        // i_off + i  (column of x; element u at x_off + u*din)
+  int din, mul_in, mul_in_pad, mul_out;
+  int n_off;        // column offset inside a Y row: path.n_off + i*mul_out
+  int wp_off;       // float offset of the packed weights [HK*mul_out][mul_in_pad]
+};
+struct DevPath {    // coupling stage descriptor
+  int n_off, mul_out, din, ds, dout, s_off, c_off, o_off;
+  int mul_in, i_off, w_off;   // used by the per-edge-weight form (k_tp_apply)
+};
+struct CgItem { int path_begin, path_end, o_off, dout, w; };  // one (output block, w) work item
+
+// Y[node][k][n] = sum_u x[node][x_off + u*din] * Wp[(k*mul_out+w)][u]   (k < HK, bias row k = H)
+void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const PathComp* pcs, int n_pc,
+                          int max_mul_out, int HK, int HKp, int NTs, float* Y, hipStream_t s);
+
+struct EdgeConvArgs {
+  int gcount;            // gather nodes (one workgroup each)
+  const int* goff;       // [gcount+1]
+  const int* tgt;        // [E] global target node id
+  const int* tslot;      // [E] row of msg
+  const int* arow;       // [E] attr row or nullptr (identity)
+  int tbase;             // first target node id (row 0 of P)
+  const float* HE;       // [rows][H]   W1e * edge_attr (+ per-graph term)
+  const float* P;        // [tcount][H] W1s * x_target[:ns]
+  const float* Q;        // [gcount][H] W1d * x_gather[:ns] + b1
+  const float* Y;        // [gcount][HKp][NTs]
+  const float* nvec;     // [rows][3] unit edge vectors (by arow)
+  const float* ew;       // [rows] edge weights or nullptr
+  float sgn;             // +1 / -1 : direction of nvec for this group
+  int H, HKp, NT, NTs, sh_lmax;
+  const DevPath* paths; const float* ctab; const CgItem* items; int n_items;
+  float* msg;            // [E][XS]
+};
+void launch_edge_conv(const EdgeConvArgs& a, hipStream_t s);
+
+struct ReduceGroup { const int* toff; const float* msg; int tbase, tcount; };
+// X_out[s] = BN(mean over all groups' incoming messages) + pad(X_in[s]) for s in [nbase, nbase+ncount)
+void launch_reduce_bn(const ReduceGroup* groups_dev, int n_groups, int nbase, int ncount, int D_in, int D_out,
+                      const float* bn_mean, const float* bn_scale, const float* bn_bias, int residual,
+                      const float* X_in, float* X_out, int out_stride, hipStream_t s);
+
+// ---------------------------------------------------------------- k_graph.hip
+void launch_exclusive_scan(const int* in, int* out, int n, hipStream_t s);  // out[0..n], out[n] = total
+void launch_lig_radius(const float* pos, const int* batch, const int* ptr, int nL, int maxNl, float r, int cap,
+                       int* adjrank, int* cnt_g, hipStream_t s);
+void launch_ll_count(const int* adjrank, const int* batch, const int* ptr, int nL, int maxNl, const int* bg,
+                     const int* bt, int* cnt_g_inout, int* cnt_t, hipStream_t s);
+void launch_ll_fill(const float* pos, const int* batch, const int* ptr, int nL, int maxNl, const int* adjrank,
+                    const int* goff, const int* toff, const int* bg, const int* bt, int n_bonds, const int* bond_src,
+                    const int* bond_dst, const int* bond_grank, const int* bond_trank, float smooth_max,
+                    int* tgt, int* tslot, int* featidx, int* ebatch, float* dist, float* nvec, float* ew, hipStream_t s);
+void launch_cross_count(const float* lpos, const float* rpos, const int* lbatch, const int* rbatch, const int* lptr,
+                        const int* rptr, int nL, int nR, int maxNr, const float* cutoff, float const_cutoff,
+                        int* pairrank, int* cnt_l, int* cnt_r, hipStream_t s);
+void launch_cross_fill(const float* lpos, const float* rpos, const int* rbatch, const int* lptr, const int* rptr, int nL,
+                       int nR, int maxNr, const int* pairrank, const int* offs_l, const int* offs_r, const float* cutoff,
+                       float const_cutoff, int smooth, int* g1_tgt, int* g1_tslot, int* g3_tgt, int* g3_tslot,
+                       int* pbatch, float* pdist, float* pnvec, float* pew, hipStream_t s);
+void launch_cross_cutoff(const float* t_tr, int B, float smin, float smax, float* out, hipStream_t s);
+void launch_tor_radius(const float* pos, const int* ptr, const int* tor_u, const int* tor_v, const int* tor_batch, int nT,
+                       float r, int cap, float smooth_max, int* cnt, int* atom, float* dist, float* nvec, float* ew,
+                       float* bond_nvec, hipStream_t s);
+
+// ---------------------------------------------------------------- k_embed.hip
+void launch_time_embedding(const float* t, int B, const float* freq, int half, float scale, float* out, hipStream_t s);
+void launch_lig_node_embed(const int* x, int nL, const float* emb, const int* emb_off, int n_feat, int ns, float* out,
+                           hipStream_t s);
+void launch_add_rowvec(float* X, int ldx, const float* base, int ldb, const float* vec, int ldv, const int* idx, int rows,
+                       int cols, int zero_to, hipStream_t s);
+struct EdgeMlpArgs {
+  int E = 0; const int* e_dev = nullptr;          // rows (capacity) and optional live count
+  const float* dist = nullptr;                    // [E]
+  const float* offsets = nullptr; int D = 0; float coeff = 0;  // GaussianSmearing
+  const float* feat = nullptr; const int* featidx = nullptr; int nfeat = 0;  // optional extra features (row featidx[e], -1 = zeros)
+  const float* W0f = nullptr; int ldw0f = 0;      // [ns][nfeat]
+  const float* W0g = nullptr; int ldw0g = 0;      // [ns][D]
+  const float* gvec = nullptr; const int* gidx = nullptr;  // [G][ns] per-graph hidden term incl. bias (gidx null -> row 0)
+  const float* W1 = nullptr; const float* b1 = nullptr;    // [ns][ns], [ns]
+  int ns = 0;
+  float* out = nullptr; int ldo = 0;
+};
+void launch_edge_mlp(const EdgeMlpArgs& a, hipStream_t s);
+void launch_rec_edge_geom(const float* pos, const int* src, const int* dst, int E, float smooth_max, float* dist,
+                          float* nvec, float* ew, hipStream_t s);
+void launch_concat_rec_input(const float* rec_x, int ldx, const float* emb, int ns, int lm, int nR, float* out,
+                             hipStream_t s);
+
+// ---------------------------------------------------------------- k_readout.hip
+void launch_center_edges(const float* pos, const int* batch, const int* ptr, int B, int nL, float* dist, float* nvec,
+                         hipStream_t s);
+void launch_sh_rows(const float* nvec, float sgn, int E, int lmax, float* sh, int lds, hipStream_t s);
+void launch_tor_sh(const float* edge_nvec, const float* bond_nvec, int nT, int cap, int lmax, const float* T, int ds,
+                   int dts, float* out, hipStream_t s);
+void launch_gather_cols(float* dst, int ldd, int col0, const float* src, int lds_, const int* rowidx, int rows, int cols,
+                        const int* rowidx2, hipStream_t s);
+struct TpApplyArgs {
+  int E; const int* valid_cnt; int cap;   // if valid_cnt: edge e = seg*cap + r is live iff r < valid_cnt[seg]
+  const float* Wt; int ldw;               // [E][weight_numel]
+  const float* X; const int* xrow;        // gather rows of the node table (stride XS)
+  const float* sh; int lds_;              // [E][sh_dim]
+  const float* ew;                        // optional per-edge weight
+  const DevPath* paths; const float* ctab; const CgItem* items; int n_items;
+  float* out; int ldo;                    // [E][out_dim]
+};
+void launch_tp_apply(const TpApplyArgs& a, hipStream_t s);
+void launch_segment_mean_bn(const float* rows, int ldr, const int* seg_off, const int* seg_cnt, int cap, int n_seg,
+                            int D, const float* bn_mean, const float* bn_scale, const float* bn_bias, float* out,
+                            int ldo, hipStream_t s);
+struct ScoreHeadArgs {
+  int B; const float* gp;                       // [B][12] (or [B][6] odd_parity)
+  int odd_parity, scale_by_sigma, ns, ldw0;     // ldw0 = 1 + sigma_embed_dim (row stride of the first Linear)
+  const float *tr_w0n, *tr_sig, *tr_w3, *tr_b3;  // w0n [ns] (norm column), sig [B][ns] (incl bias)
+  const float *rot_w0n, *rot_sig, *rot_w3, *rot_b3;
+  const float *t_tr, *t_rot;
+  float tr_smin, tr_smax, rot_smin, rot_smax;
+  const float* so3_table; int so3_n;
+  float *tr_out, *rot_out;
+};
+void launch_score_heads(const ScoreHeadArgs& a, hipStream_t s);
+struct TorHeadArgs {
+  int nT, ns, in_dim; const float* feat;  // [nT][in_dim] after BN
+  const float* W0;                        // [ns][in_dim]
+  const float* W3;                        // [ns]
+  const int* tor_batch; const float* t_tor; float smin, smax; int scale_by_sigma;
+  const float* torus_table; int torus_n;
+  float* out;
+};
+void launch_tor_head(const TorHeadArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- k_sample.hip
+struct PerturbArgs {
+  int B, R; float *tr, *rot, *tor;  // scores in / perturbations out (in place)
+  const float *z_tr, *z_rot, *z_tor;  // may be nullptr (zero noise)
+  float c_tr_s, c_tr_z, c_rot_s, c_rot_z, c_tor_s, c_tor_z;
+  int use_rng; unsigned long long seed; const long long* sample_ids; int step;
+};
+void launch_perturb(const PerturbArgs& a, hipStream_t s);
+void launch_modify_conformer(float* pos, int B, int Nl, int R, const int* rot_u, const int* rot_v,
+                             const unsigned char* mask_rotate, const float* tr, const float* rot, const float* tor,
+                             hipStream_t s);
+
+}  // namespace ddmi

@@ -1,0 +1,100 @@
+// Host-side state of a ddmi_model: configuration, weights (host copy keyed like the reference
+// state_dict + packed device forms), the static description of the current batch of complexes
+// and the device workspace.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "o3_host.h"
+
+namespace ddmi {
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  int64_t numel() const { int64_t n = 1; for (auto d : shape) n *= d; return n; }
+};
+
+// Bump allocator over one hipMalloc'ed slab (freed with the owner).
+class DevicePool {
+ public:
+  ~DevicePool();
+  void* alloc_bytes(size_t n);
+  template <class T> T* alloc(size_t n) { return reinterpret_cast<T*>(alloc_bytes(n * sizeof(T))); }
+  template <class T> T* upload(const std::vector<T>& v) {
+    T* p = alloc<T>(v.size() ? v.size() : 1);
+    if (!v.empty()) DDMI_CHECK_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+  }
+  void release();
+  size_t total_bytes() const { return total_; }
+ private:
+  std::vector<void*> blocks_;
+  size_t total_ = 0;
+};
+
+struct ConvW {  // one TensorProductConvLayer
+  std::string name;
+  int G = 1;
+  bool faster = false, residual = true, has_bn = true, yform = true;
+  Irreps in_irr, sh_irr, out_irr;
+  TPTable table;
+  int n_edge = 0, H = 0, HK = 0, HKp = 0, D_in = 0, D_out = 0, NT = 0, NTs = 0, sh_dim = 0, Wn = 0;
+  std::vector<float*> W1, b1, W2, b2, wpack;
+  PathComp* pcs = nullptr; int n_pc = 0, max_mul_out = 0;
+  DevPath* paths = nullptr; float* ctab = nullptr; CgItem* items = nullptr; int n_items = 0;
+  float *bn_mean = nullptr, *bn_scale = nullptr, *bn_bias = nullptr;
+};
+
+struct Mlp2W { float *W0 = nullptr, *b0 = nullptr, *W3 = nullptr, *b3 = nullptr; int in = 0, hid = 0, out = 0; };
+
+struct DebugEntry { const void* ptr; std::vector<int64_t> shape; bool is_int; };
+
+struct Model {
+  ddmi_config cfg{};
+  int device = 0;
+  // ---- weights
+  std::vector<std::pair<std::string, std::vector<int64_t>>> spec;  // expected state_dict keys, in order
+  std::map<std::string, HostTensor> host_w;
+  bool committed = false;
+  DevicePool wpool, tpool;
+  int ns = 0, sd = 0, D = 0, Dc = 0, nf = 0, lm = 0, H = 0;
+  float* lig_emb = nullptr; int* lig_emb_off = nullptr;
+  Mlp2W lig_enc;     // additional_features_embedder as (W0 = [ns][ns+sd], b0)
+  Mlp2W lig_edge, rec_edge, rec_sigma, cross_edge, center_edge, final_edge, tr_final, rot_final;
+  float* rec_emb = nullptr; float *rec_enc_W = nullptr, *rec_enc_b = nullptr;
+  float *off_lig = nullptr, *off_rec = nullptr, *off_cross = nullptr, *off_center = nullptr;
+  float coeff_lig = 0, coeff_rec = 0, coeff_cross = 0, coeff_center = 0;
+  std::vector<ConvW> rec_emb_layers, lig_emb_layers, conv_layers;
+  ConvW final_conv, tor_conv;
+  float *tor_W0 = nullptr, *tor_W3 = nullptr;
+  float* tor_T = nullptr; int tor_ds = 0, tor_dts = 0;  // FullTensorProduct(sh, 2e) dense table
+  float* time_freq = nullptr;
+  std::vector<float> time_freq_host;
+  float *so3_table = nullptr, *torus_table = nullptr; int so3_n = 0, torus_n = 0;
+  // ---- complex + workspace
+  bool has_complex = false;
+  DevicePool cpool;
+  struct Cx;  // defined in complex.cpp
+  std::shared_ptr<Cx> cx;
+  std::map<std::string, DebugEntry> debug;
+  // ---- kernel timing
+  bool timing = false;
+  struct TimedPhase { std::string name; double ms = 0; int64_t launches = 0; };
+  std::vector<TimedPhase> phases;
+};
+
+// weights.cpp
+void build_weight_spec(Model& m);
+void commit_weights(Model& m);
+// complex.cpp
+void set_complex(Model& m, const ddmi_complex& c, hipStream_t s);
+void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor, float* tr_out,
+             float* rot_out, float* tor_out, hipStream_t s);
+void modify_conformer(Model& m, float* lig_pos, const float* tr, const float* rot, const float* tor, hipStream_t s);
+void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s);
+
+}  // namespace ddmi

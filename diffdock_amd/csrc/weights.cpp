@@ -1,0 +1,330 @@
+// Weight ABI = the reference state_dict keys (models/cg_model.py:85-255,
+// models/layers.py:10-67, models/tensor_layers.py:298-307) and their device packing.
+#include <algorithm>
+#include <cmath>
+
+#include "model.h"
+
+namespace ddmi {
+
+static const int LIG_DIMS[16] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2};  // datasets/process_mols.py:59-76
+static const int REC_DIMS[1] = {38};                                                   // process_mols.py:85-87
+
+DevicePool::~DevicePool() { release(); }
+void DevicePool::release() {
+  for (void* p : blocks_) hipFree(p);
+  blocks_.clear();
+  total_ = 0;
+}
+void* DevicePool::alloc_bytes(size_t n) {
+  void* p = nullptr;
+  const size_t bytes = round_up((long)(n ? n : 1), 256);
+  DDMI_CHECK_HIP(hipMalloc(&p, bytes));
+  blocks_.push_back(p);
+  total_ += bytes;
+  return p;
+}
+
+static Irreps layer_irreps(const ddmi_config& c, int i) {
+  const int ns = c.ns, nv = c.nv, last = c.reduce_pseudoscalars ? nv : ns;
+  i = std::min(i, 3);
+  if (c.use_second_order_repr) {
+    switch (i) {
+      case 0: return make_irreps({{ns, 0, 1}});
+      case 1: return make_irreps({{ns, 0, 1}, {nv, 1, -1}, {nv, 2, 1}});
+      case 2: return make_irreps({{ns, 0, 1}, {nv, 1, -1}, {nv, 2, 1}, {nv, 1, 1}, {nv, 2, -1}});
+      default: return make_irreps({{ns, 0, 1}, {nv, 1, -1}, {nv, 2, 1}, {nv, 1, 1}, {nv, 2, -1}, {last, 0, -1}});
+    }
+  }
+  switch (i) {
+    case 0: return make_irreps({{ns, 0, 1}});
+    case 1: return make_irreps({{ns, 0, 1}, {nv, 1, -1}});
+    case 2: return make_irreps({{ns, 0, 1}, {nv, 1, -1}, {nv, 1, 1}});
+    default: return make_irreps({{ns, 0, 1}, {nv, 1, -1}, {nv, 1, 1}, {last, 0, -1}});
+  }
+}
+
+static int conv_groups(const ddmi_config& c, int l) {
+  if (!c.differentiate_convolutions) return 1;
+  return l == c.num_conv_layers - 1 ? 2 : 4;
+}
+
+static void init_conv_meta(const ddmi_config& c, ConvW& L, const std::string& name, const Irreps& in, const Irreps& sh,
+                           const Irreps& out, int n_edge, int G, bool faster, bool residual, bool yform) {
+  L.name = name; L.G = G; L.faster = faster; L.residual = residual; L.has_bn = c.batch_norm != 0; L.yform = yform;
+  L.in_irr = in; L.sh_irr = sh; L.out_irr = out;
+  L.table = faster ? faster_table(in, out) : fctp_table(in, sh, out);
+  std::stable_sort(L.table.paths.begin(), L.table.paths.end(),
+                   [](const TPPath& a, const TPPath& b) { return a.out_block < b.out_block; });
+  L.n_edge = n_edge; L.H = n_edge; L.HK = L.H + 1; L.HKp = (int)round_up(L.HK, 4);
+  L.D_in = irreps_dim(in); L.D_out = irreps_dim(out); L.sh_dim = irreps_dim(sh); L.Wn = L.table.weight_numel;
+  int nt = 0;
+  for (auto& p : L.table.paths) nt += p.din * p.mul_out;
+  L.NT = nt; L.NTs = (int)round_up(nt, 64);
+}
+
+void build_weight_spec(Model& m) {
+  const ddmi_config& c = m.cfg;
+  DDMI_REQUIRE(c.ns > 0 && c.nv >= 0 && c.num_conv_layers >= 1, DDMI_ERR_ARG, "bad ns/nv/num_conv_layers");
+  DDMI_REQUIRE(c.sh_lmax == 1 || c.sh_lmax == 2, DDMI_ERR_ARG, "sh_lmax must be 1 or 2");
+  DDMI_REQUIRE(c.sigma_embed_dim % 2 == 0 && c.sigma_embed_dim >= 4, DDMI_ERR_ARG, "sigma_embed_dim must be even");
+  DDMI_REQUIRE(c.embed_also_ligand || c.num_prot_emb_layers == 0, DDMI_ERR_ARG,
+               "embed_also_ligand=False with embedding layers is rejected by the reference (cg_model.py:263)");
+  DDMI_REQUIRE(irreps_dim(layer_irreps(c, 3)) <= XS, DDMI_ERR_ARG, "irreps wider than the node-table stride");
+  m.ns = c.ns; m.sd = c.sigma_embed_dim; m.D = c.distance_embed_dim; m.Dc = c.cross_distance_embed_dim;
+  m.nf = c.in_lig_edge_features; m.lm = c.lm_embedding_dim; m.H = 3 * c.ns;
+  auto& S = m.spec;
+  S.clear();
+  const int ns = m.ns, sd = m.sd;
+  auto lin = [&](const std::string& n, int fin, int fout, bool bias = true) {
+    S.push_back({n + ".weight", {fout, fin}});
+    if (bias) S.push_back({n + ".bias", {fout}});
+  };
+  auto mlp = [&](const std::string& n, int fin, int hid, int fout) { lin(n + ".0", fin, hid); lin(n + ".3", hid, fout); };
+  auto encoder = [&](const std::string& n, const int* dims, int nd, int extra) {
+    for (int i = 0; i < nd; ++i) S.push_back({n + ".atom_embedding_list." + std::to_string(i) + ".weight", {dims[i], ns}});
+    if (extra > 0) lin(n + ".additional_features_embedder", extra + ns, ns);
+  };
+  auto bn = [&](const std::string& n, const Irreps& irr) {
+    int n0 = 0;
+    for (auto& b : irr) if (b.l == 0 && b.p == 1) n0 += b.mul;
+    const int nf = irreps_num(irr);
+    S.push_back({n + ".running_mean", {n0}});
+    S.push_back({n + ".running_var", {nf}});
+    S.push_back({n + ".weight", {nf}});
+    S.push_back({n + ".bias", {n0}});
+  };
+  auto conv = [&](ConvW& L) {
+    for (int g = 0; g < L.G; ++g) {
+      const std::string pre = L.G == 1 ? L.name + ".fc" : L.name + ".fc." + std::to_string(g);
+      lin(pre + ".0", L.n_edge, L.H);
+      lin(pre + ".3", L.H, L.Wn);
+    }
+    if (L.has_bn) bn(L.name + ".batch_norm", L.out_irr);
+  };
+  const Irreps sh = sh_irreps(c.sh_lmax);
+  const bool faster = c.sh_lmax == 1 && !c.use_second_order_repr;
+  const int K = c.num_prot_emb_layers, Lc = c.num_conv_layers;
+  encoder("lig_node_embedding", LIG_DIMS, 16, sd);
+  mlp("lig_edge_embedding", m.nf + sd + m.D, ns, ns);
+  encoder("rec_node_embedding", REC_DIMS, 1, m.lm);
+  mlp("rec_edge_embedding", m.D, ns, ns);
+  mlp("rec_sigma_embedding", sd, ns, ns);
+  mlp("cross_edge_embedding", sd + m.Dc, ns, ns);
+  S.push_back({"lig_distance_expansion.offset", {m.D}});
+  S.push_back({"rec_distance_expansion.offset", {m.D}});
+  S.push_back({"cross_distance_expansion.offset", {m.Dc}});
+  m.rec_emb_layers.assign(K, ConvW());
+  m.lig_emb_layers.assign(c.embed_also_ligand ? K : 0, ConvW());
+  m.conv_layers.assign(Lc, ConvW());
+  for (int i = 0; i < K; ++i) {
+    init_conv_meta(c, m.rec_emb_layers[i], "rec_emb_layers." + std::to_string(i), layer_irreps(c, i), sh,
+                   layer_irreps(c, i + 1), 3 * ns, 1, faster, true, true);
+    conv(m.rec_emb_layers[i]);
+  }
+  for (int i = 0; i < (int)m.lig_emb_layers.size(); ++i) {
+    init_conv_meta(c, m.lig_emb_layers[i], "lig_emb_layers." + std::to_string(i), layer_irreps(c, i), sh,
+                   layer_irreps(c, i + 1), 3 * ns, 1, faster, true, true);
+    conv(m.lig_emb_layers[i]);
+  }
+  for (int l = 0; l < Lc; ++l) {
+    init_conv_meta(c, m.conv_layers[l], "conv_layers." + std::to_string(l), layer_irreps(c, K + l), sh,
+                   layer_irreps(c, K + l + 1), 3 * ns, conv_groups(c, l), faster, true, true);
+    conv(m.conv_layers[l]);
+  }
+  const Irreps last_out = layer_irreps(c, K + Lc);
+  S.push_back({"center_distance_expansion.offset", {m.D}});
+  mlp("center_edge_embedding", m.D + sd, ns, ns);
+  const Irreps fout = c.odd_parity ? make_irreps({{1, 1, -1}, {1, 1, 1}}) : make_irreps({{2, 1, -1}, {2, 1, 1}});
+  init_conv_meta(c, m.final_conv, "final_conv", last_out, sh, fout, 2 * ns, 1, false, false, false);
+  conv(m.final_conv);
+  mlp("tr_final_layer", 1 + sd, ns, 1);
+  mlp("rot_final_layer", 1 + sd, ns, 1);
+  if (!c.no_torsion) {
+    mlp("final_edge_embedding", m.D, ns, ns);
+    Irreps tor_sh;
+    full_tp_dense(sh, make_irreps({{1, 2, 1}}), &tor_sh);
+    const Irreps tout = c.odd_parity ? make_irreps({{ns, 0, -1}}) : make_irreps({{ns, 0, -1}, {ns, 0, 1}});
+    init_conv_meta(c, m.tor_conv, "tor_bond_conv", last_out, tor_sh, tout, 3 * ns, 1, false, false, false);
+    conv(m.tor_conv);
+    lin("tor_final_layer.0", c.odd_parity ? ns : 2 * ns, ns, false);
+    lin("tor_final_layer.3", ns, 1, false);
+  }
+}
+
+// ------------------------------------------------------------------------------ commit
+static const HostTensor& W(Model& m, const std::string& k) {
+  auto it = m.host_w.find(k);
+  DDMI_REQUIRE(it != m.host_w.end(), DDMI_ERR_KEY, "missing state_dict key: " + k);
+  return it->second;
+}
+static float* up(Model& m, const std::string& k) { return m.wpool.upload(W(m, k).data); }
+
+static Mlp2W up_mlp(Model& m, const std::string& n) {
+  Mlp2W r;
+  const HostTensor &w0 = W(m, n + ".0.weight"), &w3 = W(m, n + ".3.weight");
+  r.in = (int)w0.shape[1]; r.hid = (int)w0.shape[0]; r.out = (int)w3.shape[0];
+  r.W0 = up(m, n + ".0.weight"); r.b0 = up(m, n + ".0.bias");
+  r.W3 = up(m, n + ".3.weight"); r.b3 = up(m, n + ".3.bias");
+  return r;
+}
+
+static void commit_conv(Model& m, ConvW& L) {
+  const int H = L.H, HK = L.HK;
+  // coupling tables ---------------------------------------------------------------
+  std::vector<DevPath> dp;
+  std::vector<float> ctab;
+  int n_off = 0;
+  for (auto& p : L.table.paths) {
+    DevPath d{};
+    d.n_off = n_off; d.mul_out = p.mul_out; d.din = p.din; d.ds = p.ds; d.dout = p.dout; d.s_off = p.s_off;
+    d.c_off = (int)ctab.size(); d.o_off = p.o_off; d.mul_in = p.mul_in; d.i_off = p.i_off; d.w_off = p.w_off;
+    for (double v : p.C) ctab.push_back((float)v);
+    dp.push_back(d);
+    n_off += p.din * p.mul_out;
+  }
+  std::vector<CgItem> items;
+  for (int ob = 0; ob < (int)L.out_irr.size(); ++ob) {
+    int pb = -1, pe = -1;
+    for (int i = 0; i < (int)L.table.paths.size(); ++i)
+      if (L.table.paths[i].out_block == ob) { if (pb < 0) pb = i; pe = i + 1; }
+    if (pb < 0) { pb = pe = 0; }  // an output block no path reaches stays zero
+    for (int w = 0; w < L.out_irr[ob].mul; ++w) items.push_back({pb, pe, L.out_irr[ob].off, L.out_irr[ob].d(), w});
+  }
+  L.paths = m.wpool.upload(dp);
+  L.ctab = m.wpool.upload(ctab);
+  L.items = m.wpool.upload(items);
+  L.n_items = (int)items.size();
+  // dense layers --------------------------------------------------------------------
+  std::vector<PathComp> pcs;
+  L.max_mul_out = 0;
+  for (int g = 0; g < L.G; ++g) {
+    const std::string pre = L.G == 1 ? L.name + ".fc" : L.name + ".fc." + std::to_string(g);
+    L.W1.push_back(up(m, pre + ".0.weight"));
+    L.b1.push_back(up(m, pre + ".0.bias"));
+    const HostTensor &w2 = W(m, pre + ".3.weight"), &b2 = W(m, pre + ".3.bias");
+    if (!L.yform) {
+      L.W2.push_back(m.wpool.upload(w2.data));
+      L.b2.push_back(m.wpool.upload(b2.data));
+      continue;
+    }
+    // packed [path][HK*mul_out][mul_in_pad]: Wp[(k*mul_out+w)][u] = W2[slot(u,w)][k], k = H -> bias
+    std::vector<float> pack;
+    for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
+      const TPPath& p = L.table.paths[pi];
+      const int pad = (int)round_up(p.mul_in, 8);
+      const size_t base = pack.size();
+      pack.resize(base + (size_t)HK * p.mul_out * pad, 0.f);
+      for (int k = 0; k < HK; ++k)
+        for (int w = 0; w < p.mul_out; ++w)
+          for (int u = 0; u < p.mul_in; ++u) {
+            const size_t slot = (size_t)p.w_off + (size_t)u * p.mul_out + w;
+            pack[base + ((size_t)k * p.mul_out + w) * pad + u] = k < H ? w2.data[slot * H + k] : b2.data[slot];
+          }
+      if (g == 0) {
+        for (int i = 0; i < p.din; ++i)
+          pcs.push_back({p.i_off + i, p.din, p.mul_in, pad, p.mul_out, dp[pi].n_off + i * p.mul_out, (int)base});
+        L.max_mul_out = std::max(L.max_mul_out, p.mul_out);
+      }
+    }
+    L.wpack.push_back(m.wpool.upload(pack));
+  }
+  if (L.yform) { L.pcs = m.wpool.upload(pcs); L.n_pc = (int)pcs.size(); }
+  // batch norm (e3nn.nn.BatchNorm eval, eps 1e-5): per-column mean / scale / bias ---------
+  if (L.has_bn) {
+    const std::string n = L.name + ".batch_norm";
+    const HostTensor &rm = W(m, n + ".running_mean"), &rv = W(m, n + ".running_var"), &w = W(m, n + ".weight"),
+                     &b = W(m, n + ".bias");
+    std::vector<float> mean(L.D_out, 0.f), scale(L.D_out, 1.f), bias(L.D_out, 0.f);
+    int iv = 0, im = 0;
+    for (auto& blk : L.out_irr) {
+      for (int u = 0; u < blk.mul; ++u) {
+        const float sc = w.data[iv + u] / std::sqrt(rv.data[iv + u] + 1e-5f);
+        for (int k = 0; k < blk.d(); ++k) {
+          const int col = blk.off + u * blk.d() + k;
+          scale[col] = sc;
+          if (blk.l == 0 && blk.p == 1) { mean[col] = rm.data[im + u]; bias[col] = b.data[im + u]; }
+        }
+      }
+      iv += blk.mul;
+      if (blk.l == 0 && blk.p == 1) im += blk.mul;
+    }
+    L.bn_mean = m.wpool.upload(mean); L.bn_scale = m.wpool.upload(scale); L.bn_bias = m.wpool.upload(bias);
+  }
+}
+
+void commit_weights(Model& m) {
+  for (auto& kv : m.spec) {
+    auto it = m.host_w.find(kv.first);
+    DDMI_REQUIRE(it != m.host_w.end(), DDMI_ERR_KEY, "missing state_dict key: " + kv.first);
+    DDMI_REQUIRE(it->second.shape == kv.second, DDMI_ERR_KEY, "shape mismatch for " + kv.first);
+  }
+  m.wpool.release();
+  const ddmi_config& c = m.cfg;
+  // ligand atom encoder: concatenated embedding tables
+  {
+    std::vector<float> emb;
+    std::vector<int> off;
+    int rows = 0;
+    for (int i = 0; i < 16; ++i) {
+      off.push_back(rows);
+      const HostTensor& t = W(m, "lig_node_embedding.atom_embedding_list." + std::to_string(i) + ".weight");
+      emb.insert(emb.end(), t.data.begin(), t.data.end());
+      rows += LIG_DIMS[i];
+    }
+    m.lig_emb = m.wpool.upload(emb);
+    m.lig_emb_off = m.wpool.upload(off);
+    m.lig_enc.W0 = up(m, "lig_node_embedding.additional_features_embedder.weight");
+    m.lig_enc.b0 = up(m, "lig_node_embedding.additional_features_embedder.bias");
+  }
+  m.rec_emb = up(m, "rec_node_embedding.atom_embedding_list.0.weight");
+  if (m.lm > 0) {
+    m.rec_enc_W = up(m, "rec_node_embedding.additional_features_embedder.weight");
+    m.rec_enc_b = up(m, "rec_node_embedding.additional_features_embedder.bias");
+  }
+  m.lig_edge = up_mlp(m, "lig_edge_embedding");
+  m.rec_edge = up_mlp(m, "rec_edge_embedding");
+  m.rec_sigma = up_mlp(m, "rec_sigma_embedding");
+  m.cross_edge = up_mlp(m, "cross_edge_embedding");
+  m.center_edge = up_mlp(m, "center_edge_embedding");
+  m.tr_final = up_mlp(m, "tr_final_layer");
+  m.rot_final = up_mlp(m, "rot_final_layer");
+  auto offs = [&](const std::string& k, float*& dev, float& coeff) {
+    const HostTensor& t = W(m, k);
+    DDMI_REQUIRE(t.data.size() >= 2, DDMI_ERR_ARG, "distance expansion needs >= 2 gaussians");
+    dev = m.wpool.upload(t.data);
+    const float d = t.data[1] - t.data[0];             // GaussianSmearing.coeff, models/layers.py:25
+    coeff = (float)(-0.5 / ((double)d * (double)d));
+  };
+  offs("lig_distance_expansion.offset", m.off_lig, m.coeff_lig);
+  offs("rec_distance_expansion.offset", m.off_rec, m.coeff_rec);
+  offs("cross_distance_expansion.offset", m.off_cross, m.coeff_cross);
+  offs("center_distance_expansion.offset", m.off_center, m.coeff_center);
+  for (auto& L : m.rec_emb_layers) commit_conv(m, L);
+  for (auto& L : m.lig_emb_layers) commit_conv(m, L);
+  for (auto& L : m.conv_layers) commit_conv(m, L);
+  commit_conv(m, m.final_conv);
+  if (!c.no_torsion) {
+    m.final_edge = up_mlp(m, "final_edge_embedding");
+    commit_conv(m, m.tor_conv);
+    m.tor_W0 = up(m, "tor_final_layer.0.weight");
+    m.tor_W3 = up(m, "tor_final_layer.3.weight");
+    Irreps tsh;
+    std::vector<double> T = full_tp_dense(sh_irreps(c.sh_lmax), make_irreps({{1, 2, 1}}), &tsh);
+    std::vector<float> Tf(T.begin(), T.end());
+    m.tor_T = m.wpool.upload(Tf);
+    m.tor_ds = (c.sh_lmax + 1) * (c.sh_lmax + 1);
+    m.tor_dts = irreps_dim(tsh);
+  }
+  // sinusoidal embedding frequencies (utils/diffusion_utils.py:101-103) unless supplied by the caller
+  const int half = m.sd / 2;
+  if ((int)m.time_freq_host.size() != half) {
+    m.time_freq_host.resize(half);
+    const double e = std::log(10000.0) / (half - 1);
+    for (int k = 0; k < half; ++k) m.time_freq_host[k] = std::exp((float)((float)k * (float)(-e)));
+  }
+  m.time_freq = m.wpool.upload(m.time_freq_host);
+  m.committed = true;
+}
+
+}  // namespace ddmi

@@ -235,6 +235,8 @@ def set_time(batch, t_tr, t_rot, t_tor, batchsize, device=None):
 def as_numpy_mask(mask_rotate):
     """mask_rotate is a numpy bool [R, Nl] on a single graph and a list of them on a
     batch (Appendix A.9); sampling() uses data_list[0]['ligand'].mask_rotate[0]."""
-    if isinstance(mask_rotate, list):
+    while isinstance(mask_rotate, (list, tuple)):
         mask_rotate = mask_rotate[0]
+    if torch.is_tensor(mask_rotate):
+        mask_rotate = mask_rotate.cpu().numpy()
     return np.asarray(mask_rotate, dtype=bool)

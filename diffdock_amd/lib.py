@@ -1,0 +1,118 @@
+"""ctypes binding of libddmi.so (include/ddmi.h) -- the stub INTEGRATION.md shows.
+
+The product path has exactly one implementation: the gfx950 library built from
+diffdock_amd/csrc by `make` (or `__graft_entry__.build()`).  If it is missing, loading
+fails loudly; there is no CPU / PyTorch fallback.  (`load(path=...)` exists so that the CPU
+test-suite can open the hipemu build of the same sources -- test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+DEFAULT_LIB = os.path.join(CSRC, "libddmi.so")
+
+
+class DdmiError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("ns", "nv", "num_conv_layers", "num_prot_emb_layers", "sh_lmax",
+                                         "sigma_embed_dim", "distance_embed_dim", "cross_distance_embed_dim",
+                                         "in_lig_edge_features", "lm_embedding_dim")] + \
+               [(n, C.c_float) for n in ("lig_max_radius", "rec_max_radius", "cross_max_distance", "center_max_distance")] + \
+               [(n, C.c_int32) for n in ("dynamic_max_cross", "use_second_order_repr", "reduce_pseudoscalars",
+                                         "differentiate_convolutions", "embed_also_ligand", "batch_norm", "smooth_edges",
+                                         "odd_parity", "no_torsion", "scale_by_sigma", "fixed_center_conv")] + \
+               [(n, C.c_float) for n in ("embedding_scale", "tr_sigma_min", "tr_sigma_max", "rot_sigma_min",
+                                         "rot_sigma_max", "tor_sigma_min", "tor_sigma_max")]
+
+
+class Complex(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_graphs", "n_lig", "n_rec", "n_bond_edges", "n_rec_edges", "n_tor")] + \
+               [(n, C.c_void_p) for n in ("lig_ptr", "rec_ptr", "lig_x", "bond_index", "bond_attr", "edge_mask", "rec_x",
+                                          "rec_pos", "rec_edge_index", "mask_rotate")]
+
+
+class SampleCfg(C.Structure):
+    _fields_ = [("inference_steps", C.c_int32), ("tr_schedule", C.c_void_p), ("rot_schedule", C.c_void_p),
+                ("tor_schedule", C.c_void_p), ("ode", C.c_int32), ("no_random", C.c_int32),
+                ("no_final_step_noise", C.c_int32), ("temp_sampling", C.c_double * 3), ("temp_psi", C.c_double * 3),
+                ("temp_sigma_data", C.c_double * 3), ("seed", C.c_uint64), ("sample_ids", C.c_void_p),
+                ("z_tr", C.c_void_p), ("z_rot", C.c_void_p), ("z_tor", C.c_void_p)]
+
+
+def make_config(cfg) -> Config:
+    c = Config()
+    for name, _ in Config._fields_:
+        if name == "lm_embedding_dim":
+            c.lm_embedding_dim = cfg.lm_embedding_dim
+        else:
+            setattr(c, name, getattr(cfg, name))
+    return c
+
+
+_DECLS = {
+    "ddmi_create": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(C.c_void_p)]),
+    "ddmi_destroy": (None, [C.c_void_p]),
+    "ddmi_last_error": (C.c_char_p, []),
+    "ddmi_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "ddmi_commit_weights": (C.c_int, [C.c_void_p]),
+    "ddmi_num_weights": (C.c_int, [C.c_void_p]),
+    "ddmi_weight_spec": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "ddmi_set_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "ddmi_set_time_frequencies": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "ddmi_set_complex": (C.c_int, [C.c_void_p, C.POINTER(Complex), C.c_void_p]),
+    "ddmi_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
+    "ddmi_modify_conformer": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "ddmi_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SampleCfg), C.c_void_p]),
+    "ddmi_debug_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ddmi_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddmi_wigner_3j": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ddmi_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddmi_kernel_timings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_DECLS)
+_cache = {}
+
+
+def build(verbose=False):
+    """Compile libddmi.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-j8", "-C", CSRC], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise DdmiError("building libddmi.so failed")
+    return DEFAULT_LIB
+
+
+def load(path: str | None = None):
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _cache:
+        return _cache[path]
+    if not os.path.exists(path):
+        raise DdmiError(f"{path} not found: build the HIP extension first (make -C diffdock_amd/csrc, or "
+                        f"__graft_entry__.build()).  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _DECLS.items():
+        fn = getattr(lib, name)       # AttributeError if the library does not export the symbol
+        fn.restype, fn.argtypes = res, args
+    _cache[path] = lib
+    return lib
+
+
+def check(lib, code):
+    if code != 0:
+        raise DdmiError(f"ddmi error {code}: {lib.ddmi_last_error().decode()}")
+
+
+def wigner_3j(lib, l1, l2, l3):
+    out = np.zeros((2 * l1 + 1, 2 * l2 + 1, 2 * l3 + 1))
+    check(lib, lib.ddmi_wigner_3j(l1, l2, l3, out.ctypes.data))
+    return out

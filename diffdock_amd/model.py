@@ -1,0 +1,230 @@
+"""`MIScoreModel`: drop-in for the reference score model object.
+
+The reference boundary for this path is a Python duck type:
+    model = get_model(args, device, t_to_sigma, no_parallel=True)      utils/utils.py:172
+    model.load_state_dict(sd, strict=True); model.to(device); model.eval()   inference.py:202-205
+    tr, rot, tor = model(batch)[:3]                                    utils/sampling.py:116
+`MIScoreModel` keeps that surface (same state_dict keys, same call signature, same return
+tuple `(tr[B,3], rot[B,3], tor[sum R], None)`) and forwards to libddmi.so through ctypes.
+PyTorch is used only as the owner of device memory and of the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .config import ModelConfig, config_from_args
+from .hetero import as_numpy_mask
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def time_frequencies(sigma_embed_dim: int) -> torch.Tensor:
+    """Frequencies of sinusoidal_embedding, computed with the reference's exact fp32 op sequence
+    (utils/diffusion_utils.py:101-103) so the device phases are bit-identical."""
+    half = sigma_embed_dim // 2
+    emb = math.log(10000) / (half - 1)
+    return torch.exp(torch.arange(half, dtype=torch.float32) * -emb)
+
+
+class MIScoreModel:
+    def __init__(self, cfg: ModelConfig, device="cuda:0", lib_path: str | None = None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.lib = _lib.load(lib_path)
+        self._h = C.c_void_p()
+        dev_index = self.device.index or 0 if self.device.type == "cuda" else 0
+        _lib.check(self.lib, self.lib.ddmi_create(C.byref(_lib.make_config(cfg)), dev_index, C.byref(self._h)))
+        self._complex_key = None
+        self._keep = None
+        self._state: Dict[str, torch.Tensor] = {}
+        self._tables_set = False
+        self.training = False
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def eval(self):
+        return self
+
+    def to(self, device):
+        assert torch.device(device).type == self.device.type, "a handle is bound to its device at construction"
+        return self
+
+    def parameters(self):
+        return iter(self._state.values())
+
+    def state_dict(self):
+        return dict(self._state)
+
+    def expected_keys(self):
+        n = self.lib.ddmi_num_weights(self._h)
+        out = {}
+        for i in range(n):
+            key, shape, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+            _lib.check(self.lib, self.lib.ddmi_weight_spec(self._h, i, C.byref(key), shape, C.byref(nd)))
+            out[key.value.decode()] = tuple(shape[:nd.value])
+        return out
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        expected = self.expected_keys()
+        # e3nn keeps constant buffers under *.tp.* / final_tp_tor.* in real checkpoints; they are not weights
+        given = {k: v for k, v in sd.items() if ".tp." not in k and not k.startswith("final_tp_tor.")}
+        missing = [k for k in expected if k not in given]
+        unexpected = [k for k in given if k not in expected]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        freq = time_frequencies(self.cfg.sigma_embed_dim).contiguous()
+        _lib.check(self.lib, self.lib.ddmi_set_time_frequencies(self._h, _ptr(freq), freq.numel()))
+        for k in expected:
+            if k not in given:
+                continue
+            t = given[k].detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            _lib.check(self.lib, self.lib.ddmi_set_weight(self._h, k.encode(), _ptr(t), shape, t.dim()))
+            self._state[k] = t
+        _lib.check(self.lib, self.lib.ddmi_commit_weights(self._h))
+        self._complex_key = None
+        return self
+
+    def set_tables(self, so3_exp_score_norms: np.ndarray, torus_score_norm: np.ndarray):
+        """Score-norm tables (utils/so3.py:59, utils/torus.py:72-76); see diffdock_amd/tables.py."""
+        for kind, tab in ((0, so3_exp_score_norms), (1, torus_score_norm)):
+            tab = np.ascontiguousarray(tab, dtype=np.float64)
+            _lib.check(self.lib, self.lib.ddmi_set_table(self._h, kind, tab.ctypes.data, tab.size))
+        self._tables_set = True
+        return self
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.ddmi_destroy(self._h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ batch -> ddmi_complex
+    def _stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def _ensure_complex(self, data):
+        lig, rec = data["ligand"], data["receptor"]
+        bond, rr = data["ligand", "ligand"], data["receptor", "receptor"]
+        key = (rec.x.data_ptr(), rec.pos.data_ptr(), lig.x.data_ptr(), bond.edge_index.data_ptr(),
+               rr.edge_index.data_ptr(), int(data.num_graphs), tuple(lig.pos.shape), tuple(rec.pos.shape))
+        if key == self._complex_key:
+            return
+        if not self._tables_set:
+            from .tables import default_tables
+            self.set_tables(*default_tables())
+        dev = self.device
+        B = int(data.num_graphs)
+
+        def ptr_of(batch_vec, n):
+            cnt = torch.bincount(batch_vec.to("cpu"), minlength=B)
+            p = torch.zeros(B + 1, dtype=torch.int32)
+            p[1:] = torch.cumsum(cnt, 0)
+            assert int(p[-1]) == n
+            return p
+        lig_ptr, rec_ptr = ptr_of(lig.batch, lig.pos.shape[0]), ptr_of(rec.batch, rec.pos.shape[0])
+        i32 = lambda t: t.to(dev, torch.int32).contiguous()
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+        edge_mask = lig.edge_mask.to(dev, torch.uint8).contiguous()
+        n_tor = int(lig.edge_mask.sum())
+        mask_rotate = None
+        mr_attr = getattr(lig, "mask_rotate", None) if hasattr(lig, "mask_rotate") else None
+        if mr_attr is not None:
+            mr = as_numpy_mask(mr_attr)
+            if mr.size and mr.shape[0] * B == n_tor and mr.shape[1] * B == lig.pos.shape[0]:
+                mask_rotate = torch.from_numpy(np.ascontiguousarray(mr.astype(np.uint8))).to(dev)
+        keep = dict(lig_ptr=lig_ptr, rec_ptr=rec_ptr, lig_x=i32(lig.x[:, :16]), bond_index=i32(bond.edge_index),
+                    bond_attr=f32(bond.edge_attr), edge_mask=edge_mask, rec_x=f32(rec.x), rec_pos=f32(rec.pos),
+                    rec_edge_index=i32(rr.edge_index), mask_rotate=mask_rotate)
+        c = _lib.Complex()
+        c.num_graphs, c.n_lig, c.n_rec = B, lig.pos.shape[0], rec.pos.shape[0]
+        c.n_bond_edges, c.n_rec_edges, c.n_tor = bond.edge_index.shape[1], rr.edge_index.shape[1], n_tor
+        for name in ("lig_ptr", "rec_ptr", "lig_x", "bond_index", "bond_attr", "edge_mask", "rec_x", "rec_pos",
+                     "rec_edge_index", "mask_rotate"):
+            setattr(c, name, keep[name].data_ptr() if keep[name] is not None else None)
+        _lib.check(self.lib, self.lib.ddmi_set_complex(self._h, C.byref(c), self._stream()))
+        self._keep, self._complex_key = keep, key
+        self._B, self._n_tor, self._n_lig = B, n_tor, lig.pos.shape[0]
+
+    # ------------------------------------------------------------------ model(batch)
+    def __call__(self, data):
+        self._ensure_complex(data)
+        dev = self.device
+        pos = data["ligand"].pos.to(dev, torch.float32).contiguous()
+        t = [data.complex_t[k].to(dev, torch.float32).contiguous() for k in ("tr", "rot", "tor")]
+        tr = torch.empty(self._B, 3, device=dev)
+        rot = torch.empty(self._B, 3, device=dev)
+        no_tor = self.cfg.no_torsion or self._n_tor == 0
+        tor = torch.empty(0 if no_tor else self._n_tor, device=dev)
+        _lib.check(self.lib, self.lib.ddmi_forward(self._h, _ptr(pos), _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(tr),
+                                                   _ptr(rot), None if no_tor else _ptr(tor), self._stream()))
+        return tr, rot, tor, None
+
+    forward = __call__
+
+    def modify_conformer_batch(self, pos, data, tr_update, rot_update, torsion_updates, mask_rotate=None):
+        """utils/diffusion_utils.py:60-78 on the device (same argument order; mask_rotate comes from the batch)."""
+        self._ensure_complex(data)
+        dev = self.device
+        out = pos.to(dev, torch.float32).contiguous().clone()
+        f = lambda x: None if x is None else x.to(dev, torch.float32).contiguous()
+        tr_u, rot_u, tor_u = f(tr_update), f(rot_update), f(torsion_updates)
+        _lib.check(self.lib, self.lib.ddmi_modify_conformer(self._h, _ptr(out), _ptr(tr_u), _ptr(rot_u), _ptr(tor_u),
+                                                            self._stream()))
+        return out
+
+    def sample_batch(self, data, inference_steps, schedules, noise=None, seed=0, sample_ids=None, ode=False,
+                     no_random=False, no_final_step_noise=False, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5):
+        """The whole step loop of sampling() (utils/sampling.py:96-191) for one collated batch, on the device."""
+        self._ensure_complex(data)
+        dev = self.device
+        pos = data["ligand"].pos.to(dev, torch.float32).contiguous().clone()
+        sc = _lib.SampleCfg()
+        sched = [np.ascontiguousarray(np.asarray(s, dtype=np.float64)) for s in schedules]
+        sc.inference_steps = inference_steps
+        sc.tr_schedule, sc.rot_schedule, sc.tor_schedule = (s.ctypes.data for s in sched)
+        sc.ode, sc.no_random, sc.no_final_step_noise = int(ode), int(no_random), int(no_final_step_noise)
+        three = lambda v: list(v) if hasattr(v, "__iter__") else [v] * 3
+        for name, v in (("temp_sampling", temp_sampling), ("temp_psi", temp_psi), ("temp_sigma_data", temp_sigma_data)):
+            arr = getattr(sc, name)
+            for i, x in enumerate(three(v)):
+                arr[i] = float(x)
+        sc.seed = int(seed)
+        ids = None
+        if sample_ids is not None:
+            ids = np.ascontiguousarray(np.asarray(sample_ids, dtype=np.int64))
+            sc.sample_ids = ids.ctypes.data
+        zs = [None, None, None]
+        if noise is not None:
+            zs = [None if z is None else z.to(dev, torch.float32).contiguous() for z in noise]
+            sc.z_tr, sc.z_rot, sc.z_tor = (None if z is None else z.data_ptr() for z in zs)
+        _lib.check(self.lib, self.lib.ddmi_sample(self._h, _ptr(pos), C.byref(sc), self._stream()))
+        return pos
+
+    # ------------------------------------------------------------------ introspection
+    def debug_buffer(self, name: str) -> np.ndarray:
+        shape, nd, is_int = (C.c_int64 * 4)(), C.c_int(), C.c_int()
+        _lib.check(self.lib, self.lib.ddmi_debug_shape(self._h, name.encode(), shape, C.byref(nd), C.byref(is_int)))
+        arr = np.empty(tuple(shape[:nd.value]), dtype=np.int32 if is_int.value else np.float32)
+        _lib.check(self.lib, self.lib.ddmi_debug_read(self._h, name.encode(), arr.ctypes.data, arr.nbytes, self._stream()))
+        return arr
+
+
+def get_model(args, device, t_to_sigma=None, no_parallel=True, confidence_mode=False, old=False, lib_path=None):
+    """Same signature as the reference factory (utils/utils.py:172).  `t_to_sigma` is accepted for
+    compatibility; the geometric schedule it implements (utils/diffusion_utils.py:28-32) is evaluated
+    in-library from the sigma bounds in `args`."""
+    if confidence_mode or old:
+        raise NotImplementedError("confidence / legacy models are outside the built path (SURVEY.md 8f)")
+    cfg = args if isinstance(args, ModelConfig) else config_from_args(args)
+    return MIScoreModel(cfg, device=device, lib_path=lib_path)

@@ -1,0 +1,128 @@
+"""CPU run of the UNMODIFIED kernel sources (diffdock_amd/csrc/*.hip) under tests/hipemu against the
+oracle and the reference-executed fixtures: graph construction, CSR layouts, MFMA fragment layouts, the
+node-contracted tensor-product layer, read-outs, pose update and the device-resident step loop.
+(GPU numerics and performance are covered by the `-m gpu` tests.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from diffdock_amd.hetero import HeteroBatch, set_time
+from diffdock_amd.model import MIScoreModel
+from oracle.cg_model import CGModelOracle
+from oracle.conformer import get_t_schedule
+from util import fixture_case, graph_from_dict, load_fixture, rel_err, split_draws, tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "hipemu", "libddmi_emu.so")
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter"]
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    r = subprocess.run(["make", "-j8", "-C", os.path.join(ROOT, "diffdock_amd", "csrc"), "emu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return EMU
+
+
+def make_model(cfg, sd, emu_lib):
+    m = MIScoreModel(cfg, device="cpu", lib_path=emu_lib)
+    m.load_state_dict(sd)
+    m.set_tables(*tables())
+    return m
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference_fixture(name, emu_lib):
+    fx, cfg, data_list = fixture_case(name)
+    m = make_model(cfg, fx["state_dict"], emu_lib)
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    tr, rot, tor, none = m(batch)
+    assert none is None
+    ref = fx["forward"]
+    assert rel_err(tr, ref["tr"]) < 1e-4 and rel_err(rot, ref["rot"]) < 1e-4 and rel_err(tor, ref["tor"]) < 1e-4
+    if cfg.num_prot_emb_layers == 0:   # per-layer node tables (ligand + receptor rows)
+        for l, ref_nodes in enumerate(ref["conv_out"]):
+            mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))
+            n = ref_nodes.shape[0] if l < len(ref["conv_out"]) - 1 else batch["ligand"].pos.shape[0]
+            assert rel_err(mine[:n, :ref_nodes.shape[1]], ref_nodes[:n]) < 1e-4, l
+    # edge counts of the graphs built on the device against the oracle's graph builders
+    so3_t, tor_t = tables()
+    inter = CGModelOracle(cfg, fx["state_dict"], so3_t, tor_t)(batch, return_intermediates=True)[4]
+    assert int(m.debug_buffer("goff_ll")[-1]) == inter["edge_counts"][0]
+    assert int(m.debug_buffer("offs_l")[-1]) == inter["edge_counts"][1] == int(m.debug_buffer("offs_r")[-1])
+
+
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2"])
+def test_device_loop_matches_reference_trajectory(name, emu_lib):
+    fx, cfg, data_list = fixture_case(name)
+    m = make_model(cfg, fx["state_dict"], emu_lib)
+    s = fx["sampling"]
+    B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
+    noise = split_draws(s["draws"], s["steps"], B, R)
+    sched = get_t_schedule(s["steps"])
+    pos = m.sample_batch(HeteroBatch.from_data_list(data_list), s["steps"], (sched, sched, sched), noise=noise,
+                         no_final_step_noise=True, **s["temp"])
+    assert (pos.reshape(B, -1, 3) - s["final_pos"]).abs().max() < 2e-3   # Angstrom, 4 chaotic fp32 steps
+
+
+def test_modify_conformer_matches_reference(emu_lib):
+    fx, cfg, _ = fixture_case("tiny_l1")
+    u = load_fixture("units")
+    m = make_model(cfg, fx["state_dict"], emu_lib)
+    B = u["mc_tr"].shape[0]
+    b = HeteroBatch.from_data_list([graph_from_dict(u["mc_graph"]) for _ in range(B)])
+    out = m.modify_conformer_batch(u["mc_pos_in"], b, u["mc_tr"], u["mc_rot"], u["mc_tor"])
+    assert (out - u["mc_pos_out"]).abs().max() < 5e-5
+    rigid = m.modify_conformer_batch(u["mc_pos_in"], b, u["mc_tr"], u["mc_rot"], None)
+    from oracle.conformer import modify_conformer_batch
+    ref = modify_conformer_batch(u["mc_pos_in"], B, None, None, u["mc_tr"], u["mc_rot"], None)
+    assert (rigid - ref).abs().max() < 5e-5
+
+
+def test_no_cross_edges_and_ragged_batch(emu_lib):
+    """Edge cases the reference handles (with e3nn tensor products): a ligand out of cross-graph range
+    (empty cross groups) and a batch of two DIFFERENT complexes (ragged sizes)."""
+    from diffdock_amd.config import TINY
+    from diffdock_amd.synth import make_complex
+    from diffdock_amd.weights import init_state_dict
+    cfg = TINY.replace(sh_lmax=2)
+    sd = init_state_dict(cfg, seed=5)
+    g1, g2 = make_complex(seed=11, n_res=24, n_lig=9), make_complex(seed=12, n_res=31, n_lig=13)
+    g1["ligand"].pos = g1["ligand"].pos + torch.tensor([[500.0, 0.0, 0.0]])   # far away: no cross edges for graph 0
+    batch = HeteroBatch.from_data_list([g1, g2])
+    set_time(batch, 0.4, 0.4, 0.4, 2)
+    so3_t, tor_t = tables()
+    ref = CGModelOracle(cfg, sd, so3_t, tor_t)(batch)
+    m = make_model(cfg, sd, emu_lib)
+    out = m(batch)
+    for a, b in zip(out[:3], ref[:3]):
+        assert rel_err(a, b) < 1e-4
+    g2["ligand"].pos = g2["ligand"].pos + torch.tensor([[0.0, 700.0, 0.0]])    # now NO cross edges at all
+    batch = HeteroBatch.from_data_list([g1, g2])
+    set_time(batch, 0.4, 0.4, 0.4, 2)
+    ref = CGModelOracle(cfg, sd, so3_t, tor_t)(batch)
+    out = make_model(cfg, sd, emu_lib)(batch)
+    assert int(m.debug_buffer("offs_l")[-1]) >= 0
+    for a, b in zip(out[:3], ref[:3]):
+        assert rel_err(a, b) < 1e-4
+
+
+def test_errors_are_python_exceptions(emu_lib):
+    from diffdock_amd.lib import DdmiError
+    fx, cfg, data_list = fixture_case("tiny_l1")
+    m = MIScoreModel(cfg, device="cpu", lib_path=emu_lib)
+    sd = dict(fx["state_dict"])
+    k = next(iter(sd))
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({kk: v for kk, v in sd.items() if kk != k})           # strict: missing key
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({**sd, "bogus.weight": torch.zeros(1)})              # strict: unexpected key
+    bad = dict(sd)
+    bad[k] = torch.zeros(3, 3)
+    with pytest.raises(DdmiError):
+        m.load_state_dict(bad)                                                  # shape mismatch
+    assert set(m.expected_keys()) == set(sd)
