@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""poses/sec of the reverse-diffusion sampling loop (20 inference steps x 40 samples, DDL-synth score model).
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched through
+torch.distributed.run, one rank per GPU.  A "step" = one complete pass of the hot path over one batch:
+all 20 reverse-diffusion steps of the rank's 40 poses of one synthetic 300-residue / 30-atom complex
+(BASELINE.json configs[2]), i.e. 20 score-model forwards + 20 pose updates, entirely on the device
+(ddmi_sample).  Inputs (graph, weights, tables, initial poses) are resident in HBM before the timed
+region.  Each rank owns 40 independent poses (weak scaling: N GPUs sample 40*N poses); the only
+collective is one RCCL all_gather of the final coordinates per step, as the reference's sampler would
+hand them to the confidence model.
+
+Cross graph: the untrained (random-weight) score model cannot keep the ligand in the pocket, and with the
+reference's dynamic cutoff 3*sigma_tr+20 A the ligand would drift out of range and the cross graph would
+thin out, shrinking the work.  The bench therefore pins the cross graph at its upper bound
+(dynamic_max_cross=False, cutoff = cross_max_distance = 80 A: every ligand-atom x residue pair is an
+edge, as SURVEY.md 8 assumes: 1.02 M edges per interaction layer at 40 poses) and reports the measured
+edge count in `config`.
+
+Extra objects on the JSON line: `roofline` (dominant kernel, HIP-event timed inside the timed region) and
+`cpu_baseline` (the oracle = pure-torch restatement of the reference, timed on this host's cores on a
+bounded sample: 2 poses x 2 steps of the same complex).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from diffdock_amd.config import DDL_SYNTH  # noqa: E402
+from diffdock_amd.hetero import HeteroBatch, set_time  # noqa: E402
+from diffdock_amd.model import MIScoreModel  # noqa: E402
+from diffdock_amd.synth import make_complex, make_pose_list  # noqa: E402
+from diffdock_amd.tables import default_tables  # noqa: E402
+from diffdock_amd.weights import init_state_dict  # noqa: E402
+
+INFERENCE_STEPS, SAMPLES, N_RES, N_LIG = 20, 40, 300, 30
+HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS = 8000.0, 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
+TEMP = dict(temp_sampling=[1.170050527854316, 2.06391612594481, 7.044261621607846],       # default_inference_args.yaml
+            temp_psi=[0.727287304570729, 0.9022615585677628, 0.5946212391366862],
+            temp_sigma_data=[0.9299802531572672, 0.7464326999906034, 0.6943254174849822])
+
+
+def bench_cfg():
+    return DDL_SYNTH.replace(dynamic_max_cross=False, cross_max_distance=80.0)
+
+
+def t_schedule(steps):
+    return np.linspace(1, 0, steps + 1)[:-1]      # get_t_schedule('expbeta', alpha=beta=1), diffusion_utils.py:138-142
+
+
+def cpu_baseline(cfg, sd, so3_t, tor_t, g):
+    """Oracle (restated reference, pure torch fp32, all host cores) on a bounded sample of the same workload."""
+    from oracle.cg_model import CGModelOracle
+    from oracle.sampling import sampling as oracle_sampling
+    torch.set_num_threads(os.cpu_count())
+    n_s, n_steps = 2, 2
+    dl = make_pose_list(g, n_s, tr_sigma_max=cfg.tr_sigma_max, seed=77, initial_noise_std_proportion=0.3)
+    model = CGModelOracle(cfg, sd, so3_t, tor_t)
+    R = int(dl[0]["ligand"].edge_mask.sum())
+    gen = torch.Generator().manual_seed(0)
+    noise = (torch.randn(INFERENCE_STEPS, n_s, 3, generator=gen), torch.randn(INFERENCE_STEPS, n_s, 3, generator=gen),
+             torch.randn(INFERENCE_STEPS, n_s * R, generator=gen))
+    s = t_schedule(INFERENCE_STEPS)
+    t0 = time.time()
+    # first n_steps of the 20-step schedule (largest cross cutoffs = the same all-pairs graph as the GPU run)
+    oracle_sampling(dl, model, n_steps, cfg, noise, schedules=(s, s, s), batch_size=n_s, **TEMP)
+    dt = time.time() - t0
+    poses_per_s = n_s / (dt / n_steps * INFERENCE_STEPS)
+    return {"value": poses_per_s, "unit": "poses/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_s} poses x {n_steps} of {INFERENCE_STEPS} steps, same complex and weights, "
+                      f"extrapolated linearly; torch {torch.__version__}, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=SAMPLES, help="poses per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    cfg = bench_cfg()
+    sd = init_state_dict(cfg, seed=1234)
+    so3_t, tor_t = default_tables()
+    model = MIScoreModel(cfg, device=str(dev))
+    model.load_state_dict(sd)
+    model.set_tables(so3_t, tor_t)
+    g = make_complex(seed=0, n_res=N_RES, n_lig=N_LIG)
+    B = args.samples
+    dl = make_pose_list(g, B, tr_sigma_max=cfg.tr_sigma_max, seed=1000 + rank, initial_noise_std_proportion=0.3)
+    batch = HeteroBatch.from_data_list(dl).to(dev)
+    sched = t_schedule(INFERENCE_STEPS)
+    ids = list(range(rank * B, (rank + 1) * B))
+    gathered = [torch.empty(B * N_LIG, 3, device=dev) for _ in range(world)] if world > 1 else None
+
+    def one_step(seed):
+        pos = model.sample_batch(batch, INFERENCE_STEPS, (sched, sched, sched), seed=seed, sample_ids=ids,
+                                 no_final_step_noise=True, **TEMP)
+        if world > 1:
+            dist.all_gather(gathered, pos)
+        return pos
+
+    for w in range(args.warmup):
+        one_step(w)
+    model.set_kernel_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        pos = one_step(100 + k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    timings = model.kernel_timings()
+    model.set_kernel_timing(False)
+    assert torch.isfinite(pos).all()
+
+    if rank == 0:
+        # edges actually processed by the last forward of the run
+        e_ll = int(model.debug_buffer("goff_ll")[-1])
+        e_lr = int(model.debug_buffer("offs_l")[-1])
+        e_rr = int(model.debug_buffer("rr_goff")[-1])
+        L = cfg.num_conv_layers
+        edges_per_layer = e_ll + 2 * e_lr + e_rr
+        # ---- roofline of the dominant kernel (by HIP-event time inside the timed region)
+        kern = {k: v for k, v in timings.items() if k.startswith("k_") or k == "conv_fc1_gemms"}
+        dom = max(kern, key=lambda k: kern[k][0]) if kern else None
+        roof = None
+        if dom:
+            ms, n = kern[dom]
+            avg_s = ms / max(n, 1) * 1e-3
+            ns, HK, NT, NTs, HKp = cfg.ns, 3 * cfg.ns + 1, 524, 576, 148
+            n_groups = 4 * (L - 1) + 2
+            nodes_gather = (2 * (B * N_LIG) + 2 * (B * N_RES)) * (L - 1) + (B * N_LIG + B * N_RES)   # sum over launches
+            edges_total = edges_per_layer * (L - 1) + (e_ll + e_lr)
+            if dom == "k_edge_conv":     # T = h * Y_d : 2*HK*NT flop / edge ; bytes: Y_d read once per gather node + HE + msg
+                flops = 2.0 * HK * NT * edges_total / n_groups
+                bytes_ = (nodes_gather * HK * NT * 4 + edges_total * (3 * ns * 4 + 156 * 4 + 40)) / n_groups
+            elif dom == "k_node_contract":   # writes Y: HK*NT floats per gather node; reads x rows + packed W2 (L2-resident)
+                flops = 2.0 * HK * 9648 * nodes_gather / n_groups
+                bytes_ = nodes_gather * (HK * NT * 4 + 156 * 4) / n_groups
+            else:
+                flops, bytes_ = 0.0, 0.0
+            ai = flops / max(bytes_, 1.0)
+            ridge = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+            if ai > ridge:
+                ach = flops / avg_s / 1e12
+                roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+            else:
+                ach = bytes_ / avg_s / 1e9
+                roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            roof.update({"avg_launch_ms": avg_s * 1e3, "launches": n, "alg_flops_per_launch": flops,
+                         "alg_bytes_per_launch": bytes_})
+        cpu = None if args.no_cpu_baseline else cpu_baseline(cfg, sd, so3_t, tor_t, g)
+        out = {
+            "metric": "poses/sec (20 steps x 40 samples, DiffDock-L score model)", "value": world * B * args.steps / dt,
+            "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: DDL-synth score model (ns=48 nv=10 6 layers sh_lmax=1), "
+                                   f"{INFERENCE_STEPS} steps x {B} poses/GPU, synthetic {N_RES}-residue receptor / "
+                                   f"{N_LIG}-atom ligand, cross graph pinned at its upper bound (static 80 A cutoff), "
+                                   f"low-temperature SDE, random-init weights",
+                       "poses_per_gpu": B, "inference_steps": INFERENCE_STEPS, "edges_per_layer": edges_per_layer,
+                       "edges": {"lig_lig": e_ll, "cross_each_direction": e_lr, "rec_rec": e_rr},
+                       "parallelism": f"pose-sharded x{world}, 1 all_gather/step" if world > 1 else "single GPU"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "phase_ms_per_forward": {k: v[0] / max(args.steps * INFERENCE_STEPS, 1) for k, v in timings.items()},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,9 +154,17 @@ int ddmi_wigner_3j(int l1, int l2, int l3, double* out) {
   });
 }
 
-int ddmi_set_kernel_timing(ddmi_model* h, int enabled) { if (!h) return DDMI_ERR_ARG; h->m.timing = enabled != 0; return DDMI_OK; }
+int ddmi_set_kernel_timing(ddmi_model* h, int enabled) {
+  if (!h) return DDMI_ERR_ARG;
+  resolve_timings(h->m);
+  h->m.timing = enabled != 0;
+  if (enabled) h->m.phases.clear();
+  return DDMI_OK;
+}
 int ddmi_kernel_timings(ddmi_model* h, int i, const char** name, double* ms, int64_t* launches) {
-  if (!h || i < 0 || i >= (int)h->m.phases.size()) return DDMI_ERR_ARG;
+  if (!h) return DDMI_ERR_ARG;
+  resolve_timings(h->m);
+  if (i < 0 || i >= (int)h->m.phases.size()) return DDMI_ERR_ARG;
   *name = h->m.phases[i].name.c_str(); *ms = h->m.phases[i].ms; *launches = h->m.phases[i].launches;
   return DDMI_OK;
 }

@@ -40,6 +40,34 @@ struct Model::Cx {
   float *s_tr, *s_rot, *s_tor, *s_t = nullptr; long long* s_ids = nullptr; size_t s_t_cap = 0;
 };
 
+static hipEvent_t get_event(Model& m) {
+  if (!m.free_events.empty()) { hipEvent_t e = m.free_events.back(); m.free_events.pop_back(); return e; }
+  hipEvent_t e;
+  DDMI_CHECK_HIP(hipEventCreate(&e));
+  return e;
+}
+PhaseTimer::PhaseTimer(Model& model, const char* name, hipStream_t stream) : m(model), s(stream) {
+  if (!m.timing) return;
+  for (size_t i = 0; i < m.phases.size(); ++i) if (m.phases[i].name == name) idx = (int)i;
+  if (idx < 0) { m.phases.push_back({name, 0.0, 0}); idx = (int)m.phases.size() - 1; }
+  a = get_event(m); b = get_event(m);
+  (void)hipEventRecord(a, s);
+}
+PhaseTimer::~PhaseTimer() {
+  if (idx < 0) return;
+  (void)hipEventRecord(b, s);
+  m.pending.push_back({idx, a, b});
+}
+void resolve_timings(Model& m) {
+  for (auto& p : m.pending) {
+    (void)hipEventSynchronize(p.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { m.phases[p.phase].ms += ms; m.phases[p.phase].launches++; }
+    m.free_events.push_back(p.a); m.free_events.push_back(p.b);
+  }
+  m.pending.clear();
+}
+
 namespace {
 
 typedef Model::Cx Cx;
@@ -86,21 +114,31 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const int wg = std::min<int>((int)gi, L.G - 1);
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
-    if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]
-      gemm(g.sig, ns, W1, L.n_edge, nullptr, c.rr_rowbias, H, c.B, H, ns, 0, s);
-      rb = c.rr_rowbias;
+    {
+      PhaseTimer t(m, "conv_fc1_gemms", s);
+      if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]
+        gemm(g.sig, ns, W1, L.n_edge, nullptr, c.rr_rowbias, H, c.B, H, ns, 0, s);
+        rb = c.rr_rowbias;
+      }
+      gemm(g.ea, ns, W1, L.n_edge, nullptr, c.HE, H, g.ea_rows, H, ns, 0, s, g.ea_rows_dev, rb, g.sig_idx, H);
+      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, c.P, H, g.tcount, H, ns, 0, s);
+      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], c.Q, H, g.gcount, H, ns, 0, s);
     }
-    gemm(g.ea, ns, W1, L.n_edge, nullptr, c.HE, H, g.ea_rows, H, ns, 0, s, g.ea_rows_dev, rb, g.sig_idx, H);
-    gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, c.P, H, g.tcount, H, ns, 0, s);
-    gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], c.Q, H, g.gcount, H, ns, 0, s);
-    launch_node_contract(Xin, g.gbase, g.gcount, L.wpack[wg], L.pcs, L.n_pc, L.max_mul_out, L.HK, L.HKp, L.NTs, c.Y, s);
+    {
+      PhaseTimer t(m, "k_node_contract", s);
+      launch_node_contract(Xin, g.gbase, g.gcount, L.wpack[wg], L.pcs, L.n_pc, L.max_mul_out, L.HK, L.HKp, L.NTs, c.Y, s);
+    }
     EdgeConvArgs a{};
     a.gcount = g.gcount; a.goff = g.goff; a.tgt = g.tgt; a.tslot = g.tslot; a.arow = g.arow; a.tbase = g.tbase;
     a.HE = c.HE; a.P = c.P; a.Q = c.Q; a.Y = c.Y; a.nvec = g.nvec; a.ew = g.ew; a.sgn = g.sgn;
     a.H = H; a.HKp = L.HKp; a.NT = L.NT; a.NTs = L.NTs; a.sh_lmax = m.cfg.sh_lmax;
     a.paths = L.paths; a.ctab = L.ctab; a.items = L.items; a.n_items = L.n_items; a.msg = g.msg;
-    launch_edge_conv(a, s);
+    {
+      PhaseTimer t(m, "k_edge_conv", s);
+      launch_edge_conv(a, s);
+    }
   }
+  PhaseTimer t(m, "k_reduce_bn", s);
   launch_reduce_bn(rg_dev, n_rg, nbase, ncount, L.D_in, L.D_out, L.has_bn ? L.bn_mean : nullptr,
                    L.has_bn ? L.bn_scale : nullptr, L.has_bn ? L.bn_bias : nullptr, L.residual ? 1 : 0, Xin, Xout, XS, s);
 }
@@ -353,6 +391,8 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   Cx& c = *m.cx;
   const ddmi_config& cfg = m.cfg;
   const int ns = m.ns, sd = m.sd, B = c.B, nL = c.nL, nR = c.nR;
+  PhaseTimer t_fwd(m, "forward_total", s);
+  std::unique_ptr<PhaseTimer> t_phase(new PhaseTimer(m, "embed_and_graphs", s));
   // ---- per-graph time terms
   launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, c.temb, s);
   gemm(c.temb, sd, m.rec_sigma.W0, sd, m.rec_sigma.b0, c.hidB, ns, B, ns, sd, 1, s);
@@ -411,11 +451,13 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   const RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                       nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
   const int Lc = (int)m.conv_layers.size();
+  t_phase.reset();
   for (int l = 0; l < Lc; ++l, ++xi) {
     if (l < Lc - 1) run_conv(m, m.conv_layers[l], {g_ll, g_lr, g_rr, g_rl}, c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s);
     else run_conv(m, m.conv_layers[l], {g_ll, g_lr}, c.rg_lig, 2, c.X[xi], c.X[xi + 1], 0, nL, s);
   }
   const float* XL = c.X[xi];
+  PhaseTimer t_read(m, "readouts", s);
   // ---- translation / rotation heads (cg_model.py:368-395)
   const ConvW& F = m.final_conv;
   launch_center_edges(lig_pos, c.lig_batch, c.lig_ptr, B, nL, c.c_dist, c.c_nvec, s);

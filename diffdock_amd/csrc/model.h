@@ -85,7 +85,18 @@ struct Model {
   bool timing = false;
   struct TimedPhase { std::string name; double ms = 0; int64_t launches = 0; };
   std::vector<TimedPhase> phases;
+  struct EventPair { int phase; hipEvent_t a, b; };
+  std::vector<EventPair> pending;     // recorded on the launch stream, resolved by resolve_timings()
+  std::vector<hipEvent_t> free_events;
 };
+
+// RAII bracket: HIP events on the stream the kernels are launched on (only when timing is enabled)
+struct PhaseTimer {
+  Model& m; hipStream_t s; int idx = -1; hipEvent_t a{}, b{};
+  PhaseTimer(Model& model, const char* name, hipStream_t stream);
+  ~PhaseTimer();
+};
+void resolve_timings(Model& m);
 
 // weights.cpp
 void build_weight_spec(Model& m);

@@ -212,6 +212,20 @@ class MIScoreModel:
         return pos
 
     # ------------------------------------------------------------------ introspection
+    def set_kernel_timing(self, enabled: bool):
+        _lib.check(self.lib, self.lib.ddmi_set_kernel_timing(self._h, int(enabled)))
+
+    def kernel_timings(self):
+        """{phase: (total_ms, launches)} measured with HIP events on the launch stream."""
+        out, i = {}, 0
+        while True:
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            if self.lib.ddmi_kernel_timings(self._h, i, C.byref(name), C.byref(ms), C.byref(n)) != 0:
+                break
+            out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out
+
     def debug_buffer(self, name: str) -> np.ndarray:
         shape, nd, is_int = (C.c_int64 * 4)(), C.c_int(), C.c_int()
         _lib.check(self.lib, self.lib.ddmi_debug_shape(self._h, name.encode(), shape, C.byref(nd), C.byref(is_int)))

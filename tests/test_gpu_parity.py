@@ -1,0 +1,150 @@
+"""Parity of the gfx950 build on a real MI355X, through the C ABI (libddmi.so via diffdock_amd.model).
+
+Tolerance: BASELINE.json north_star = 1e-4 relative fp32 on the score outputs (tr / rot / tor); the
+kernels run exact-fp32 MFMA, differences come from re-association only.  Full-size cases use
+size-independent properties: SE(3) equivariance of the scores, batch/shard invariance, determinism."""
+import numpy as np
+import pytest
+import torch
+
+from diffdock_amd.config import DDL_SYNTH
+from diffdock_amd.hetero import HeteroBatch, set_time
+from diffdock_amd.model import MIScoreModel
+from diffdock_amd.synth import make_complex, make_pose_list
+from diffdock_amd.weights import init_state_dict
+from oracle.cg_model import CGModelOracle
+from oracle.conformer import get_t_schedule
+from util import fixture_case, graph_from_dict, load_fixture, rel_err, split_draws, tables
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter"]
+
+
+def gpu_model(cfg, sd):
+    assert torch.cuda.is_available(), "these tests need the MI355X (run through gpurun with -m gpu)"
+    m = MIScoreModel(cfg, device="cuda:0")     # raises DdmiError if libddmi.so is not built: no fallback
+    m.load_state_dict(sd)
+    m.set_tables(*tables())
+    return m
+
+
+def to_gpu(batch):
+    return batch.to("cuda:0")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference_fixture(name):
+    fx, cfg, data_list = fixture_case(name)
+    m = gpu_model(cfg, fx["state_dict"])
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    tr, rot, tor, none = m(to_gpu(batch))
+    ref = fx["forward"]
+    assert none is None and tr.is_cuda
+    assert rel_err(tr.cpu(), ref["tr"]) < REL and rel_err(rot.cpu(), ref["rot"]) < REL and rel_err(tor.cpu(), ref["tor"]) < REL
+    if cfg.num_prot_emb_layers == 0:
+        for l, ref_nodes in enumerate(ref["conv_out"]):
+            mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))
+            n = ref_nodes.shape[0] if l < len(ref["conv_out"]) - 1 else batch["ligand"].pos.shape[0]
+            assert rel_err(mine[:n, :ref_nodes.shape[1]], ref_nodes[:n]) < REL, l
+
+
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2"])
+def test_device_loop_matches_reference_trajectory(name):
+    fx, cfg, data_list = fixture_case(name)
+    m = gpu_model(cfg, fx["state_dict"])
+    s = fx["sampling"]
+    B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
+    noise = split_draws(s["draws"], s["steps"], B, R)
+    sched = get_t_schedule(s["steps"])
+    pos = m.sample_batch(to_gpu(HeteroBatch.from_data_list(data_list)), s["steps"], (sched, sched, sched), noise=noise,
+                         no_final_step_noise=True, **s["temp"])
+    assert (pos.cpu().reshape(B, -1, 3) - s["final_pos"]).abs().max() < 2e-3   # Angstrom after 4 chaotic fp32 steps
+
+
+def test_modify_conformer_matches_reference():
+    fx, cfg, _ = fixture_case("tiny_l1")
+    u = load_fixture("units")
+    m = gpu_model(cfg, fx["state_dict"])
+    B = u["mc_tr"].shape[0]
+    b = to_gpu(HeteroBatch.from_data_list([graph_from_dict(u["mc_graph"]) for _ in range(B)]))
+    out = m.modify_conformer_batch(u["mc_pos_in"], b, u["mc_tr"], u["mc_rot"], u["mc_tor"])
+    assert (out.cpu() - u["mc_pos_out"]).abs().max() < 5e-5
+
+
+def synth_batch(cfg, n_res, n_lig, B, seed, t):
+    g = make_complex(seed=seed, n_res=n_res, n_lig=n_lig)
+    dl = make_pose_list(g, B, tr_sigma_max=cfg.tr_sigma_max, seed=seed + 1, initial_noise_std_proportion=0.6)
+    batch = HeteroBatch.from_data_list(dl)
+    set_time(batch, t, t, t, B)
+    return batch
+
+
+@pytest.mark.parametrize("lmax,t", [(1, 0.8), (2, 0.15)])
+def test_ddl_synth_forward_matches_oracle(lmax, t):
+    """The declared benchmark architecture (ns=48, nv=10, 6 layers, 64-d embeddings) on a 300-residue /
+    30-atom complex, 2 poses (the oracle materialises [E, 6928] weights, so it stays small)."""
+    cfg = DDL_SYNTH.replace(sh_lmax=lmax)
+    sd = init_state_dict(cfg, seed=1234)
+    batch = synth_batch(cfg, 300, 30, 2, seed=3, t=t)
+    so3_t, tor_t = tables()
+    tr, rot, tor, _ = CGModelOracle(cfg, sd, so3_t, tor_t)(batch)
+    m = gpu_model(cfg, sd)
+    tr2, rot2, tor2, _ = m(to_gpu(batch))
+    assert rel_err(tr2.cpu(), tr) < REL and rel_err(rot2.cpu(), rot) < REL and rel_err(tor2.cpu(), tor) < REL
+
+
+def test_full_size_properties():
+    """BASELINE configs[2] shape (40 poses x 300 residues x 30 atoms): equivariance, shard invariance,
+    run-to-run determinism of the device path."""
+    cfg = DDL_SYNTH
+    sd = init_state_dict(cfg, seed=1234)
+    m = gpu_model(cfg, sd)
+    B = 40
+    batch = synth_batch(cfg, 300, 30, B, seed=4, t=0.5)
+    tr, rot, tor, _ = m(to_gpu(batch))
+    tr_b, rot_b, tor_b, _ = m(to_gpu(batch))
+    assert torch.equal(tr, tr_b) and torch.equal(rot, rot_b) and torch.equal(tor, tor_b)      # deterministic
+    assert torch.isfinite(tr).all() and torch.isfinite(rot).all() and torch.isfinite(tor).all()
+    # global rotation + translation of the whole complex: tr is a vector (1o+1e summed -> rotates), rot likewise
+    q = torch.tensor([0.3, -0.5, 0.7, 0.4], dtype=torch.float64)
+    q = q / q.norm()
+    w, x, y, z = q
+    Rm = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]).float()
+    shift = torch.tensor([[3.0, -2.0, 5.0]])
+    rb = synth_batch(cfg, 300, 30, B, seed=4, t=0.5)
+    rb["ligand"].pos = rb["ligand"].pos @ Rm.T + shift
+    rb["receptor"].pos = rb["receptor"].pos @ Rm.T + shift
+    tr_r, rot_r, tor_r, _ = m(to_gpu(rb))
+    assert rel_err(tr_r.cpu(), tr.cpu() @ Rm.T) < 2e-3 and rel_err(rot_r.cpu(), rot.cpu() @ Rm.T) < 2e-3
+    assert rel_err(tor_r.cpu(), tor.cpu()) < 2e-3
+    # shard invariance: poses 0..19 / 20..39 evaluated alone equal their rows in the batch of 40
+    g = make_complex(seed=4, n_res=300, n_lig=30)
+    dl = make_pose_list(g, B, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.6)
+    R = tor.numel() // B
+    for lo in (0, 20):
+        sb = HeteroBatch.from_data_list(dl[lo:lo + 20])
+        set_time(sb, 0.5, 0.5, 0.5, 20)
+        tr_s, rot_s, tor_s, _ = m(to_gpu(sb))
+        assert rel_err(tr_s.cpu(), tr[lo:lo + 20].cpu()) < 1e-5
+        assert rel_err(tor_s.cpu(), tor[lo * R:(lo + 20) * R].cpu()) < 1e-5
+
+
+def test_sharded_sampling_is_sample_invariant():
+    """Counter-based noise keyed by sample id: sampling 8 poses at once == sampling them as 2 shards."""
+    cfg = DDL_SYNTH.replace(num_conv_layers=3, tr_sigma_max=5.0)
+    sd = init_state_dict(cfg, seed=7)
+    m = gpu_model(cfg, sd)
+    g = make_complex(seed=9, n_res=120, n_lig=20)
+    dl = make_pose_list(g, 8, tr_sigma_max=cfg.tr_sigma_max, seed=10, initial_noise_std_proportion=0.5)
+    sched = get_t_schedule(5)
+    full = m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl)), 5, (sched, sched, sched), seed=123,
+                          sample_ids=list(range(8)), no_final_step_noise=True).cpu().reshape(8, -1, 3)
+    parts = []
+    for lo in (0, 4):
+        parts.append(m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl[lo:lo + 4])), 5, (sched, sched, sched), seed=123,
+                                    sample_ids=list(range(lo, lo + 4)), no_final_step_noise=True).cpu().reshape(4, -1, 3))
+    assert (torch.cat(parts) - full).abs().max() < 1e-3

@@ -1,0 +1,58 @@
+"""Host logic: score-norm tables against the reference-generated fixtures, C-ABI symbol surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from diffdock_amd import lib as L
+from diffdock_amd import tables as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_so3_table_matches_reference_module():
+    mine, ref = T.so3_exp_score_norms(), np.load(os.path.join(GOLD, "so3_exp_score_norms.npy"))
+    # eps >= 0.0074 (index 600): the whole range a model can reach (rot_sigma_min is 0.03 .. 0.1); below it the
+    # reference's L=2000 truncated series is not converged (it even yields NaN there) and nothing is pinned
+    assert not np.isnan(mine[600:]).any()
+    assert np.max(np.abs(mine[600:] - ref[600:]) / np.abs(ref[600:])) < 1e-6
+
+
+def test_shipped_tables_equal_reference_fixtures():
+    so3, tor = T.default_tables(cache=False)
+    ref_so3, ref_tor = np.load(os.path.join(GOLD, "so3_exp_score_norms.npy")), np.load(os.path.join(GOLD, "torus_score_norm.npy"))
+    assert np.array_equal(tor, ref_tor)          # seeded Monte-Carlo, same call sequence as utils/torus.py
+    assert np.max(np.abs(so3[600:] - ref_so3[600:]) / np.abs(ref_so3[600:])) < 1e-6
+
+
+@pytest.fixture(scope="module")
+def gpu_lib_path():
+    if not os.path.exists(L.DEFAULT_LIB):
+        L.build()
+    return L.DEFAULT_LIB
+
+
+def test_library_exports_every_declared_symbol(gpu_lib_path):
+    """include/ddmi.h vs the gfx950 shared library (no compute calls: there is no GPU here)."""
+    header = open(os.path.join(ROOT, "include", "ddmi.h")).read()
+    declared = set(re.findall(r"\b(ddmi_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ddmi_stream"}
+    assert declared == set(L.EXPORTED_SYMBOLS), declared ^ set(L.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(gpu_lib_path)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(L.DdmiError):
+        L.load(str(tmp_path / "libddmi.so"))
+
+
+def test_wigner_3j_host_entry_point_matches_oracle(gpu_lib_path):
+    from oracle.e3nn_lite import wigner_3j
+    lib = L.load(gpu_lib_path)
+    for ls in [(1, 1, 0), (1, 1, 1), (1, 1, 2), (1, 2, 1), (2, 2, 2), (1, 2, 3), (2, 2, 4)]:
+        assert np.allclose(L.wigner_3j(lib, *ls), wigner_3j(*ls).numpy(), atol=1e-12)
