@@ -1,0 +1,49 @@
+"""Pose-sharded sampling over the GPUs of one node.
+
+The N poses of a complex are independent trajectories over shared read-only inputs, so the path shards
+without any per-step traffic: rank r takes poses r::world (contiguous blocks here), every rank holds a copy of
+the weights and of the complex, and ONE all_gather of the final coordinates (RCCL over xGMI when the backend is
+"nccl"; ~1.8 KB per rank at 5 x 30 atoms -- latency only) hands the poses back.  The reference has no
+distributed inference path at all (`no_parallel=True`, inference.py:201).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous block partition of n poses; the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_poses(local_pos: torch.Tensor, n_total: int, n_atoms: int) -> torch.Tensor:
+    """all_gather of [n_local, n_atoms, 3] blocks (padded to the largest block) -> [n_total, n_atoms, 3] on every rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cap = max(shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world))
+    buf = torch.zeros(cap, n_atoms, 3, device=local_pos.device, dtype=local_pos.dtype)
+    buf[:local_pos.shape[0]] = local_pos
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        parts.append(out[r][:hi - lo])
+    return torch.cat(parts, 0)
+
+
+def sample_sharded(data_list, model, inference_steps, schedules, sampler, **kw):
+    """Run `sampler` (diffdock_amd.sampling.sampling or any function with its signature) on this rank's block of
+    `data_list` and return the final coordinates of ALL poses [N, n_atoms, 3] on every rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    N = len(data_list)
+    lo, hi = shard_bounds(N, rank, world)
+    mine = data_list[lo:hi]
+    if mine:
+        sampler(mine, model, inference_steps, schedules[0], schedules[1], schedules[2], sample_id_offset=lo, **kw)
+    n_atoms = data_list[0]["ligand"].pos.shape[0]
+    dev = mine[0]["ligand"].pos.device if mine else torch.device("cpu")
+    local = torch.stack([d["ligand"].pos for d in mine]) if mine else torch.zeros(0, n_atoms, 3, device=dev)
+    return gather_poses(local, N, n_atoms)

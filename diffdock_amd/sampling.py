@@ -1,0 +1,106 @@
+"""`sampling()` with the reference's signature (utils/sampling.py:69-72), running the step loop on the device.
+
+    data_list, confidence = sampling(data_list, model, inference_steps, tr_schedule, rot_schedule,
+                                     tor_schedule, device, t_to_sigma, model_args, ...)
+
+Differences, all documented: the Gaussian draws come from a counter-based generator keyed by
+(seed, global sample index, step, component) instead of the global torch RNG (so that a run sharded over GPUs
+reproduces the single-GPU trajectories), or are injected through `noise=`; the confidence model
+(sampling.py:208-227), visualisation hooks and per-step `crop_beyond` (sampling.py:104-109) are not on the built
+path yet and raise NotImplementedError when requested.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .hetero import HeteroBatch, set_time
+
+
+def _batches(data_list, batch_size):
+    for lo in range(0, len(data_list), batch_size):
+        yield lo, data_list[lo:lo + batch_size]
+
+
+def _collate(chunk):
+    try:  # real PyG objects collate themselves
+        from torch_geometric.data import Batch  # type: ignore
+        return Batch.from_data_list(chunk)
+    except Exception:
+        return HeteroBatch.from_data_list(chunk)
+
+
+def step_coefficients(model_args, t_idx, inference_steps, schedules, ode=False, no_random=False, no_final_step_noise=False,
+                      temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5):
+    """Host float64 scalars of one step (utils/sampling.py:97-186): per component (score coefficient, noise
+    coefficient).  Mirrors the in-library computation of ddmi_sample; used by the step-wise python loop."""
+    three = lambda v: list(v) if hasattr(v, "__iter__") else [v] * 3
+    T, psi, sdat = three(temp_sampling), three(temp_psi), three(temp_sigma_data)
+    out = []
+    last = t_idx == inference_steps - 1
+    for i, (name, sched) in enumerate(zip(("tr", "rot", "tor"), schedules)):
+        t = float(sched[t_idx])
+        dt = t if last else t - float(sched[t_idx + 1])
+        smin, smax = getattr(model_args, f"{name}_sigma_min"), getattr(model_args, f"{name}_sigma_max")
+        sigma = smin ** (1 - t) * smax ** t
+        g = sigma * np.sqrt(2 * np.log(smax / smin))
+        a, z = (0.5 * g * g * dt if ode else g * g * dt), g * np.sqrt(dt)
+        if T[i] != 1.0:
+            sigma_data = np.exp(sdat[i] * np.log(smax) + (1 - sdat[i]) * np.log(smin))
+            lam = (sigma_data + sigma) / (sigma_data + sigma / T[i])
+            a, z = g * g * dt * (lam + T[i] * psi[i] / 2), g * np.sqrt(dt * (1 + psi[i]))
+        if no_random or ode or (no_final_step_noise and last):
+            z = 0.0
+        out.append((float(a), float(z)))
+    return out
+
+
+def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device=None, t_to_sigma=None,
+             model_args=None, no_random=False, ode=False, visualization_list=None, confidence_model=None,
+             confidence_data_list=None, confidence_model_args=None, t_schedule=None, batch_size=32,
+             no_final_step_noise=False, pivot=None, return_full_trajectory=False, temp_sampling=1.0, temp_psi=0.0,
+             temp_sigma_data=0.5, return_features=False, seed=0, noise=None, sample_id_offset=0, native_loop=True):
+    if confidence_model is not None or visualization_list is not None or return_full_trajectory or return_features or pivot:
+        raise NotImplementedError("confidence model / visualisation / trajectories are outside the built path (SURVEY.md 8f)")
+    if model_args is not None and getattr(model_args, "crop_beyond", None) is not None:
+        raise NotImplementedError("per-step crop_beyond is a 'next' row (SURVEY.md 8f.1); use crop_beyond=None")
+    N = len(data_list)
+    schedules = (np.asarray(tr_schedule, dtype=np.float64), np.asarray(rot_schedule, dtype=np.float64),
+                 np.asarray(tor_schedule, dtype=np.float64))
+    cfg = model.cfg if model_args is None else model_args
+    with torch.no_grad():
+        for lo, chunk in _batches(data_list, batch_size):
+            batch = _collate(chunk)
+            b = batch.num_graphs
+            n = batch["ligand"].pos.shape[0] // b
+            if device is not None:
+                batch = batch.to(device)
+            ids = list(range(sample_id_offset + lo, sample_id_offset + lo + b))
+            R = int(batch["ligand"].edge_mask.sum()) // b
+            z = None
+            if noise is not None:
+                z = (noise[0][:, lo:lo + b], noise[1][:, lo:lo + b], noise[2][:, lo * R:(lo + b) * R])
+            if native_loop and hasattr(model, "sample_batch"):
+                pos = model.sample_batch(batch, inference_steps, schedules, noise=z, seed=seed, sample_ids=ids, ode=ode,
+                                         no_random=no_random, no_final_step_noise=no_final_step_noise,
+                                         temp_sampling=temp_sampling, temp_psi=temp_psi, temp_sigma_data=temp_sigma_data)
+            else:   # step-wise: model(batch) per step, exactly the reference's loop structure
+                assert z is not None or no_random, "the step-wise loop needs injected noise (or no_random)"
+                pos = batch["ligand"].pos
+                for t_idx in range(inference_steps):
+                    set_time(batch, schedules[0][t_idx], schedules[1][t_idx], schedules[2][t_idx], b, device=pos.device)
+                    batch["ligand"].pos = pos
+                    tr, rot, tor = model(batch)[:3]
+                    (a_tr, z_tr), (a_rot, z_rot), (a_tor, z_tor) = step_coefficients(
+                        cfg, t_idx, inference_steps, schedules, ode, no_random, no_final_step_noise, temp_sampling,
+                        temp_psi, temp_sigma_data)
+                    zz = [torch.zeros_like(tr), torch.zeros_like(rot), torch.zeros_like(tor)] if z is None else \
+                        [z[0][t_idx].to(tr.device), z[1][t_idx].to(tr.device), z[2][t_idx].to(tr.device)]
+                    trp = np.float32(a_tr) * tr + np.float32(z_tr) * zz[0]
+                    rotp = np.float32(a_rot) * rot + np.float32(z_rot) * zz[1]
+                    torp = (np.float32(a_tor) * tor + np.float32(z_tor) * zz[2]) if tor.numel() else None
+                    pos = model.modify_conformer_batch(pos, batch, trp, rotp, torp)
+            pos = pos.reshape(b, n, 3)
+            for i in range(b):
+                data_list[lo + i]["ligand"].pos = pos[i]
+    return data_list, None

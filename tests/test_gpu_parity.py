@@ -98,7 +98,9 @@ def test_ddl_synth_forward_matches_oracle(lmax, t):
 def test_full_size_properties():
     """BASELINE configs[2] shape (40 poses x 300 residues x 30 atoms): equivariance, shard invariance,
     run-to-run determinism of the device path."""
-    cfg = DDL_SYNTH
+    # fixed_center_conv=True: with the reference's default a pose's score depends on its index in the batch
+    # (cg_model.py:371-374 indexes the ligand table by graph id), which would make shard invariance meaningless
+    cfg = DDL_SYNTH.replace(fixed_center_conv=True)
     sd = init_state_dict(cfg, seed=1234)
     m = gpu_model(cfg, sd)
     B = 40
@@ -135,7 +137,7 @@ def test_full_size_properties():
 
 def test_sharded_sampling_is_sample_invariant():
     """Counter-based noise keyed by sample id: sampling 8 poses at once == sampling them as 2 shards."""
-    cfg = DDL_SYNTH.replace(num_conv_layers=3, tr_sigma_max=5.0)
+    cfg = DDL_SYNTH.replace(num_conv_layers=3, tr_sigma_max=5.0, fixed_center_conv=True)
     sd = init_state_dict(cfg, seed=7)
     m = gpu_model(cfg, sd)
     g = make_complex(seed=9, n_res=120, n_lig=20)
