@@ -102,6 +102,7 @@ struct RunGroup {
   const float* sig; const int* sig_idx;   // optional per-graph vector [B][ns] added to every edge attr row
   const float *nvec, *ew; float sgn;
   float* msg;
+  int esplit = 1;
 };
 
 // One TensorProductConvLayer in the node-contracted form (k_conv.hip).
@@ -126,13 +127,14 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     }
     {
       PhaseTimer t(m, "k_node_contract", s);
-      launch_node_contract(Xin, g.gbase, g.gcount, L.wpack[wg], L.pcs, L.n_pc, L.max_mul_out, L.HK, L.HKp, L.NTs, c.Y, s);
+      launch_node_contract(Xin, g.gbase, g.gcount, L.wpack[wg], L.nc_items, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, c.Y, s);
     }
     EdgeConvArgs a{};
     a.gcount = g.gcount; a.goff = g.goff; a.tgt = g.tgt; a.tslot = g.tslot; a.arow = g.arow; a.tbase = g.tbase;
     a.HE = c.HE; a.P = c.P; a.Q = c.Q; a.Y = c.Y; a.nvec = g.nvec; a.ew = g.ew; a.sgn = g.sgn;
-    a.H = H; a.HKp = L.HKp; a.NT = L.NT; a.NTs = L.NTs; a.sh_lmax = m.cfg.sh_lmax;
-    a.paths = L.paths; a.ctab = L.ctab; a.items = L.items; a.n_items = L.n_items; a.msg = g.msg;
+    a.H = H; a.HKp = L.HKp; a.NTs = L.NTs; a.sh_lmax = m.cfg.sh_lmax; a.D_out = L.D_out; a.GN = L.GN; a.n_ob = L.n_ob;
+    a.maxd = L.maxd; a.obs = L.obs; a.qdesc = L.qdesc; a.paths = L.paths; a.ctab = L.ctab; a.gmap = L.gmap; a.msg = g.msg;
+    a.esplit = g.esplit > 0 ? g.esplit : 1;
     {
       PhaseTimer t(m, "k_edge_conv", s);
       launch_edge_conv(a, s);

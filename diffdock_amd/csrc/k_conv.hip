@@ -17,67 +17,88 @@
 namespace ddmi {
 
 // ------------------------------------------------------------------ node pre-contraction
-// grid (col blocks of 128 over HK*mul_out, node blocks of 32, path-components); 4 waves, each a
-// 32 x 32 tile on v_mfma_f32_32x32x2_f32 with K = mul_in (10..48): the kernel is write-bound.
+// Workgroup = 16 gather nodes x KC consecutive k (rows of W2^T incl. the bias row).  Per k the four waves
+// share the (path, 16-wide w tile) work items: A = x rows from LDS (one fragment per input component i),
+// B = the k-th slab of the packed second-layer weights (L2-resident, 4 MB per edge group), v_mfma_f32_16x16x4_f32,
+// results scattered into an LDS row image in the item-major column order and then streamed out as 256-B runs
+// Y[node][super-tile][k][64] -- the exact order k_edge_conv reads them back.
+constexpr int NC_NODES = 16, NC_KC = 5, NC_XS = XS + 1;
+
 __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
                                                        const float* __restrict__ wpack,
-                                                       const PathComp* __restrict__ pcs, int HK, int HKp, int NTs,
-                                                       float* __restrict__ Y) {
-  const PathComp pc = pcs[blockIdx.z];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int ncols = HK * pc.mul_out;
-  const int n0 = blockIdx.x * 128 + wave * 32;
-  const int m0 = blockIdx.y * 32;
-  if (n0 >= ncols || m0 >= gcount) return;
-  const int node = min(m0 + r, gcount - 1);
-  const int col = min(n0 + r, ncols - 1);
-  const float* __restrict__ xp = X + (size_t)(gbase + node) * XS + pc.x_off;
-  const float* __restrict__ wp = wpack + pc.wp_off + (size_t)col * pc.mul_in_pad;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int k0 = 0; k0 < pc.mul_in_pad; k0 += 8) {
-    const int k = k0 + 4 * h;
-    float av[4], bv[4];
-    if (k + 3 < pc.mul_in_pad) {
-      const float4 b4 = *reinterpret_cast<const float4*>(wp + k);
-      bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
-    } else {
-      bv[0] = bv[1] = bv[2] = bv[3] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) av[j] = (k + j) < pc.mul_in ? xp[(k + j) * pc.din] : 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+                                                       const NcItem* __restrict__ items, int n_items, int KS, int HK,
+                                                       int HKp, int NTs, float* __restrict__ Y) {
+  DDMI_DYN_SMEM(float, smem);
+  float* xbuf = smem;                                   // [16][XS+1]
+  float* obuf = smem + ((NC_NODES * NC_XS + 3) & ~3);   // [16][NTs]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int node0 = blockIdx.x * NC_NODES;
+  const int n_super = NTs >> 6;
+  for (int idx = tid; idx < NC_NODES * XS; idx += 256) {
+    const int nl = idx / XS, c = idx - nl * XS;
+    xbuf[nl * NC_XS + c] = (node0 + nl) < gcount ? X[(size_t)(gbase + node0 + nl) * XS + c] : 0.f;
   }
-  const int n = n0 + r;
-  if (n >= ncols) return;
-  const int k = n / pc.mul_out, w = n - k * pc.mul_out;
-  float* __restrict__ yp = Y + (size_t)k * NTs + pc.n_off + w;
+  for (int idx = tid; idx < NC_NODES * NTs; idx += 256) obuf[idx] = 0.f;
+  __syncthreads();
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int kk = 0; kk < NC_KC; ++kk) {
+    const int k = blockIdx.y * NC_KC + kk;
+    if (k >= HK) break;
+    const float* __restrict__ slab = wpack + (size_t)k * KS;
+    for (int it = wave; it < n_items; it += 4) {
+      const NcItem I = items[it];
+      f32x4 acc[5];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-    if (m < gcount) yp[(size_t)m * HKp * NTs] = acc[i];
+      for (int i = 0; i < 5; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* __restrict__ bp = slab + I.wk_off + (size_t)lq * I.w_pad + I.w0 + lr;
+      const float* __restrict__ xp = xbuf + lr * NC_XS + I.x_off;
+      for (int u0 = 0; u0 < I.u_pad; u0 += 4) {
+        const float b = bp[(size_t)u0 * I.w_pad];
+        const int u = u0 + lq;
+        const bool ok = u < I.mul_in;
+        for (int i = 0; i < I.din; ++i) {
+          const float a = ok ? xp[u * I.din + i] : 0.f;
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        }
+      }
+      if (lr < I.n_w) {
+        float* __restrict__ op = obuf + I.col_base + (I.w0 + lr) * I.itemw;
+        for (int i = 0; i < I.din; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) op[(4 * lq + r) * NTs + i] = acc[i][r];
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NC_NODES * (NTs >> 2); idx += 256) {
+      const int nl = idx / (NTs >> 2), q = idx - nl * (NTs >> 2);
+      const int node = node0 + nl;
+      if (node >= gcount) continue;
+      const int col = q << 2, st = col >> 6, c = col & 63;
+      *reinterpret_cast<float4*>(Y + (((size_t)node * n_super + st) * HKp + k) * 64 + c) =
+          *reinterpret_cast<const float4*>(obuf + nl * NTs + col);
+    }
+    __syncthreads();
   }
 }
 
-void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const PathComp* pcs, int n_pc,
-                          int max_mul_out, int HK, int HKp, int NTs, float* Y, hipStream_t s) {
-  if (gcount <= 0 || n_pc <= 0) return;
-  dim3 grid(cdiv((long)HK * max_mul_out, 128), cdiv(gcount, 32), n_pc);
-  hipLaunchKernelGGL(k_node_contract, grid, dim3(256), 0, s, X, gbase, gcount, wpack, pcs, HK, HKp, NTs, Y);
+void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcItem* items, int n_items,
+                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s) {
+  if (gcount <= 0 || n_items <= 0) return;
+  const size_t smem = (size_t)(((NC_NODES * NC_XS + 3) & ~3) + NC_NODES * NTs) * sizeof(float);
+  dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, NC_KC));
+  hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, items, n_items, KS, HK, HKp, NTs, Y);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------ edge kernel
-// One workgroup (8 waves) per gather node d; its edges are processed 16 at a time:
-//   phase 1  h[16][HKp]   = relu(HE[arow] + P[tgt] + Q[d]) (+) 1            -> LDS
-//   phase 2  T[16][NT]    = h * Y_d   wave w owns column super-tiles w, w+8, .. of 64 columns;
-//            per k-step of 4 one ds_read (A), one 16-B global load (B, 4 column tiles) and
-//            four v_mfma_f32_16x16x4_f32; accumulators -> LDS as float4 rows
-//   phase 3  coupling with the edge's spherical harmonics, one thread per (edge, out block, w),
-//            message written to its slot of the target-CSR (no atomics, deterministic)
+// One workgroup per (gather node d, split); edges are processed 32 at a time (two 16-row MFMA tiles):
+//   phase 1  h[32][HKp] = relu(HE[arow] + P[tgt] + Q[d]) (+) 1, per-edge coupling vectors
+//            G[e][path][i][k'] = sum_j C[i][j][k'] sh_e[j]                                       -> LDS
+//   phase 2  wave w owns the 64-column super-tiles w, w+W, ..: T = h * Y_d on v_mfma_f32_16x16x4_f32, Y_d streamed
+//            from HBM in its storage order with a 2-deep register prefetch (one 16-B load feeds 8 MFMAs); the
+//            accumulators never leave registers: lane (l&15) of a 16-lane group holds one quad of an item for 4
+//            edges, contracts it with G, sums the item's quads with wave shuffles -> message image in LDS
+//   phase 3  message rows streamed to their slots of the target-ordered buffer (no atomics, deterministic)
 __device__ __forceinline__ void edge_sh(const float* n, float sgn, int lmax, float* sh) {
   const float x = sgn * n[0], y = sgn * n[1], z = sgn * n[2];
   sh[0] = 1.f;
@@ -90,27 +111,35 @@ __device__ __forceinline__ void edge_sh(const float* n, float sgn, int lmax, flo
     sh[6] = s5 * (y * y - 0.5f * (x * x + z * z));
     sh[7] = s5 * (s3 * y * z);
     sh[8] = s5 * ((s3 / 2) * (z * z - x * x));
+  } else {
+    sh[4] = sh[5] = sh[6] = sh[7] = sh[8] = 0.f;
   }
 }
 
-__global__ __launch_bounds__(512) void k_edge_conv(EdgeConvArgs a) {
+constexpr int EC_E = 32;   // edges per pass
+
+__global__ __launch_bounds__(768) void k_edge_conv(EdgeConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
-  const int HS = a.HKp + 1;                 // odd-ish row stride: conflict-free column reads
-  float* hbuf = smem;                       // [16][HS]
-  float* tbuf = smem + ((16 * HS + 3) & ~3);  // [16][NTs]
-  float* shbuf = tbuf + 16 * a.NTs;         // [16][12]: sh(9) + ew + pad
-  int* ibuf = reinterpret_cast<int*>(shbuf + 16 * 12);  // [16] tslot
+  const int HS = a.HKp + 1;                          // odd row stride: conflict-free A-fragment reads
+  const int GS = a.GN | 1, MS = a.D_out | 1;
+  float* hbuf = smem;                                // [32][HS]
+  float* gbuf = hbuf + EC_E * HS;                    // [32][GS]
+  float* mbuf = gbuf + EC_E * GS;                    // [32][MS]
+  float* wbuf = mbuf + EC_E * MS;                    // [32] edge weight
+  int* ibuf = reinterpret_cast<int*>(wbuf + EC_E);   // [32] tslot
   const int d = blockIdx.x;
   const int e_begin = a.goff[d], e_end = a.goff[d + 1];
-  if (e_begin >= e_end) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* __restrict__ Yd = a.Y + (size_t)d * a.HKp * a.NTs;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
+  const int n_super = a.NTs >> 6;
+  const float* __restrict__ Yd = a.Y + (size_t)d * n_super * a.HKp * 64;
   const float* __restrict__ Qd = a.Q + (size_t)d * a.H;
-  const int n_super = (a.NT + 63) >> 6;
-  for (int e0 = e_begin; e0 < e_end; e0 += 16) {
-    const int ne = min(16, e_end - e0);
+  const int lr = lane & 15, lq = lane >> 4;
+  int pass = 0;
+  for (int e0 = e_begin; e0 < e_end; e0 += EC_E, ++pass) {
+    if (pass % a.esplit != (int)blockIdx.y) continue;
+    const int ne = min(EC_E, e_end - e0);
     // ---- phase 1
-    for (int idx = tid; idx < 16 * a.HKp; idx += 512) {
+    for (int idx = tid; idx < EC_E * a.HKp; idx += nthr) {
       const int el = idx / a.HKp, k = idx - el * a.HKp;
       float v = 0.f;
       if (el < ne) {
@@ -125,67 +154,109 @@ __global__ __launch_bounds__(512) void k_edge_conv(EdgeConvArgs a) {
       }
       hbuf[el * HS + k] = v;
     }
-    if (tid < 16) {
-      float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < ne * a.GN; idx += nthr) {
+      const int el = idx / a.GN, g = idx - el * a.GN;
+      const int e = e0 + el;
+      const int ar = a.arow ? a.arow[e] : e;
+      float sh[9];
+      edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
+      const GEntry G = a.gmap[g];
+      float acc = 0.f;
+      for (int j = 0; j < G.ds; ++j) acc = fmaf(a.ctab[G.c_idx + j * G.dout], sh[G.s_off + j], acc);
+      gbuf[el * GS + g] = acc;
+    }
+    for (int idx = tid; idx < EC_E * a.D_out; idx += nthr) mbuf[(idx / a.D_out) * MS + (idx % a.D_out)] = 0.f;
+    if (tid < EC_E) {
       float w = 0.f;
       int slot = 0;
       if (tid < ne) {
         const int e = e0 + tid;
         const int ar = a.arow ? a.arow[e] : e;
-        edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
         w = a.ew ? a.ew[ar] : 1.f;
         slot = a.tslot[e];
       }
-#pragma unroll
-      for (int j = 0; j < 9; ++j) shbuf[tid * 12 + j] = sh[j];
-      shbuf[tid * 12 + 9] = w;
+      wbuf[tid] = w;
       ibuf[tid] = slot;
     }
     __syncthreads();
     // ---- phase 2
-    for (int st = wave; st < n_super; st += 8) {
-      const int col0 = st * 64 + 4 * (lane & 15);
-      f32x4 acc[4];
+    const bool two = ne > 16;
+    for (int st = wave; st < n_super; st += nwave) {
+      const int col0 = st * 64 + 4 * lr;
+      f32x4 acc0[4], acc1[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* __restrict__ hp = hbuf + (lane & 15) * HS + (lane >> 4);
-      const float* __restrict__ yp = Yd + (size_t)(lane >> 4) * a.NTs + col0;
+      for (int c = 0; c < 4; ++c) { acc0[c] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const float* __restrict__ hp0 = hbuf + lr * HS + lq;
+      const float* __restrict__ hp1 = hp0 + 16 * HS;
+      const float* __restrict__ yp = Yd + ((size_t)st * a.HKp + lq) * 64 + 4 * lr;
+      float4 b0 = *reinterpret_cast<const float4*>(yp);
+      float4 b1 = a.HKp > 4 ? *reinterpret_cast<const float4*>(yp + 4 * 64) : b0;
       for (int k0 = 0; k0 < a.HKp; k0 += 4) {
-        const float av = hp[k0];
-        const float4 b4 = *reinterpret_cast<const float4*>(yp + (size_t)k0 * a.NTs);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b4.x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b4.y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b4.z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b4.w, acc[3], 0, 0, 0);
+        const float4 b = b0;
+        b0 = b1;
+        if (k0 + 8 < a.HKp) b1 = *reinterpret_cast<const float4*>(yp + (size_t)(k0 + 8) * 64);
+        const float a0 = hp0[k0];
+        acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc0[0], 0, 0, 0);
+        acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.y, acc0[1], 0, 0, 0);
+        acc0[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.z, acc0[2], 0, 0, 0);
+        acc0[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.w, acc0[3], 0, 0, 0);
+        if (two) {
+          const float a1 = hp1[k0];
+          acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.x, acc1[0], 0, 0, 0);
+          acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc1[1], 0, 0, 0);
+          acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.z, acc1[2], 0, 0, 0);
+          acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.w, acc1[3], 0, 0, 0);
+        }
       }
+      // coupling in registers: this lane's quad = columns col0 .. col0+3
+      int ob = -1;
+      for (int b = 0; b < a.n_ob; ++b)
+        if (col0 >= a.obs[b].base && col0 < a.obs[b].base + a.obs[b].mul * a.obs[b].itemw) ob = b;
+      ObInfo O{0, 4, 0, 0, 1};
+      int w = 0, qi = 0;
+      QuadDesc qd{{-1, -1, -1, -1}, {0, 0, 0, 0}};
+      if (ob >= 0) {
+        O = a.obs[ob];
+        const int rel = col0 - O.base;
+        w = rel / O.itemw;
+        qi = (rel - w * O.itemw) >> 2;
+        qd = a.qdesc[ob * 4 + qi];
+      }
+      int goffs[4];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int row = 4 * (lane >> 4) + rr;
-        *reinterpret_cast<float4*>(tbuf + row * a.NTs + col0) = make_float4(acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr]);
+      for (int c = 0; c < 4; ++c) goffs[c] = qd.path[c] >= 0 ? a.paths[qd.path[c]].g_off + qd.comp[c] * O.dout : -1;
+      const int nq = O.itemw >> 2;
+      for (int rt = 0; rt < (two ? 2 : 1); ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int el = rt * 16 + 4 * lq + r;
+          float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+          const float* __restrict__ G = gbuf + el * GS;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (goffs[c] < 0) continue;
+            const float t = rt == 0 ? acc0[c][r] : acc1[c][r];
+            for (int k = 0; k < O.dout; ++k) m[k] = fmaf(G[goffs[c] + k], t, m[k]);
+          }
+          for (int k = 0; k < a.maxd; ++k) {      // sum the item's quads (items never straddle a 16-lane group)
+            const float m1 = __shfl_down(m[k], 1, 64);
+            if (nq >= 2) m[k] += m1;
+            const float m2 = __shfl_down(m[k], 2, 64);
+            if (nq >= 4) m[k] += m2;
+          }
+          if (ob >= 0 && qi == 0 && el < ne) {
+            float* __restrict__ mp = mbuf + el * MS + O.o_off + w * O.dout;
+            const float we = wbuf[el];
+            for (int k = 0; k < O.dout; ++k) mp[k] = we * m[k];
+          }
+        }
       }
     }
     __syncthreads();
     // ---- phase 3
-    for (int idx = tid; idx < ne * a.n_items; idx += 512) {
-      const int el = idx / a.n_items, it = idx - el * a.n_items;
-      const CgItem item = a.items[it];
-      const float* __restrict__ T = tbuf + el * a.NTs;
-      const float* __restrict__ sh = shbuf + el * 12;
-      float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int p = item.path_begin; p < item.path_end; ++p) {
-        const DevPath P = a.paths[p];
-        const float* __restrict__ C = a.ctab + P.c_off;
-        for (int i = 0; i < P.din; ++i) {
-          const float t = T[P.n_off + i * P.mul_out + item.w];
-          for (int j = 0; j < P.ds; ++j) {
-            const float ts = t * sh[P.s_off + j];
-            for (int k = 0; k < P.dout; ++k) m[k] = fmaf(C[(i * P.ds + j) * P.dout + k], ts, m[k]);
-          }
-        }
-      }
-      const float w = sh[9];
-      float* __restrict__ out = a.msg + (size_t)ibuf[el] * XS + item.o_off + item.w * item.dout;
-      for (int k = 0; k < item.dout; ++k) out[k] = w * m[k];
+    for (int idx = tid; idx < ne * a.D_out; idx += nthr) {
+      const int el = idx / a.D_out, c = idx - el * a.D_out;
+      a.msg[(size_t)ibuf[el] * XS + c] = mbuf[el * MS + c];
     }
     __syncthreads();
   }
@@ -193,8 +264,11 @@ __global__ __launch_bounds__(512) void k_edge_conv(EdgeConvArgs a) {
 
 void launch_edge_conv(const EdgeConvArgs& a, hipStream_t s) {
   if (a.gcount <= 0) return;
-  const size_t smem = (size_t)(((16 * (a.HKp + 1) + 3) & ~3) + 16 * a.NTs + 16 * 12 + 16) * sizeof(float);
-  hipLaunchKernelGGL(k_edge_conv, dim3(a.gcount), dim3(512), smem, s, a);
+  const int HS = a.HKp + 1, GS = a.GN | 1, MS = a.D_out | 1;
+  const size_t smem = (size_t)(EC_E * (HS + GS + MS) + 2 * EC_E) * sizeof(float);
+  const int n_super = a.NTs >> 6;
+  const int waves = n_super < 12 ? n_super : 12;
+  hipLaunchKernelGGL(k_edge_conv, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

@@ -21,24 +21,29 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- k_conv.hip
-struct PathComp {   // one (path, input component i) slab of the node pre-contraction
-  int x_off;        // i_off + i  (column of x; element u at x_off + u*din)
-  int din, mul_in, mul_in_pad, mul_out;
-  int n_off;        // column offset inside a Y row: path.n_off + i*mul_out
-  int wp_off;       // float offset of the packed weights [HK*mul_out][mul_in_pad]
-};
-struct DevPath {    // coupling stage descriptor
+// Column layout of a contracted node row Y_d[k][n] ("item-major"): for every output block ob and every output
+// channel w one ITEM of itemw = 4, 8 or 16 consecutive columns holding the (path, i) terms that feed that output
+// channel, so that after the edge GEMM one lane (or 2/4 neighbouring lanes) owns everything an output needs.
+struct ObInfo { int base, itemw, mul, o_off, dout; };       // columns [base, base + mul*itemw)
+struct QuadDesc { int path[4]; int comp[4]; };             // per (ob, quad in item): path = -1 -> padding column
+struct DevPath {    // coupling descriptor of one tensor-product path
   int n_off, mul_out, din, ds, dout, s_off, c_off, o_off;
   int mul_in, i_off, w_off;   // used by the per-edge-weight form (k_tp_apply)
+  int g_off;                  // offset of this path's [din][dout] block in the per-edge coupling vector G
 };
-struct CgItem { int path_begin, path_end, o_off, dout, w; };  // one (output block, w) work item
+struct GEntry { int c_idx, s_off, ds, dout; };              // G[g] = sum_j ctab[c_idx + j*dout] * sh[s_off + j]
+struct CgItem { int path_begin, path_end, o_off, dout, w; };  // (output block, w) work item of k_tp_apply
+struct NcItem {     // one (path, 16-wide w tile) unit of work of the node contraction
+  int x_off, din, mul_in, u_pad, w0, n_w, w_pad, wk_off, col_base, itemw;
+};
 
-// Y[node][k][n] = sum_u x[node][x_off + u*din] * Wp[(k*mul_out+w)][u]   (k < HK, bias row k = H)
-void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const PathComp* pcs, int n_pc,
-                          int max_mul_out, int HK, int HKp, int NTs, float* Y, hipStream_t s);
+// Y[node][st][k][64] (st = 64-column super-tile) = sum_u x[node][x_off + u*din + i] * W2pack[k][path][u][w]
+void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcItem* items, int n_items,
+                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s);
 
 struct EdgeConvArgs {
-  int gcount;            // gather nodes (one workgroup each)
+  int gcount;            // gather nodes
+  int esplit;            // workgroups per gather node (its 32-edge passes are dealt round-robin)
   const int* goff;       // [gcount+1]
   const int* tgt;        // [E] global target node id
   const int* tslot;      // [E] row of msg
@@ -47,12 +52,12 @@ struct EdgeConvArgs {
   const float* HE;       // [rows][H]   W1e * edge_attr (+ per-graph term)
   const float* P;        // [tcount][H] W1s * x_target[:ns]
   const float* Q;        // [gcount][H] W1d * x_gather[:ns] + b1
-  const float* Y;        // [gcount][HKp][NTs]
+  const float* Y;        // [gcount][n_super][HKp][64]
   const float* nvec;     // [rows][3] unit edge vectors (by arow)
   const float* ew;       // [rows] edge weights or nullptr
   float sgn;             // +1 / -1 : direction of nvec for this group
-  int H, HKp, NT, NTs, sh_lmax;
-  const DevPath* paths; const float* ctab; const CgItem* items; int n_items;
+  int H, HKp, NTs, sh_lmax, D_out, GN, n_ob, maxd;
+  const ObInfo* obs; const QuadDesc* qdesc; const DevPath* paths; const float* ctab; const GEntry* gmap;
   float* msg;            // [E][XS]
 };
 void launch_edge_conv(const EdgeConvArgs& a, hipStream_t s);

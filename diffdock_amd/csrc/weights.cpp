@@ -58,8 +58,16 @@ static void init_conv_meta(const ddmi_config& c, ConvW& L, const std::string& na
                    [](const TPPath& a, const TPPath& b) { return a.out_block < b.out_block; });
   L.n_edge = n_edge; L.H = n_edge; L.HK = L.H + 1; L.HKp = (int)round_up(L.HK, 4);
   L.D_in = irreps_dim(in); L.D_out = irreps_dim(out); L.sh_dim = irreps_dim(sh); L.Wn = L.table.weight_numel;
+  // item-major column layout: per output block, per w, one item of (power-of-two quads) x 4 columns
   int nt = 0;
-  for (auto& p : L.table.paths) nt += p.din * p.mul_out;
+  for (int ob = 0; ob < (int)out.size(); ++ob) {
+    int wi = 0;
+    for (auto& p : L.table.paths) if (p.out_block == ob) wi += p.din;
+    int quads = 1;
+    while (quads * 4 < wi) quads *= 2;
+    if (quads > 4 && yform) throw Error(DDMI_ERR_ARG, "tensor product with more than 16 terms per output channel");
+    nt = (int)round_up(nt, quads * 4) + out[ob].mul * quads * 4;
+  }
   L.NT = nt; L.NTs = (int)round_up(nt, 64);
 }
 
@@ -174,30 +182,66 @@ static void commit_conv(Model& m, ConvW& L) {
   // coupling tables ---------------------------------------------------------------
   std::vector<DevPath> dp;
   std::vector<float> ctab;
+  std::vector<GEntry> gmap;
   int n_off = 0;
+  L.maxd = 1;
   for (auto& p : L.table.paths) {
     DevPath d{};
     d.n_off = n_off; d.mul_out = p.mul_out; d.din = p.din; d.ds = p.ds; d.dout = p.dout; d.s_off = p.s_off;
     d.c_off = (int)ctab.size(); d.o_off = p.o_off; d.mul_in = p.mul_in; d.i_off = p.i_off; d.w_off = p.w_off;
+    d.g_off = (int)gmap.size();
+    for (int i = 0; i < p.din; ++i)
+      for (int k = 0; k < p.dout; ++k) gmap.push_back({d.c_off + i * p.ds * p.dout + k, p.s_off, p.ds, p.dout});
     for (double v : p.C) ctab.push_back((float)v);
     dp.push_back(d);
     n_off += p.din * p.mul_out;
+    L.maxd = std::max(L.maxd, p.dout);
   }
   std::vector<CgItem> items;
+  std::vector<ObInfo> obs;
+  std::vector<QuadDesc> qdesc;
+  std::vector<int> slot_base(L.table.paths.size(), 0);   // column of (path, i=0) inside its item
+  int col = 0;
   for (int ob = 0; ob < (int)L.out_irr.size(); ++ob) {
-    int pb = -1, pe = -1;
+    int pb = -1, pe = -1, wi = 0;
     for (int i = 0; i < (int)L.table.paths.size(); ++i)
-      if (L.table.paths[i].out_block == ob) { if (pb < 0) pb = i; pe = i + 1; }
+      if (L.table.paths[i].out_block == ob) { if (pb < 0) pb = i; pe = i + 1; slot_base[i] = wi; wi += L.table.paths[i].din; }
     if (pb < 0) { pb = pe = 0; }  // an output block no path reaches stays zero
     for (int w = 0; w < L.out_irr[ob].mul; ++w) items.push_back({pb, pe, L.out_irr[ob].off, L.out_irr[ob].d(), w});
+    int quads = 1;
+    while (quads * 4 < wi) quads *= 2;
+    col = (int)round_up(col, quads * 4);
+    obs.push_back({col, quads * 4, L.out_irr[ob].mul, L.out_irr[ob].off, L.out_irr[ob].d()});
+    for (int q = 0; q < 4 && L.yform; ++q) {
+      QuadDesc qd;
+      for (int c = 0; c < 4; ++c) {
+        const int slot = q * 4 + c;
+        qd.path[c] = -1; qd.comp[c] = 0;
+        for (int i = pb; i < pe; ++i)
+          if (slot >= slot_base[i] && slot < slot_base[i] + L.table.paths[i].din) { qd.path[c] = i; qd.comp[c] = slot - slot_base[i]; }
+      }
+      qdesc.push_back(qd);
+    }
+    col += L.out_irr[ob].mul * quads * 4;
   }
+  if (L.yform && col != L.NT) throw Error(DDMI_ERR_ARG, "internal: column layout mismatch");
   L.paths = m.wpool.upload(dp);
   L.ctab = m.wpool.upload(ctab);
   L.items = m.wpool.upload(items);
   L.n_items = (int)items.size();
+  L.obs = m.wpool.upload(obs); L.n_ob = (int)obs.size();
+  L.qdesc = m.wpool.upload(qdesc);
+  L.gmap = m.wpool.upload(gmap); L.GN = (int)gmap.size();
   // dense layers --------------------------------------------------------------------
-  std::vector<PathComp> pcs;
-  L.max_mul_out = 0;
+  // packed second layer for the node contraction: [k][path][u_pad4][w_pad16], k = H is the bias row
+  std::vector<int> wk_off(L.table.paths.size(), 0);
+  int KS = 0;
+  for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
+    const TPPath& p = L.table.paths[pi];
+    wk_off[pi] = KS;
+    KS += (int)round_up(p.mul_in, 4) * (int)round_up(p.mul_out, 16);
+  }
+  L.KS = KS;
   for (int g = 0; g < L.G; ++g) {
     const std::string pre = L.G == 1 ? L.name + ".fc" : L.name + ".fc." + std::to_string(g);
     L.W1.push_back(up(m, pre + ".0.weight"));
@@ -208,28 +252,34 @@ static void commit_conv(Model& m, ConvW& L) {
       L.b2.push_back(m.wpool.upload(b2.data));
       continue;
     }
-    // packed [path][HK*mul_out][mul_in_pad]: Wp[(k*mul_out+w)][u] = W2[slot(u,w)][k], k = H -> bias
-    std::vector<float> pack;
+    std::vector<float> pack((size_t)HK * KS, 0.f);
     for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
       const TPPath& p = L.table.paths[pi];
-      const int pad = (int)round_up(p.mul_in, 8);
-      const size_t base = pack.size();
-      pack.resize(base + (size_t)HK * p.mul_out * pad, 0.f);
+      const int wpad = (int)round_up(p.mul_out, 16);
       for (int k = 0; k < HK; ++k)
-        for (int w = 0; w < p.mul_out; ++w)
-          for (int u = 0; u < p.mul_in; ++u) {
+        for (int u = 0; u < p.mul_in; ++u)
+          for (int w = 0; w < p.mul_out; ++w) {
             const size_t slot = (size_t)p.w_off + (size_t)u * p.mul_out + w;
-            pack[base + ((size_t)k * p.mul_out + w) * pad + u] = k < H ? w2.data[slot * H + k] : b2.data[slot];
+            pack[(size_t)k * KS + wk_off[pi] + (size_t)u * wpad + w] = k < H ? w2.data[slot * H + k] : b2.data[slot];
           }
-      if (g == 0) {
-        for (int i = 0; i < p.din; ++i)
-          pcs.push_back({p.i_off + i, p.din, p.mul_in, pad, p.mul_out, dp[pi].n_off + i * p.mul_out, (int)base});
-        L.max_mul_out = std::max(L.max_mul_out, p.mul_out);
-      }
     }
     L.wpack.push_back(m.wpool.upload(pack));
   }
-  if (L.yform) { L.pcs = m.wpool.upload(pcs); L.n_pc = (int)pcs.size(); }
+  if (L.yform) {
+    // work list of the node contraction: (path, 16-wide w tile), heaviest first so the 4 waves balance
+    std::vector<NcItem> nc;
+    for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
+      const TPPath& p = L.table.paths[pi];
+      const ObInfo& O = obs[p.out_block];
+      const int wpad = (int)round_up(p.mul_out, 16), upad = (int)round_up(p.mul_in, 4);
+      for (int w0 = 0; w0 < p.mul_out; w0 += 16)
+        nc.push_back({p.i_off, p.din, p.mul_in, upad, w0, std::min(16, p.mul_out - w0), wpad, wk_off[pi],
+                      O.base + slot_base[pi], O.itemw});
+    }
+    std::stable_sort(nc.begin(), nc.end(), [](const NcItem& a, const NcItem& b) { return a.u_pad * a.din > b.u_pad * b.din; });
+    L.nc_items = m.wpool.upload(nc);
+    L.n_nc = (int)nc.size();
+  }
   // batch norm (e3nn.nn.BatchNorm eval, eps 1e-5): per-column mean / scale / bias ---------
   if (L.has_bn) {
     const std::string n = L.name + ".batch_norm";
