@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <cstdlib>
 
 #include "model.h"
 
@@ -13,6 +14,7 @@ namespace ddmi {
 struct Model::Cx {
   int B = 0, nL = 0, nR = 0, N = 0, Eb = 0, Err = 0, nT = 0;
   int maxNl = 0, maxNr = 0, Ell_cap = 0, Elr_cap = 0, tor_cap = 32, Et = 0, lig_cap = 33;
+  int y_chunk = 0, esplit_lig = 1;   // tuning knobs (env DDMI_Y_CHUNK / DDMI_ESPLIT)
   bool uniform = false; int Nl_one = 0, R_one = 0;
   std::vector<int> lig_ptr_h, rec_ptr_h;
   // static
@@ -125,17 +127,22 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, c.P, H, g.tcount, H, ns, 0, s);
       gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], c.Q, H, g.gcount, H, ns, 0, s);
     }
-    {
-      PhaseTimer t(m, "k_node_contract", s);
-      launch_node_contract(Xin, g.gbase, g.gcount, L.wpack[wg], L.nc_items, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, c.Y, s);
-    }
     EdgeConvArgs a{};
-    a.gcount = g.gcount; a.goff = g.goff; a.tgt = g.tgt; a.tslot = g.tslot; a.arow = g.arow; a.tbase = g.tbase;
-    a.HE = c.HE; a.P = c.P; a.Q = c.Q; a.Y = c.Y; a.nvec = g.nvec; a.ew = g.ew; a.sgn = g.sgn;
+    a.tgt = g.tgt; a.tslot = g.tslot; a.arow = g.arow; a.tbase = g.tbase;
+    a.HE = c.HE; a.P = c.P; a.Y = c.Y; a.nvec = g.nvec; a.ew = g.ew; a.sgn = g.sgn;
     a.H = H; a.HKp = L.HKp; a.NTs = L.NTs; a.sh_lmax = m.cfg.sh_lmax; a.D_out = L.D_out; a.GN = L.GN; a.n_ob = L.n_ob;
     a.maxd = L.maxd; a.obs = L.obs; a.qdesc = L.qdesc; a.paths = L.paths; a.ctab = L.ctab; a.gmap = L.gmap; a.msg = g.msg;
     a.esplit = g.esplit > 0 ? g.esplit : 1;
-    {
+    // gather nodes are processed in chunks whose contracted rows (341 KB each at ns=48) fit the scratch Y buffer;
+    // with a chunk below the 256 MB Infinity Cache the rows are consumed while still on-die
+    const int chunk = c.y_chunk > 0 ? std::min(c.y_chunk, g.gcount) : g.gcount;
+    for (int d0 = 0; d0 < g.gcount; d0 += chunk) {
+      const int n = std::min(chunk, g.gcount - d0);
+      {
+        PhaseTimer t(m, "k_node_contract", s);
+        launch_node_contract(Xin, g.gbase + d0, n, L.wpack[wg], L.nc_items, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, c.Y, s);
+      }
+      a.gcount = n; a.goff = g.goff + d0; a.Q = c.Q + (size_t)d0 * H;
       PhaseTimer t(m, "k_edge_conv", s);
       launch_edge_conv(a, s);
     }
@@ -307,7 +314,10 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   for (auto& L : m.conv_layers) upd(L);
   for (auto& L : m.lig_emb_layers) upd(L);
   for (auto& L : m.rec_emb_layers) upd(L);
-  c.Y = dalloc<float>(m, nullptr, {std::max(nL, nR), HKp, NTs}, true);
+  if (const char* e = getenv("DDMI_Y_CHUNK")) c.y_chunk = atoi(e);
+  if (const char* e = getenv("DDMI_ESPLIT")) c.esplit_lig = std::max(1, atoi(e));
+  const int y_nodes = c.y_chunk > 0 ? std::min(c.y_chunk, std::max(nL, nR)) : std::max(nL, nR);
+  c.Y = dalloc<float>(m, nullptr, {y_nodes, HKp, NTs}, true);
   const int ecap[4] = {c.Ell_cap, c.Elr_cap, c.Err, c.Elr_cap};
   for (int g = 0; g < 4; ++g) c.msg[g] = dalloc<float>(m, nullptr, {ecap[g], XS});
   {
@@ -450,8 +460,9 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
                       nullptr, c.pnvec, c.pew, 1.f, c.msg[1]};
   const RunGroup g_rr{nL, nR, nL, nR, c.rr_goff, c.rr_tgt, c.rr_tslot, c.rr_arow, c.rec_edge_base, c.Err, nullptr, c.rec_sig,
                       c.rr_batch, c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
-  const RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
-                      nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
+  RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
+                nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
+  g_rl.esplit = c.esplit_lig;   // ligand gather nodes carry up to Nr edges each: split their passes over workgroups
   const int Lc = (int)m.conv_layers.size();
   t_phase.reset();
   for (int l = 0; l < Lc; ++l, ++xi) {

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
                                                        int HKp, int NTs, float* __restrict__ Y) {
   DDMI_DYN_SMEM(float, smem);
   float* xbuf = smem;                                   // [16][XS+1]
-  float* obuf = smem + ((NC_NODES * NC_XS + 3) & ~3);   // [16][NTs]
+  float* obuf = smem + ((NC_NODES * NC_XS + 3) & ~3);   // [16][NTs + 4] (row shift of 4 banks)
+  const int OS = NTs + 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int node0 = blockIdx.x * NC_NODES;
   const int n_super = NTs >> 6;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
     const int nl = idx / XS, c = idx - nl * XS;
     xbuf[nl * NC_XS + c] = (node0 + nl) < gcount ? X[(size_t)(gbase + node0 + nl) * XS + c] : 0.f;
   }
-  for (int idx = tid; idx < NC_NODES * NTs; idx += 256) obuf[idx] = 0.f;
+  for (int idx = tid; idx < NC_NODES * OS; idx += 256) obuf[idx] = 0.f;
   __syncthreads();
   const int lr = lane & 15, lq = lane >> 4;
   for (int kk = 0; kk < NC_KC; ++kk) {
@@ -52,20 +53,27 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
       for (int i = 0; i < 5; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* __restrict__ bp = slab + I.wk_off + (size_t)lq * I.w_pad + I.w0 + lr;
       const float* __restrict__ xp = xbuf + lr * NC_XS + I.x_off;
-      for (int u0 = 0; u0 < I.u_pad; u0 += 4) {
-        const float b = bp[(size_t)u0 * I.w_pad];
-        const int u = u0 + lq;
-        const bool ok = u < I.mul_in;
-        for (int i = 0; i < I.din; ++i) {
-          const float a = ok ? xp[u * I.din + i] : 0.f;
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+      // all B fragments of the item are requested before the first MFMA (u_pad <= 64): one L2 round trip per item
+      for (int ub = 0; ub < I.u_pad; ub += 64) {
+        float bv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bv[j] = (ub + 4 * j) < I.u_pad ? bp[(size_t)(ub + 4 * j) * I.w_pad] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (ub + 4 * j >= I.u_pad) break;
+          const int u = ub + 4 * j + lq;
+          const bool ok = u < I.mul_in;
+          for (int i = 0; i < I.din; ++i) {
+            const float a = ok ? xp[u * I.din + i] : 0.f;
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[j], acc[i], 0, 0, 0);
+          }
         }
       }
       if (lr < I.n_w) {
         float* __restrict__ op = obuf + I.col_base + (I.w0 + lr) * I.itemw;
         for (int i = 0; i < I.din; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) op[(4 * lq + r) * NTs + i] = acc[i][r];
+          for (int r = 0; r < 4; ++r) op[(4 * lq + r) * OS + i] = acc[i][r];
       }
     }
     __syncthreads();
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
       if (node >= gcount) continue;
       const int col = q << 2, st = col >> 6, c = col & 63;
       *reinterpret_cast<float4*>(Y + (((size_t)node * n_super + st) * HKp + k) * 64 + c) =
-          *reinterpret_cast<const float4*>(obuf + nl * NTs + col);
+          *reinterpret_cast<const float4*>(obuf + nl * OS + col);
     }
     __syncthreads();
   }
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
 void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcItem* items, int n_items,
                           int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s) {
   if (gcount <= 0 || n_items <= 0) return;
-  const size_t smem = (size_t)(((NC_NODES * NC_XS + 3) & ~3) + NC_NODES * NTs) * sizeof(float);
+  const size_t smem = (size_t)(((NC_NODES * NC_XS + 3) & ~3) + NC_NODES * (NTs + 4)) * sizeof(float);
   dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, NC_KC));
   hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, items, n_items, KS, HK, HKp, NTs, Y);
   DDMI_CHECK_HIP(hipGetLastError());
@@ -189,24 +197,34 @@ __global__ __launch_bounds__(768) void k_edge_conv(EdgeConvArgs a) {
       const float* __restrict__ hp0 = hbuf + lr * HS + lq;
       const float* __restrict__ hp1 = hp0 + 16 * HS;
       const float* __restrict__ yp = Yd + ((size_t)st * a.HKp + lq) * 64 + 4 * lr;
-      float4 b0 = *reinterpret_cast<const float4*>(yp);
-      float4 b1 = a.HKp > 4 ? *reinterpret_cast<const float4*>(yp + 4 * 64) : b0;
-      for (int k0 = 0; k0 < a.HKp; k0 += 4) {
-        const float4 b = b0;
-        b0 = b1;
-        if (k0 + 8 < a.HKp) b1 = *reinterpret_cast<const float4*>(yp + (size_t)(k0 + 8) * 64);
-        const float a0 = hp0[k0];
-        acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc0[0], 0, 0, 0);
-        acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.y, acc0[1], 0, 0, 0);
-        acc0[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.z, acc0[2], 0, 0, 0);
-        acc0[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.w, acc0[3], 0, 0, 0);
-        if (two) {
-          const float a1 = hp1[k0];
-          acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.x, acc1[0], 0, 0, 0);
-          acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc1[1], 0, 0, 0);
-          acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.z, acc1[2], 0, 0, 0);
-          acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.w, acc1[3], 0, 0, 0);
+      // Y_d super-tile streamed in blocks of 4 k-steps (4 x 16 B per lane), next block in flight during the 32 MFMAs
+      const int nsteps = a.HKp >> 2;
+      float4 cur[4], nxt[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cur[j] = j < nsteps ? *reinterpret_cast<const float4*>(yp + (size_t)j * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s0 = 0; s0 < nsteps; s0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          nxt[j] = (s0 + 4 + j) < nsteps ? *reinterpret_cast<const float4*>(yp + (size_t)(s0 + 4 + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (s0 + j >= nsteps) break;
+          const float4 b = cur[j];
+          const float a0 = hp0[(s0 + j) * 4];
+          acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc0[0], 0, 0, 0);
+          acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.y, acc0[1], 0, 0, 0);
+          acc0[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.z, acc0[2], 0, 0, 0);
+          acc0[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.w, acc0[3], 0, 0, 0);
+          if (two) {
+            const float a1 = hp1[(s0 + j) * 4];
+            acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.x, acc1[0], 0, 0, 0);
+            acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc1[1], 0, 0, 0);
+            acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.z, acc1[2], 0, 0, 0);
+            acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.w, acc1[3], 0, 0, 0);
+          }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
       }
       // coupling in registers: this lane's quad = columns col0 .. col0+3
       int ob = -1;
