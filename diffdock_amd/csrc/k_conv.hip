@@ -12,6 +12,8 @@
 //                     m_e[o,w,k'] = sum_{paths,i,j} C[i][j][k'] sh_e[j] T[e][path,i,w]
 //   k_reduce_bn     : deterministic segmented mean over the target-CSR, BatchNorm, residual
 // Results equal the reference up to fp32 re-association.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ddmi {
@@ -24,10 +26,13 @@ namespace ddmi {
 // Y[node][super-tile][k][64] -- the exact order k_edge_conv reads them back.
 constexpr int NC_NODES = 16, NC_KC = 5, NC_XS = XS + 1;
 
+// Ablation mask for profiling (env DDMI_ABLATE, 0 in production): lets bench runs switch off individual phases.
+static int ablate_mask() { static int m = getenv("DDMI_ABLATE") ? atoi(getenv("DDMI_ABLATE")) : 0; return m; }
+
 __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
                                                        const float* __restrict__ wpack,
                                                        const NcItem* __restrict__ items, int n_items, int KS, int HK,
-                                                       int HKp, int NTs, float* __restrict__ Y) {
+                                                       int HKp, int NTs, float* __restrict__ Y, int dbg) {
   DDMI_DYN_SMEM(float, smem);
   float* xbuf = smem;                                   // [16][XS+1]
   float* obuf = smem + ((NC_NODES * NC_XS + 3) & ~3);   // [16][NTs + 4] (row shift of 4 banks)
@@ -57,10 +62,10 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
       for (int ub = 0; ub < I.u_pad; ub += 64) {
         float bv[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bv[j] = (ub + 4 * j) < I.u_pad ? bp[(size_t)(ub + 4 * j) * I.w_pad] : 0.f;
+        for (int j = 0; j < 16; ++j) bv[j] = ((ub + 4 * j) < I.u_pad && !(dbg & 256)) ? bp[(size_t)(ub + 4 * j) * I.w_pad] : 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          if (ub + 4 * j >= I.u_pad) break;
+          if (ub + 4 * j >= I.u_pad || (dbg & 512)) break;
           const int u = ub + 4 * j + lq;
           const bool ok = u < I.mul_in;
           for (int i = 0; i < I.din; ++i) {
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
           }
         }
       }
-      if (lr < I.n_w) {
+      if (lr < I.n_w && !(dbg & 1024)) {
         float* __restrict__ op = obuf + I.col_base + (I.w0 + lr) * I.itemw;
         for (int i = 0; i < I.din; ++i)
 #pragma unroll
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
     for (int idx = tid; idx < NC_NODES * (NTs >> 2); idx += 256) {
       const int nl = idx / (NTs >> 2), q = idx - nl * (NTs >> 2);
       const int node = node0 + nl;
-      if (node >= gcount) continue;
+      if (node >= gcount || (dbg & 2048)) continue;
       const int col = q << 2, st = col >> 6, c = col & 63;
       *reinterpret_cast<float4*>(Y + (((size_t)node * n_super + st) * HKp + k) * 64 + c) =
           *reinterpret_cast<const float4*>(obuf + nl * OS + col);
@@ -94,7 +99,8 @@ void launch_node_contract(const float* X, int gbase, int gcount, const float* wp
   if (gcount <= 0 || n_items <= 0) return;
   const size_t smem = (size_t)(((NC_NODES * NC_XS + 3) & ~3) + NC_NODES * (NTs + 4)) * sizeof(float);
   dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, NC_KC));
-  hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, items, n_items, KS, HK, HKp, NTs, Y);
+  hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, items, n_items, KS, HK, HKp, NTs, Y,
+                     ablate_mask());
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -126,6 +132,7 @@ __device__ __forceinline__ void edge_sh(const float* n, float sgn, int lmax, flo
 
 constexpr int EC_E = 32;   // edges per pass
 
+template <int MAXD>
 __global__ __launch_bounds__(768) void k_edge_conv(EdgeConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
   const int HS = a.HKp + 1;                          // odd row stride: conflict-free A-fragment reads
@@ -133,8 +140,8 @@ __global__ __launch_bounds__(768) void k_edge_conv(EdgeConvArgs a) {
   float* hbuf = smem;                                // [32][HS]
   float* gbuf = hbuf + EC_E * HS;                    // [32][GS]
   float* mbuf = gbuf + EC_E * GS;                    // [32][MS]
-  float* wbuf = mbuf + EC_E * MS;                    // [32] edge weight
-  int* ibuf = reinterpret_cast<int*>(wbuf + EC_E);   // [32] tslot
+  float* shbuf = mbuf + EC_E * MS;                   // [32][10]: sh(9), edge weight
+  int* ibuf = reinterpret_cast<int*>(shbuf + EC_E * 10);   // [32][3]: arow, tgt - tbase, tslot
   const int d = blockIdx.x;
   const int e_begin = a.goff[d], e_end = a.goff[d + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
@@ -142,49 +149,55 @@ __global__ __launch_bounds__(768) void k_edge_conv(EdgeConvArgs a) {
   const float* __restrict__ Yd = a.Y + (size_t)d * n_super * a.HKp * 64;
   const float* __restrict__ Qd = a.Q + (size_t)d * a.H;
   const int lr = lane & 15, lq = lane >> 4;
+  const int H4 = a.H >> 2;                           // H = 3*ns is a multiple of 4 for every supported ns
   int pass = 0;
   for (int e0 = e_begin; e0 < e_end; e0 += EC_E, ++pass) {
     if (pass % a.esplit != (int)blockIdx.y) continue;
     const int ne = min(EC_E, e_end - e0);
-    // ---- phase 1
-    for (int idx = tid; idx < EC_E * a.HKp; idx += nthr) {
-      const int el = idx / a.HKp, k = idx - el * a.HKp;
-      float v = 0.f;
-      if (el < ne) {
-        if (k < a.H) {
-          const int e = e0 + el;
-          const int ar = a.arow ? a.arow[e] : e;
-          v = a.HE[(size_t)ar * a.H + k] + a.P[(size_t)(a.tgt[e] - a.tbase) * a.H + k] + Qd[k];
-          v = v > 0.f ? v : 0.f;
-        } else if (k == a.H) {
-          v = 1.f;
-        }
+    // ---- phase 1a: per-edge indices, spherical harmonics, weight
+    if (tid < EC_E) {
+      float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float w = 0.f;
+      int ar = 0, tg = 0, slot = 0;
+      if (tid < ne) {
+        const int e = e0 + tid;
+        ar = a.arow ? a.arow[e] : e;
+        tg = a.tgt[e] - a.tbase;
+        slot = a.tslot[e];
+        edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
+        w = a.ew ? a.ew[ar] : 1.f;
       }
-      hbuf[el * HS + k] = v;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) shbuf[tid * 10 + j] = sh[j];
+      shbuf[tid * 10 + 9] = w;
+      ibuf[tid * 3] = ar; ibuf[tid * 3 + 1] = tg; ibuf[tid * 3 + 2] = slot;
+    }
+    __syncthreads();
+    // ---- phase 1b: h rows (16-B loads), bias column, coupling vectors
+    for (int idx = tid; idx < EC_E * H4; idx += nthr) {
+      const int el = idx / H4, k4 = idx - el * H4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (el < ne && !(a.dbg & 1)) {
+        const float4 x = *reinterpret_cast<const float4*>(a.HE + (size_t)ibuf[el * 3] * a.H + 4 * k4);
+        const float4 p = *reinterpret_cast<const float4*>(a.P + (size_t)ibuf[el * 3 + 1] * a.H + 4 * k4);
+        const float4 q = *reinterpret_cast<const float4*>(Qd + 4 * k4);
+        v.x = fmaxf(x.x + p.x + q.x, 0.f); v.y = fmaxf(x.y + p.y + q.y, 0.f);
+        v.z = fmaxf(x.z + p.z + q.z, 0.f); v.w = fmaxf(x.w + p.w + q.w, 0.f);
+      }
+      float* hp = hbuf + el * HS + 4 * k4;
+      hp[0] = v.x; hp[1] = v.y; hp[2] = v.z; hp[3] = v.w;
+    }
+    for (int idx = tid; idx < EC_E * (a.HKp - a.H); idx += nthr) {
+      const int el = idx / (a.HKp - a.H), k = a.H + idx - el * (a.HKp - a.H);
+      hbuf[el * HS + k] = (k == a.H && el < ne) ? 1.f : 0.f;
     }
     for (int idx = tid; idx < ne * a.GN; idx += nthr) {
       const int el = idx / a.GN, g = idx - el * a.GN;
-      const int e = e0 + el;
-      const int ar = a.arow ? a.arow[e] : e;
-      float sh[9];
-      edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
       const GEntry G = a.gmap[g];
+      const float* __restrict__ sh = shbuf + el * 10 + G.s_off;
       float acc = 0.f;
-      for (int j = 0; j < G.ds; ++j) acc = fmaf(a.ctab[G.c_idx + j * G.dout], sh[G.s_off + j], acc);
+      for (int j = 0; j < G.ds; ++j) acc = fmaf(a.ctab[G.c_idx + j * G.dout], sh[j], acc);
       gbuf[el * GS + g] = acc;
-    }
-    for (int idx = tid; idx < EC_E * a.D_out; idx += nthr) mbuf[(idx / a.D_out) * MS + (idx % a.D_out)] = 0.f;
-    if (tid < EC_E) {
-      float w = 0.f;
-      int slot = 0;
-      if (tid < ne) {
-        const int e = e0 + tid;
-        const int ar = a.arow ? a.arow[e] : e;
-        w = a.ew ? a.ew[ar] : 1.f;
-        slot = a.tslot[e];
-      }
-      wbuf[tid] = w;
-      ibuf[tid] = slot;
     }
     __syncthreads();
     // ---- phase 2
@@ -201,14 +214,14 @@ __global__ __launch_bounds__(768) void k_edge_conv(EdgeConvArgs a) {
       const int nsteps = a.HKp >> 2;
       float4 cur[4], nxt[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) cur[j] = j < nsteps ? *reinterpret_cast<const float4*>(yp + (size_t)j * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < 4; ++j) cur[j] = (j < nsteps && !(a.dbg & 2)) ? *reinterpret_cast<const float4*>(yp + (size_t)j * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
       for (int s0 = 0; s0 < nsteps; s0 += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          nxt[j] = (s0 + 4 + j) < nsteps ? *reinterpret_cast<const float4*>(yp + (size_t)(s0 + 4 + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+          nxt[j] = ((s0 + 4 + j) < nsteps && !(a.dbg & 2)) ? *reinterpret_cast<const float4*>(yp + (size_t)(s0 + 4 + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (s0 + j >= nsteps) break;
+          if (s0 + j >= nsteps || (a.dbg & 4)) break;
           const float4 b = cur[j];
           const float a0 = hp0[(s0 + j) * 4];
           acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc0[0], 0, 0, 0);
@@ -226,67 +239,82 @@ __global__ __launch_bounds__(768) void k_edge_conv(EdgeConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
       }
-      // coupling in registers: this lane's quad = columns col0 .. col0+3
+      // coupling in registers: this lane's quad = columns col0 .. col0+3 (all private arrays statically indexed)
       int ob = -1;
       for (int b = 0; b < a.n_ob; ++b)
         if (col0 >= a.obs[b].base && col0 < a.obs[b].base + a.obs[b].mul * a.obs[b].itemw) ob = b;
       ObInfo O{0, 4, 0, 0, 1};
       int w = 0, qi = 0;
-      QuadDesc qd{{-1, -1, -1, -1}, {0, 0, 0, 0}};
+      int g0 = -1, g1 = -1, g2 = -1, g3 = -1;
       if (ob >= 0) {
         O = a.obs[ob];
         const int rel = col0 - O.base;
         w = rel / O.itemw;
         qi = (rel - w * O.itemw) >> 2;
-        qd = a.qdesc[ob * 4 + qi];
+        const QuadDesc qd = a.qdesc[ob * 4 + qi];
+        g0 = qd.path[0] >= 0 ? a.paths[qd.path[0]].g_off + qd.comp[0] * O.dout : -1;
+        g1 = qd.path[1] >= 0 ? a.paths[qd.path[1]].g_off + qd.comp[1] * O.dout : -1;
+        g2 = qd.path[2] >= 0 ? a.paths[qd.path[2]].g_off + qd.comp[2] * O.dout : -1;
+        g3 = qd.path[3] >= 0 ? a.paths[qd.path[3]].g_off + qd.comp[3] * O.dout : -1;
       }
-      int goffs[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) goffs[c] = qd.path[c] >= 0 ? a.paths[qd.path[c]].g_off + qd.comp[c] * O.dout : -1;
       const int nq = O.itemw >> 2;
-      for (int rt = 0; rt < (two ? 2 : 1); ++rt) {
+      const bool writer = ob >= 0 && qi == 0;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        if ((rt == 1 && !two) || (a.dbg & 8)) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int el = rt * 16 + 4 * lq + r;
-          float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
           const float* __restrict__ G = gbuf + el * GS;
+          const float t0 = rt == 0 ? acc0[0][r] : acc1[0][r], t1 = rt == 0 ? acc0[1][r] : acc1[1][r];
+          const float t2 = rt == 0 ? acc0[2][r] : acc1[2][r], t3 = rt == 0 ? acc0[3][r] : acc1[3][r];
+          float m[MAXD];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (goffs[c] < 0) continue;
-            const float t = rt == 0 ? acc0[c][r] : acc1[c][r];
-            for (int k = 0; k < O.dout; ++k) m[k] = fmaf(G[goffs[c] + k], t, m[k]);
+          for (int k = 0; k < MAXD; ++k) {
+            float v = 0.f;
+            if (k < O.dout) {
+              if (g0 >= 0) v = fmaf(G[g0 + k], t0, v);
+              if (g1 >= 0) v = fmaf(G[g1 + k], t1, v);
+              if (g2 >= 0) v = fmaf(G[g2 + k], t2, v);
+              if (g3 >= 0) v = fmaf(G[g3 + k], t3, v);
+            }
+            const float m1 = __shfl_down(v, 1, 64);     // sum the item's quads (items never straddle a 16-lane group)
+            if (nq >= 2) v += m1;
+            const float m2 = __shfl_down(v, 2, 64);
+            if (nq >= 4) v += m2;
+            m[k] = v;
           }
-          for (int k = 0; k < a.maxd; ++k) {      // sum the item's quads (items never straddle a 16-lane group)
-            const float m1 = __shfl_down(m[k], 1, 64);
-            if (nq >= 2) m[k] += m1;
-            const float m2 = __shfl_down(m[k], 2, 64);
-            if (nq >= 4) m[k] += m2;
-          }
-          if (ob >= 0 && qi == 0 && el < ne) {
+          if (writer && el < ne) {
             float* __restrict__ mp = mbuf + el * MS + O.o_off + w * O.dout;
-            const float we = wbuf[el];
-            for (int k = 0; k < O.dout; ++k) mp[k] = we * m[k];
+            const float we = shbuf[el * 10 + 9];
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k)
+              if (k < O.dout) mp[k] = we * m[k];
           }
         }
       }
     }
     __syncthreads();
     // ---- phase 3
-    for (int idx = tid; idx < ne * a.D_out; idx += nthr) {
+    for (int idx = tid; idx < ne * a.D_out && !(a.dbg & 16); idx += nthr) {
       const int el = idx / a.D_out, c = idx - el * a.D_out;
-      a.msg[(size_t)ibuf[el] * XS + c] = mbuf[el * MS + c];
+      a.msg[(size_t)ibuf[el * 3 + 2] * XS + c] = mbuf[el * MS + c];
     }
     __syncthreads();
   }
 }
 
-void launch_edge_conv(const EdgeConvArgs& a, hipStream_t s) {
-  if (a.gcount <= 0) return;
+void launch_edge_conv(const EdgeConvArgs& a_in, hipStream_t s) {
+  if (a_in.gcount <= 0) return;
+  EdgeConvArgs a = a_in;
+  a.dbg = ablate_mask();
   const int HS = a.HKp + 1, GS = a.GN | 1, MS = a.D_out | 1;
-  const size_t smem = (size_t)(EC_E * (HS + GS + MS) + 2 * EC_E) * sizeof(float);
+  const size_t smem = (size_t)(EC_E * (HS + GS + MS) + 13 * EC_E) * sizeof(float);
   const int n_super = a.NTs >> 6;
   const int waves = n_super < 12 ? n_super : 12;
-  hipLaunchKernelGGL(k_edge_conv, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
+  if (a.H % 4 != 0) throw Error(DDMI_ERR_ARG, "3*ns must be a multiple of 4");
+  if (a.maxd <= 3) hipLaunchKernelGGL(k_edge_conv<3>, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
+  else hipLaunchKernelGGL(k_edge_conv<5>, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

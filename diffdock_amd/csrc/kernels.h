@@ -59,6 +59,7 @@ struct EdgeConvArgs {
   int H, HKp, NTs, sh_lmax, D_out, GN, n_ob, maxd;
   const ObInfo* obs; const QuadDesc* qdesc; const DevPath* paths; const float* ctab; const GEntry* gmap;
   float* msg;            // [E][XS]
+  int dbg = 0;           // profiling ablation mask (env DDMI_ABLATE)
 };
 void launch_edge_conv(const EdgeConvArgs& a, hipStream_t s);
 
