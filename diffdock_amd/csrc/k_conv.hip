@@ -24,10 +24,45 @@ namespace ddmi {
 // B = the k-th slab of the packed second-layer weights (L2-resident, 4 MB per edge group), v_mfma_f32_16x16x4_f32,
 // results scattered into an LDS row image in the item-major column order and then streamed out as 256-B runs
 // Y[node][super-tile][k][64] -- the exact order k_edge_conv reads them back.
-constexpr int NC_NODES = 16, NC_KC = 5, NC_XS = XS + 1;
+constexpr int NC_NODES = 16, NC_KC = 15, NC_XS = XS + 1;
 
 // Ablation mask for profiling (env DDMI_ABLATE, 0 in production): lets bench runs switch off individual phases.
 static int ablate_mask() { static int m = getenv("DDMI_ABLATE") ? atoi(getenv("DDMI_ABLATE")) : 0; return m; }
+
+// one (path, 16-wide w tile): all A (LDS) and B (L2) fragments are requested before the MFMA chain starts
+template <int DIN>
+__device__ __forceinline__ void nc_item(const NcItem& I, const float* __restrict__ slab, const float* __restrict__ xbuf,
+                                        float* __restrict__ obuf, int OS, int lr, int lq, int dbg) {
+  f32x4 acc[DIN];
+#pragma unroll
+  for (int i = 0; i < DIN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ bp = slab + I.wk_off + (size_t)lq * I.w_pad + I.w0 + lr;
+  const float* __restrict__ xp = xbuf + lr * NC_XS + I.x_off + lq * DIN;
+  for (int ub = 0; ub < I.u_pad; ub += 32) {
+    float bv[8], av[8][DIN];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int u = ub + 4 * j;
+      bv[j] = (u < I.u_pad && !(dbg & 256)) ? bp[(size_t)u * I.w_pad] : 0.f;
+      const bool ok = (u + lq) < I.mul_in;
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) av[j][i] = ok ? xp[u * DIN + i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (ub + 4 * j >= I.u_pad || (dbg & 512)) break;
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][i], bv[j], acc[i], 0, 0, 0);
+    }
+  }
+  if (lr < I.n_w && !(dbg & 1024)) {
+    float* __restrict__ op = obuf + I.col_base + (I.w0 + lr) * I.itemw;
+#pragma unroll
+    for (int i = 0; i < DIN; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) op[(4 * lq + r) * OS + i] = acc[i][r];
+  }
+}
 
 __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
                                                        const float* __restrict__ wpack,
@@ -37,58 +72,39 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
   float* xbuf = smem;                                   // [16][XS+1]
   float* obuf = smem + ((NC_NODES * NC_XS + 3) & ~3);   // [16][NTs + 4] (row shift of 4 banks)
   const int OS = NTs + 4;
+  NcItem* sitems = reinterpret_cast<NcItem*>(obuf + NC_NODES * OS);   // [n_items]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int node0 = blockIdx.x * NC_NODES;
-  const int n_super = NTs >> 6;
+  const int n_super = NTs >> 6, NQ = NTs >> 2;
   for (int idx = tid; idx < NC_NODES * XS; idx += 256) {
     const int nl = idx / XS, c = idx - nl * XS;
     xbuf[nl * NC_XS + c] = (node0 + nl) < gcount ? X[(size_t)(gbase + node0 + nl) * XS + c] : 0.f;
   }
   for (int idx = tid; idx < NC_NODES * OS; idx += 256) obuf[idx] = 0.f;
+  for (int idx = tid; idx < n_items; idx += 256) sitems[idx] = items[idx];
   __syncthreads();
   const int lr = lane & 15, lq = lane >> 4;
-  for (int kk = 0; kk < NC_KC; ++kk) {
-    const int k = blockIdx.y * NC_KC + kk;
-    if (k >= HK) break;
+  const int k_end = min((int)(blockIdx.y + 1) * NC_KC, HK);
+  for (int k = blockIdx.y * NC_KC; k < k_end; ++k) {
     const float* __restrict__ slab = wpack + (size_t)k * KS;
     for (int it = wave; it < n_items; it += 4) {
-      const NcItem I = items[it];
-      f32x4 acc[5];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* __restrict__ bp = slab + I.wk_off + (size_t)lq * I.w_pad + I.w0 + lr;
-      const float* __restrict__ xp = xbuf + lr * NC_XS + I.x_off;
-      // all B fragments of the item are requested before the first MFMA (u_pad <= 64): one L2 round trip per item
-      for (int ub = 0; ub < I.u_pad; ub += 64) {
-        float bv[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) bv[j] = ((ub + 4 * j) < I.u_pad && !(dbg & 256)) ? bp[(size_t)(ub + 4 * j) * I.w_pad] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (ub + 4 * j >= I.u_pad || (dbg & 512)) break;
-          const int u = ub + 4 * j + lq;
-          const bool ok = u < I.mul_in;
-          for (int i = 0; i < I.din; ++i) {
-            const float a = ok ? xp[u * I.din + i] : 0.f;
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[j], acc[i], 0, 0, 0);
-          }
-        }
-      }
-      if (lr < I.n_w && !(dbg & 1024)) {
-        float* __restrict__ op = obuf + I.col_base + (I.w0 + lr) * I.itemw;
-        for (int i = 0; i < I.din; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) op[(4 * lq + r) * OS + i] = acc[i][r];
-      }
+      const NcItem I = sitems[it];
+      if (I.din == 1) nc_item<1>(I, slab, xbuf, obuf, OS, lr, lq, dbg);
+      else if (I.din == 3) nc_item<3>(I, slab, xbuf, obuf, OS, lr, lq, dbg);
+      else nc_item<5>(I, slab, xbuf, obuf, OS, lr, lq, dbg);
     }
     __syncthreads();
-    for (int idx = tid; idx < NC_NODES * (NTs >> 2); idx += 256) {
-      const int nl = idx / (NTs >> 2), q = idx - nl * (NTs >> 2);
-      const int node = node0 + nl;
-      if (node >= gcount || (dbg & 2048)) continue;
-      const int col = q << 2, st = col >> 6, c = col & 63;
-      *reinterpret_cast<float4*>(Y + (((size_t)node * n_super + st) * HKp + k) * 64 + c) =
-          *reinterpret_cast<const float4*>(obuf + nl * OS + col);
+    // stream the 16 finished rows out: thread q owns one float4 column group, 256-B runs per (node, super-tile)
+    if (!(dbg & 2048)) {
+      for (int q = tid; q < NQ; q += 256) {
+        const int col = q << 2, st = col >> 6, c = col & 63;
+        float* __restrict__ yq = Y + (((size_t)node0 * n_super + st) * HKp + k) * 64 + c;
+        const size_t node_stride = (size_t)n_super * HKp * 64;
+#pragma unroll 4
+        for (int nl = 0; nl < NC_NODES; ++nl)
+          if (node0 + nl < gcount)
+            *reinterpret_cast<float4*>(yq + nl * node_stride) = *reinterpret_cast<const float4*>(obuf + nl * OS + col);
+      }
     }
     __syncthreads();
   }
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
 void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcItem* items, int n_items,
                           int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s) {
   if (gcount <= 0 || n_items <= 0) return;
-  const size_t smem = (size_t)(((NC_NODES * NC_XS + 3) & ~3) + NC_NODES * (NTs + 4)) * sizeof(float);
+  const size_t smem = (size_t)(((NC_NODES * NC_XS + 3) & ~3) + NC_NODES * (NTs + 4)) * sizeof(float) + n_items * sizeof(NcItem);
   dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, NC_KC));
   hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, items, n_items, KS, HK, HKp, NTs, Y,
                      ablate_mask());
@@ -133,7 +149,7 @@ __device__ __forceinline__ void edge_sh(const float* n, float sgn, int lmax, flo
 constexpr int EC_E = 32;   // edges per pass
 
 template <int MAXD>
-__global__ __launch_bounds__(768) void k_edge_conv(EdgeConvArgs a) {
+__global__ __launch_bounds__(576, 5) void k_edge_conv(EdgeConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
   const int HS = a.HKp + 1;                          // odd row stride: conflict-free A-fragment reads
   const int GS = a.GN | 1, MS = a.D_out | 1;
@@ -311,7 +327,7 @@ void launch_edge_conv(const EdgeConvArgs& a_in, hipStream_t s) {
   const int HS = a.HKp + 1, GS = a.GN | 1, MS = a.D_out | 1;
   const size_t smem = (size_t)(EC_E * (HS + GS + MS) + 13 * EC_E) * sizeof(float);
   const int n_super = a.NTs >> 6;
-  const int waves = n_super < 12 ? n_super : 12;
+  const int waves = n_super < 9 ? n_super : 9;   // 2 workgroups of <= 9 waves per CU (launch bounds: <= 102 VGPRs)
   if (a.H % 4 != 0) throw Error(DDMI_ERR_ARG, "3*ns must be a multiple of 4");
   if (a.maxd <= 3) hipLaunchKernelGGL(k_edge_conv<3>, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
   else hipLaunchKernelGGL(k_edge_conv<5>, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
