@@ -14,7 +14,7 @@ namespace ddmi {
 struct Model::Cx {
   int B = 0, nL = 0, nR = 0, N = 0, Eb = 0, Err = 0, nT = 0;
   int maxNl = 0, maxNr = 0, Ell_cap = 0, Elr_cap = 0, tor_cap = 32, Et = 0, lig_cap = 33;
-  int y_chunk = 0, esplit_lig = 1;   // tuning knobs (env DDMI_Y_CHUNK / DDMI_ESPLIT)
+  int y_chunk = 0, esplit_lig = 0;   // tuning knobs (env DDMI_Y_CHUNK / DDMI_ESPLIT); 0 = automatic
   bool uniform = false; int Nl_one = 0, R_one = 0;
   std::vector<int> lig_ptr_h, rec_ptr_h;
   // static
@@ -315,7 +315,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   for (auto& L : m.lig_emb_layers) upd(L);
   for (auto& L : m.rec_emb_layers) upd(L);
   if (const char* e = getenv("DDMI_Y_CHUNK")) c.y_chunk = atoi(e);
-  if (const char* e = getenv("DDMI_ESPLIT")) c.esplit_lig = std::max(1, atoi(e));
+  if (const char* e = getenv("DDMI_ESPLIT")) c.esplit_lig = std::max(0, atoi(e));
   const int y_nodes = c.y_chunk > 0 ? std::min(c.y_chunk, std::max(nL, nR)) : std::max(nL, nR);
   c.Y = dalloc<float>(m, nullptr, {y_nodes, HKp, NTs}, true);
   const int ecap[4] = {c.Ell_cap, c.Elr_cap, c.Err, c.Elr_cap};
@@ -462,7 +462,8 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
                       c.rr_batch, c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
   RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                 nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
-  g_rl.esplit = c.esplit_lig;   // ligand gather nodes carry up to Nr edges each: split their passes over workgroups
+  // ligand gather nodes carry up to Nr edges each: their 32-edge passes are dealt over several workgroups
+  g_rl.esplit = c.esplit_lig > 0 ? c.esplit_lig : std::max(1, std::min(8, (c.Elr_cap / std::max(nL, 1) + 63) / 64));
   const int Lc = (int)m.conv_layers.size();
   t_phase.reset();
   for (int l = 0; l < Lc; ++l, ++xi) {

@@ -149,7 +149,7 @@ __device__ __forceinline__ void edge_sh(const float* n, float sgn, int lmax, flo
 constexpr int EC_E = 32;   // edges per pass
 
 template <int MAXD>
-__global__ __launch_bounds__(576, 5) void k_edge_conv(EdgeConvArgs a) {
+__global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
   const int HS = a.HKp + 1;                          // odd row stride: conflict-free A-fragment reads
   const int GS = a.GN | 1, MS = a.D_out | 1;
@@ -327,7 +327,7 @@ void launch_edge_conv(const EdgeConvArgs& a_in, hipStream_t s) {
   const int HS = a.HKp + 1, GS = a.GN | 1, MS = a.D_out | 1;
   const size_t smem = (size_t)(EC_E * (HS + GS + MS) + 13 * EC_E) * sizeof(float);
   const int n_super = a.NTs >> 6;
-  const int waves = n_super < 9 ? n_super : 9;   // 2 workgroups of <= 9 waves per CU (launch bounds: <= 102 VGPRs)
+  const int waves = n_super < 4 ? n_super : 4;   // 3 workgroups of 4 waves per CU: their phases interleave
   if (a.H % 4 != 0) throw Error(DDMI_ERR_ARG, "3*ns must be a multiple of 4");
   if (a.maxd <= 3) hipLaunchKernelGGL(k_edge_conv<3>, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
   else hipLaunchKernelGGL(k_edge_conv<5>, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
