@@ -19,7 +19,7 @@ edge count in `config`.
 
 Extra objects on the JSON line: `roofline` (dominant kernel, HIP-event timed inside the timed region) and
 `cpu_baseline` (the oracle = pure-torch restatement of the reference, timed on this host's cores on a
-bounded sample: 1 pose x 1 of the 20 steps of the same complex, extrapolated).
+bounded sample: 2 poses x the first 3 of the 20 steps of the same complex, extrapolated linearly).
 """
 import argparse
 import json
@@ -85,7 +85,7 @@ def cpu_baseline(cfg, sd, so3_t, tor_t, g):
     from oracle.sampling import sampling as oracle_sampling
     threads = min(os.cpu_count(), 64)     # the oracle's small einsums do not scale past a few dozen threads
     torch.set_num_threads(threads)
-    n_s, n_steps = 1, 1
+    n_s, n_steps = 2, 3
     dl = make_pose_list(g, n_s, tr_sigma_max=cfg.tr_sigma_max, seed=77, initial_noise_std_proportion=0.3)
     model = CGModelOracle(cfg, sd, so3_t, tor_t)
     R = int(dl[0]["ligand"].edge_mask.sum())
