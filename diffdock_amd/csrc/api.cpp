@@ -106,6 +106,12 @@ int ddmi_forward(ddmi_model* h, const float* lig_pos, const float* t_tr, const f
   });
 }
 
+int ddmi_set_crop_cutoff(ddmi_model* h, float cutoff) {
+  if (!h) return DDMI_ERR_ARG;
+  h->m.crop_cutoff = cutoff > 0.f ? cutoff : 0.f;
+  return DDMI_OK;
+}
+
 int ddmi_modify_conformer(ddmi_model* h, float* lig_pos, const float* tr, const float* rot, const float* tor, ddmi_stream s) {
   return guard([&] {
     DDMI_REQUIRE(h && lig_pos && tr && rot, DDMI_ERR_ARG, "null argument");

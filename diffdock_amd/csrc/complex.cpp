@@ -22,7 +22,11 @@ struct Model::Cx {
   int *bond_src, *bond_dst, *bond_grank, *bond_trank, *bg, *bt; float* bond_attr;
   int *tor_u, *tor_v, *tor_batch, *tor_eu, *tor_ev, *rot_u, *rot_v; unsigned char* mask_rotate = nullptr;
   float* rec_pos; int *rr_src, *rr_dst, *rr_batch; float *rr_dist, *rr_nvec, *rr_ew, *rec_edge_base;
-  int *rr_goff, *rr_tgt, *rr_tslot, *rr_arow, *rr_toff;
+  int *rr_goff, *rr_tgt, *rr_tslot, *rr_arow, *rr_toff, *rr_tlist, *rr_gnode;
+  // per-step cropped receptor graph
+  int *keep, *cnt_g2, *cnt_t2, *goff2, *toff2, *tslot_tmp, *tgt2, *tslot2, *arow2;
+  ReduceGroup *rg_all_crop, *rg_rr_crop;
+  float* rec_node_enc;   // receptor encoder output before the embedding layers
   float* rec_node_base; int rec_base_dim = 0;
   // per forward
   float *temb, *hidB, *rec_sig, *ligsig, *ll_gvec, *cross_gvec, *center_gvec, *tr_sig, *rot_sig, *cutoff, *rr_rowbias;
@@ -245,10 +249,13 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   for (int i = 0; i < c.nR; ++i) { goff[i + 1] += goff[i]; toff[i + 1] += toff[i]; }
   std::vector<int> rr_arow(c.Err), rr_tgt(c.Err), rr_tslot(c.Err), cur(goff.begin(), goff.end() - 1), tcur(toff.begin(), toff.end() - 1);
   for (int k = 0; k < c.Err; ++k) rr_arow[cur[rr_dst[k]]++] = k;
+  std::vector<int> rr_tlist(c.Err), rr_gnode(c.Err);
   for (int e = 0; e < c.Err; ++e) {
     const int k = rr_arow[e];
     rr_tgt[e] = c.nL + rr_src[k];
     rr_tslot[e] = tcur[rr_src[k]]++;
+    rr_tlist[rr_tslot[e]] = e;
+    rr_gnode[e] = rr_dst[k];
   }
   // ---- uploads
   c.lig_batch = dup(m, "lig_batch", lig_batch); c.rec_batch = dup(m, "rec_batch", rec_batch);
@@ -275,6 +282,11 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.rr_src = dup(m, nullptr, rr_src); c.rr_dst = dup(m, nullptr, rr_dst); c.rr_batch = dup(m, nullptr, rr_batch);
   c.rr_goff = dup(m, "rr_goff", goff); c.rr_toff = dup(m, "rr_toff", toff); c.rr_arow = dup(m, nullptr, rr_arow);
   c.rr_tgt = dup(m, nullptr, rr_tgt); c.rr_tslot = dup(m, nullptr, rr_tslot);
+  c.rr_tlist = dup(m, nullptr, rr_tlist); c.rr_gnode = dup(m, nullptr, rr_gnode);
+  c.keep = dalloc<int>(m, "crop_keep", {c.nR}); c.cnt_g2 = dalloc<int>(m, nullptr, {c.nR}); c.cnt_t2 = dalloc<int>(m, nullptr, {c.nR});
+  c.goff2 = dalloc<int>(m, "rr_goff_crop", {c.nR + 1}); c.toff2 = dalloc<int>(m, nullptr, {c.nR + 1});
+  c.tslot_tmp = dalloc<int>(m, nullptr, {c.Err}); c.tgt2 = dalloc<int>(m, nullptr, {c.Err});
+  c.tslot2 = dalloc<int>(m, nullptr, {c.Err}); c.arow2 = dalloc<int>(m, nullptr, {c.Err});
   // ---- workspace
   const int B = c.B, nL = c.nL, nR = c.nR, N = c.N;
   c.rr_dist = dalloc<float>(m, nullptr, {c.Err}); c.rr_nvec = dalloc<float>(m, nullptr, {c.Err, 3});
@@ -330,6 +342,11 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     c.rg_ll = m.cpool.upload(r0);
     std::vector<ReduceGroup> r2 = {{c.rr_toff, c.msg[2], 0, nR}};  // receptor-only embedding layers index nodes from 0
     c.rg_rr = m.cpool.upload(r2);
+    std::vector<ReduceGroup> rc = rg;
+    rc[2].toff = c.toff2;
+    c.rg_all_crop = m.cpool.upload(rc);
+    std::vector<ReduceGroup> r2c = {{c.toff2, c.msg[2], nL, nR}};  // cropped embedding layers run in the full node table
+    c.rg_rr_crop = m.cpool.upload(r2c);
   }
   const ConvW& F = m.final_conv;
   c.c_dist = dalloc<float>(m, nullptr, {nL}); c.c_nvec = dalloc<float>(m, nullptr, {nL, 3});
@@ -371,7 +388,10 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     launch_add_rowvec(c.rec_node_base, XS, cat, ns, nullptr, 0, nullptr, nR, ns, 0, s);
   }
   c.rec_base_dim = ns;
+  c.rec_node_enc = nullptr;
   if (!m.rec_emb_layers.empty()) {
+    c.rec_node_enc = dalloc<float>(m, nullptr, {nR, XS}, true);
+    DDMI_CHECK_HIP(hipMemcpyAsync(c.rec_node_enc, c.rec_node_base, (size_t)nR * XS * 4, hipMemcpyDeviceToDevice, s));
     // rec_emb_layers run on the sigma-free receptor graph (cg_model.py:288-290), node ids local to the receptor
     std::vector<int> tgt_local(c.Err);
     for (int e = 0; e < c.Err; ++e) tgt_local[e] = rr_tgt[e] - c.nL;
@@ -438,8 +458,29 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   int xi = 0;
   for (size_t i = 0; i < m.lig_emb_layers.size(); ++i, ++xi)
     run_conv(m, m.lig_emb_layers[i], {g_ll}, c.rg_ll, 1, c.X[xi], c.X[xi + 1], 0, nL, s);
+  // ---- per-step receptor crop (utils/sampling.py:104-109): residue mask + re-compacted contact graph
+  const bool crop = m.crop_cutoff > 0.0;
+  const int* keep = nullptr;
+  if (crop) {
+    const double cd = m.crop_cutoff;
+    launch_crop_mask(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, nR, (float)(cd * cd), c.keep, s);
+    launch_rr_filter(c.keep, c.rr_goff, c.rr_tgt, c.rr_arow, c.rr_toff, c.rr_tlist, c.rr_gnode, nL, nR, c.cnt_g2, c.cnt_t2,
+                     c.goff2, c.toff2, c.tslot_tmp, c.tgt2, c.tslot2, c.arow2, s);
+    keep = c.keep;
+  }
   // receptor rows of the current table: cached embedding + sigma term on the scalars (cg_model.py:298-301)
-  launch_add_rowvec(c.X[xi] + (size_t)nL * XS, XS, c.rec_node_base, XS, c.rec_sig, ns, c.rec_batch, nR, c.rec_base_dim, ns, s);
+  if (crop && !m.rec_emb_layers.empty()) {
+    // the reference re-embeds the CROPPED receptor every step (the cache lives on the discarded deep copy)
+    launch_add_rowvec(c.X[0] + (size_t)nL * XS, XS, c.rec_node_enc, XS, nullptr, 0, nullptr, nR, ns, 0, s);
+    const RunGroup g_rr0{nL, nR, nL, nR, c.goff2, c.tgt2, c.tslot2, c.arow2, c.rec_edge_base, c.Err, nullptr, nullptr,
+                         nullptr, c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
+    for (size_t i = 0; i < m.rec_emb_layers.size(); ++i)
+      run_conv(m, m.rec_emb_layers[i], {g_rr0}, c.rg_rr_crop, 1, c.X[i], c.X[i + 1], nL, nR, s);
+    launch_add_rowvec(c.X[xi] + (size_t)nL * XS, XS, c.X[xi] + (size_t)nL * XS, XS, c.rec_sig, ns, c.rec_batch, nR,
+                      c.rec_base_dim, ns, s);
+  } else {
+    launch_add_rowvec(c.X[xi] + (size_t)nL * XS, XS, c.rec_node_base, XS, c.rec_sig, ns, c.rec_batch, nR, c.rec_base_dim, ns, s);
+  }
   // ---- cross graph
   const float* cut_dev = nullptr;
   if (cfg.dynamic_max_cross) {  // cutoff_b = 3 * tr_sigma_b + 20 (cg_model.py:321-322)
@@ -447,7 +488,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     cut_dev = c.cutoff;
   }
   launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
-                     cfg.cross_max_distance, c.pairrank, c.cnt_l, c.cnt_r, s);
+                     cfg.cross_max_distance, keep, c.pairrank, c.cnt_l, c.cnt_r, s);
   launch_exclusive_scan(c.cnt_l, c.offs_l, nL, s);
   launch_exclusive_scan(c.cnt_r, c.offs_r, nR, s);
   launch_cross_fill(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, c.pairrank, c.offs_l, c.offs_r,
@@ -458,8 +499,9 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   // ---- interaction layers over [ll ; lig<-rec ; rec-rec ; rec<-lig]  (cg_model.py:329-349)
   const RunGroup g_lr{nL, nR, 0, nL, c.offs_r, c.g1_tgt, c.g1_tslot, c.g1_tslot, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                       nullptr, c.pnvec, c.pew, 1.f, c.msg[1]};
-  const RunGroup g_rr{nL, nR, nL, nR, c.rr_goff, c.rr_tgt, c.rr_tslot, c.rr_arow, c.rec_edge_base, c.Err, nullptr, c.rec_sig,
-                      c.rr_batch, c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
+  const RunGroup g_rr{nL, nR, nL, nR, crop ? c.goff2 : c.rr_goff, crop ? c.tgt2 : c.rr_tgt, crop ? c.tslot2 : c.rr_tslot,
+                      crop ? c.arow2 : c.rr_arow, c.rec_edge_base, c.Err, nullptr, c.rec_sig, c.rr_batch, c.rr_nvec, c.rr_ew,
+                      1.f, c.msg[2]};
   RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                 nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
   // ligand gather nodes carry up to Nr edges each: their 32-edge passes are dealt over several workgroups
@@ -467,7 +509,8 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   const int Lc = (int)m.conv_layers.size();
   t_phase.reset();
   for (int l = 0; l < Lc; ++l, ++xi) {
-    if (l < Lc - 1) run_conv(m, m.conv_layers[l], {g_ll, g_lr, g_rr, g_rl}, c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s);
+    if (l < Lc - 1)
+      run_conv(m, m.conv_layers[l], {g_ll, g_lr, g_rr, g_rl}, crop ? c.rg_all_crop : c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s);
     else run_conv(m, m.conv_layers[l], {g_ll, g_lr}, c.rg_lig, 2, c.X[xi], c.X[xi + 1], 0, nL, s);
   }
   const float* XL = c.X[xi];
@@ -535,6 +578,7 @@ void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) 
   const ddmi_config& cfg = m.cfg;
   const int steps = sc.inference_steps, B = c.B;
   const bool torsion = !cfg.no_torsion && c.nT > 0;
+  const double saved_crop = m.crop_cutoff;
   // per-step time values for all graphs, uploaded once
   std::vector<float> tvals((size_t)steps * 3 * B);
   for (int k = 0; k < steps; ++k)
@@ -563,6 +607,7 @@ void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) 
     const double s_rot = std::pow((double)cfg.rot_sigma_min, 1 - t_rot) * std::pow((double)cfg.rot_sigma_max, t_rot);
     const double s_tor = std::pow((double)cfg.tor_sigma_min, 1 - t_tor) * std::pow((double)cfg.tor_sigma_max, t_tor);
     const float* tk = t_dev + (size_t)k * 3 * B;
+    m.crop_cutoff = sc.use_crop ? s_tr * 3.0 + sc.crop_beyond : 0.0;   // sampling.py:107
     forward(m, lig_pos, tk, tk + B, tk + 2 * B, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
     const bool zero_noise = sc.no_random || (sc.no_final_step_noise && last) || sc.ode;
     auto coeffs = [&](double sigma, double smin, double smax, double dt, int i, float& cs, float& cz) {
@@ -594,6 +639,7 @@ void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) 
     launch_perturb(p, s);
     modify_conformer(m, lig_pos, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
   }
+  m.crop_cutoff = saved_crop;
 }
 
 }  // namespace ddmi

@@ -168,30 +168,32 @@ __device__ __forceinline__ bool cross_in_range(const float* lp, const float* rp,
 __global__ void k_cross_count(const float* __restrict__ lpos, const float* __restrict__ rpos,
                               const int* __restrict__ lbatch, const int* __restrict__ rbatch,
                               const int* __restrict__ lptr, const int* __restrict__ rptr, int nL, int nR, int maxNr,
-                              const float* __restrict__ cutoff, float const_cutoff, int* __restrict__ pairrank,
-                              int* __restrict__ cnt_l, int* __restrict__ cnt_r) {
+                              const float* __restrict__ cutoff, float const_cutoff, const int* __restrict__ keep,
+                              int* __restrict__ pairrank, int* __restrict__ cnt_l, int* __restrict__ cnt_r) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < nL) {
     const int i = t, b = lbatch[i], lo = rptr[b], hi = rptr[b + 1];
     const float cut = cutoff ? cutoff[b] : const_cutoff;
     int c = 0;
     int* row = pairrank + (size_t)i * maxNr;
-    for (int j = lo; j < hi; ++j) row[j - lo] = cross_in_range(lpos + 3 * i, rpos + 3 * j, cut, cutoff != nullptr) ? c++ : -1;
+    for (int j = lo; j < hi; ++j)
+      row[j - lo] = ((!keep || keep[j]) && cross_in_range(lpos + 3 * i, rpos + 3 * j, cut, cutoff != nullptr)) ? c++ : -1;
     cnt_l[i] = c;
   } else if (t < nL + nR) {
     const int j = t - nL, b = rbatch[j], lo = lptr[b], hi = lptr[b + 1];
     const float cut = cutoff ? cutoff[b] : const_cutoff;
     int c = 0;
-    for (int i = lo; i < hi; ++i) c += cross_in_range(lpos + 3 * i, rpos + 3 * j, cut, cutoff != nullptr);
+    if (!keep || keep[j])
+      for (int i = lo; i < hi; ++i) c += cross_in_range(lpos + 3 * i, rpos + 3 * j, cut, cutoff != nullptr);
     cnt_r[j] = c;
   }
 }
 void launch_cross_count(const float* lpos, const float* rpos, const int* lbatch, const int* rbatch, const int* lptr,
                         const int* rptr, int nL, int nR, int maxNr, const float* cutoff, float const_cutoff,
-                        int* pairrank, int* cnt_l, int* cnt_r, hipStream_t s) {
+                        const int* keep, int* pairrank, int* cnt_l, int* cnt_r, hipStream_t s) {
   if (nL + nR <= 0) return;
   hipLaunchKernelGGL(k_cross_count, dim3(cdiv(nL + nR, 64)), dim3(64), 0, s, lpos, rpos, lbatch, rbatch, lptr, rptr, nL,
-                     nR, maxNr, cutoff, const_cutoff, pairrank, cnt_l, cnt_r);
+                     nR, maxNr, cutoff, const_cutoff, keep, pairrank, cnt_l, cnt_r);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -243,6 +245,77 @@ __global__ void k_cross_cutoff(const float* __restrict__ t_tr, int B, float smin
 }
 void launch_cross_cutoff(const float* t_tr, int B, float smin, float smax, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_cross_cutoff, dim3(cdiv(B, 64)), dim3(64), 0, s, t_tr, B, smin, smax, out);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
+// -------------------------------------------------- per-step receptor cropping (crop_beyond)
+// utils/utils.py:388-413 via utils/sampling.py:104-109: a residue survives iff it lies within `cutoff` of ANY
+// ligand atom of its graph; contact edges survive iff both ends do.  The reference rebuilds the PyG batch on
+// the host every step (deepcopy -> to_data_list -> crop -> from_data_list); here it is a mask over the static
+// receptor plus a re-compaction of the static contact-graph CSRs (dropped residues simply keep no edges).
+__global__ void k_crop_mask(const float* __restrict__ lpos, const float* __restrict__ rpos, const int* __restrict__ rbatch,
+                            const int* __restrict__ lptr, int nR, float cut2, int* __restrict__ keep) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nR) return;
+  const int b = rbatch[j];
+  int k = 0;
+  for (int i = lptr[b]; i < lptr[b + 1] && !k; ++i)
+    k = dist2_rn(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2], rpos[3 * j], rpos[3 * j + 1], rpos[3 * j + 2]) < cut2;
+  keep[j] = k;
+}
+void launch_crop_mask(const float* lpos, const float* rpos, const int* rbatch, const int* lptr, int nR, float cut2, int* keep,
+                      hipStream_t s) {
+  if (nR <= 0) return;
+  hipLaunchKernelGGL(k_crop_mask, dim3(cdiv(nR, 64)), dim3(64), 0, s, lpos, rpos, rbatch, lptr, nR, cut2, keep);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
+// static CSRs: gather order (goff, src = tgt - nL, dst = the gather node) and target order (toff, tlist = gather-order id)
+__global__ void k_rr_filter_count(const int* __restrict__ keep, const int* __restrict__ goff, const int* __restrict__ tgt,
+                                  const int* __restrict__ toff, const int* __restrict__ tlist,
+                                  const int* __restrict__ gnode, int nL, int nR, int* __restrict__ cnt_g,
+                                  int* __restrict__ cnt_t) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nR) return;
+  int cg = 0, ct = 0;
+  if (keep[n]) {
+    for (int e = goff[n]; e < goff[n + 1]; ++e) cg += keep[tgt[e] - nL];              // gather node n, target tgt[e]
+    for (int ts = toff[n]; ts < toff[n + 1]; ++ts) ct += keep[gnode[tlist[ts]]];      // target node n, gather gnode[e]
+  }
+  cnt_g[n] = cg;
+  cnt_t[n] = ct;
+}
+__global__ void k_rr_filter_tslot(const int* __restrict__ keep, const int* __restrict__ toff, const int* __restrict__ tlist,
+                                  const int* __restrict__ gnode, const int* __restrict__ toff2, int nR,
+                                  int* __restrict__ tslot_tmp) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nR || !keep[n]) return;
+  int r = toff2[n];
+  for (int ts = toff[n]; ts < toff[n + 1]; ++ts) {
+    const int e = tlist[ts];
+    if (keep[gnode[e]]) tslot_tmp[e] = r++;
+  }
+}
+__global__ void k_rr_filter_fill(const int* __restrict__ keep, const int* __restrict__ goff, const int* __restrict__ tgt,
+                                 const int* __restrict__ arow, const int* __restrict__ tslot_tmp,
+                                 const int* __restrict__ goff2, int nL, int nR, int* __restrict__ tgt2,
+                                 int* __restrict__ tslot2, int* __restrict__ arow2) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nR || !keep[n]) return;
+  int q = goff2[n];
+  for (int e = goff[n]; e < goff[n + 1]; ++e)
+    if (keep[tgt[e] - nL]) { tgt2[q] = tgt[e]; tslot2[q] = tslot_tmp[e]; arow2[q] = arow[e]; ++q; }
+}
+void launch_rr_filter(const int* keep, const int* goff, const int* tgt, const int* arow, const int* toff, const int* tlist,
+                      const int* gnode, int nL, int nR, int* cnt_g, int* cnt_t, int* goff2, int* toff2, int* tslot_tmp,
+                      int* tgt2, int* tslot2, int* arow2, hipStream_t s) {
+  if (nR <= 0) return;
+  const dim3 grid(cdiv(nR, 64)), block(64);
+  hipLaunchKernelGGL(k_rr_filter_count, grid, block, 0, s, keep, goff, tgt, toff, tlist, gnode, nL, nR, cnt_g, cnt_t);
+  launch_exclusive_scan(cnt_g, goff2, nR, s);
+  launch_exclusive_scan(cnt_t, toff2, nR, s);
+  hipLaunchKernelGGL(k_rr_filter_tslot, grid, block, 0, s, keep, toff, tlist, gnode, toff2, nR, tslot_tmp);
+  hipLaunchKernelGGL(k_rr_filter_fill, grid, block, 0, s, keep, goff, tgt, arow, tslot_tmp, goff2, nL, nR, tgt2, tslot2, arow2);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

@@ -81,7 +81,12 @@ void launch_ll_fill(const float* pos, const int* batch, const int* ptr, int nL, 
                     int* tgt, int* tslot, int* featidx, int* ebatch, float* dist, float* nvec, float* ew, hipStream_t s);
 void launch_cross_count(const float* lpos, const float* rpos, const int* lbatch, const int* rbatch, const int* lptr,
                         const int* rptr, int nL, int nR, int maxNr, const float* cutoff, float const_cutoff,
-                        int* pairrank, int* cnt_l, int* cnt_r, hipStream_t s);
+                        const int* keep, int* pairrank, int* cnt_l, int* cnt_r, hipStream_t s);
+void launch_crop_mask(const float* lpos, const float* rpos, const int* rbatch, const int* lptr, int nR, float cut2, int* keep,
+                      hipStream_t s);
+void launch_rr_filter(const int* keep, const int* goff, const int* tgt, const int* arow, const int* toff, const int* tlist,
+                      const int* gnode, int nL, int nR, int* cnt_g, int* cnt_t, int* goff2, int* toff2, int* tslot_tmp,
+                      int* tgt2, int* tslot2, int* arow2, hipStream_t s);
 void launch_cross_fill(const float* lpos, const float* rpos, const int* rbatch, const int* lptr, const int* rptr, int nL,
                        int nR, int maxNr, const int* pairrank, const int* offs_l, const int* offs_r, const float* cutoff,
                        float const_cutoff, int smooth, int* g1_tgt, int* g1_tslot, int* g3_tgt, int* g3_tslot,

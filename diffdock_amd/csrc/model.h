@@ -78,6 +78,7 @@ struct Model {
   float *so3_table = nullptr, *torus_table = nullptr; int so3_n = 0, torus_n = 0;
   // ---- complex + workspace
   bool has_complex = false;
+  double crop_cutoff = 0.0;  // > 0: receptor cropped to this distance from the ligand in ddmi_forward (crop_beyond)
   DevicePool cpool;
   struct Cx;  // defined in complex.cpp
   std::shared_ptr<Cx> cx;

@@ -44,7 +44,8 @@ class SampleCfg(C.Structure):
                 ("tor_schedule", C.c_void_p), ("ode", C.c_int32), ("no_random", C.c_int32),
                 ("no_final_step_noise", C.c_int32), ("temp_sampling", C.c_double * 3), ("temp_psi", C.c_double * 3),
                 ("temp_sigma_data", C.c_double * 3), ("seed", C.c_uint64), ("sample_ids", C.c_void_p),
-                ("z_tr", C.c_void_p), ("z_rot", C.c_void_p), ("z_tor", C.c_void_p)]
+                ("z_tr", C.c_void_p), ("z_rot", C.c_void_p), ("z_tor", C.c_void_p),
+                ("use_crop", C.c_int32), ("crop_beyond", C.c_double)]
 
 
 def make_config(cfg) -> Config:
@@ -69,6 +70,7 @@ _DECLS = {
     "ddmi_set_time_frequencies": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "ddmi_set_complex": (C.c_int, [C.c_void_p, C.POINTER(Complex), C.c_void_p]),
     "ddmi_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
+    "ddmi_set_crop_cutoff": (C.c_int, [C.c_void_p, C.c_float]),
     "ddmi_modify_conformer": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "ddmi_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SampleCfg), C.c_void_p]),
     "ddmi_debug_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

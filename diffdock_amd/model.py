@@ -172,6 +172,10 @@ class MIScoreModel:
 
     forward = __call__
 
+    def set_crop_cutoff(self, cutoff):
+        """crop_beyond(graph, cutoff) for the following model(batch) calls (utils/utils.py:388-413); None / 0 = off."""
+        _lib.check(self.lib, self.lib.ddmi_set_crop_cutoff(self._h, float(cutoff or 0.0)))
+
     def modify_conformer_batch(self, pos, data, tr_update, rot_update, torsion_updates, mask_rotate=None):
         """utils/diffusion_utils.py:60-78 on the device (same argument order; mask_rotate comes from the batch)."""
         self._ensure_complex(data)
@@ -184,7 +188,8 @@ class MIScoreModel:
         return out
 
     def sample_batch(self, data, inference_steps, schedules, noise=None, seed=0, sample_ids=None, ode=False,
-                     no_random=False, no_final_step_noise=False, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5):
+                     no_random=False, no_final_step_noise=False, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5,
+                     crop_beyond=None):
         """The whole step loop of sampling() (utils/sampling.py:96-191) for one collated batch, on the device."""
         self._ensure_complex(data)
         dev = self.device
@@ -200,6 +205,7 @@ class MIScoreModel:
             for i, x in enumerate(three(v)):
                 arr[i] = float(x)
         sc.seed = int(seed)
+        sc.use_crop, sc.crop_beyond = (0, 0.0) if crop_beyond is None else (1, float(crop_beyond))
         ids = None
         if sample_ids is not None:
             ids = np.ascontiguousarray(np.asarray(sample_ids, dtype=np.int64))

@@ -6,8 +6,9 @@
 Differences, all documented: the Gaussian draws come from a counter-based generator keyed by
 (seed, global sample index, step, component) instead of the global torch RNG (so that a run sharded over GPUs
 reproduces the single-GPU trajectories), or are injected through `noise=`; the confidence model
-(sampling.py:208-227), visualisation hooks and per-step `crop_beyond` (sampling.py:104-109) are not on the built
-path yet and raise NotImplementedError when requested.
+(sampling.py:208-227) and visualisation hooks are not on the built path yet and raise
+NotImplementedError when requested.  Per-step `crop_beyond` (sampling.py:104-109) runs on the device as a residue
+mask + contact-graph re-compaction instead of the reference's deepcopy / to_data_list / from_data_list round trip.
 """
 from __future__ import annotations
 
@@ -62,8 +63,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
              temp_sigma_data=0.5, return_features=False, seed=0, noise=None, sample_id_offset=0, native_loop=True):
     if confidence_model is not None or visualization_list is not None or return_full_trajectory or return_features or pivot:
         raise NotImplementedError("confidence model / visualisation / trajectories are outside the built path (SURVEY.md 8f)")
-    if model_args is not None and getattr(model_args, "crop_beyond", None) is not None:
-        raise NotImplementedError("per-step crop_beyond is a 'next' row (SURVEY.md 8f.1); use crop_beyond=None")
+    crop = getattr(model_args, "crop_beyond", None) if model_args is not None else getattr(model.cfg, "crop_beyond", None)
     N = len(data_list)
     schedules = (np.asarray(tr_schedule, dtype=np.float64), np.asarray(rot_schedule, dtype=np.float64),
                  np.asarray(tor_schedule, dtype=np.float64))
@@ -83,13 +83,17 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             if native_loop and hasattr(model, "sample_batch"):
                 pos = model.sample_batch(batch, inference_steps, schedules, noise=z, seed=seed, sample_ids=ids, ode=ode,
                                          no_random=no_random, no_final_step_noise=no_final_step_noise,
-                                         temp_sampling=temp_sampling, temp_psi=temp_psi, temp_sigma_data=temp_sigma_data)
+                                         temp_sampling=temp_sampling, temp_psi=temp_psi, temp_sigma_data=temp_sigma_data,
+                                         crop_beyond=crop)
             else:   # step-wise: model(batch) per step, exactly the reference's loop structure
                 assert z is not None or no_random, "the step-wise loop needs injected noise (or no_random)"
                 pos = batch["ligand"].pos
                 for t_idx in range(inference_steps):
                     set_time(batch, schedules[0][t_idx], schedules[1][t_idx], schedules[2][t_idx], b, device=pos.device)
                     batch["ligand"].pos = pos
+                    if crop is not None:     # sampling.py:104-109: crop at 3*tr_sigma + crop_beyond, applied on the device
+                        t = float(schedules[0][t_idx])
+                        model.set_crop_cutoff(cfg.tr_sigma_min ** (1 - t) * cfg.tr_sigma_max ** t * 3 + crop)
                     tr, rot, tor = model(batch)[:3]
                     (a_tr, z_tr), (a_rot, z_rot), (a_tor, z_tor) = step_coefficients(
                         cfg, t_idx, inference_steps, schedules, ode, no_random, no_final_step_noise, temp_sampling,
@@ -100,6 +104,8 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                     rotp = np.float32(a_rot) * rot + np.float32(z_rot) * zz[1]
                     torp = (np.float32(a_tor) * tor + np.float32(z_tor) * zz[2]) if tor.numel() else None
                     pos = model.modify_conformer_batch(pos, batch, trp, rotp, torp)
+                if crop is not None:
+                    model.set_crop_cutoff(None)
             pos = pos.reshape(b, n, 3)
             for i in range(b):
                 data_list[lo + i]["ligand"].pos = pos[i]

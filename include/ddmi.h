@@ -90,6 +90,8 @@ typedef struct ddmi_sample_cfg {
   const float* z_tr;         /* device [steps,B,3] or NULL  */
   const float* z_rot;        /* device [steps,B,3] or NULL  */
   const float* z_tor;        /* device [steps,n_tor] or NULL */
+  int32_t use_crop;          /* model_args.crop_beyond is not None (utils/sampling.py:104) */
+  double crop_beyond;        /* per-step receptor crop at 3*tr_sigma + crop_beyond (utils/sampling.py:107) */
 } ddmi_sample_cfg;
 
 /* get_model(args, device, ...) -- utils/utils.py:172.  device = HIP device ordinal. */
@@ -121,6 +123,11 @@ int ddmi_set_complex(ddmi_model* m, const ddmi_complex* c, ddmi_stream stream);
  * lig_pos [n_lig,3]; t_* [B] = batch.complex_t[...]; outputs tr [B,3], rot [B,3], tor [n_tor]. */
 int ddmi_forward(ddmi_model* m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor,
                  float* tr_out, float* rot_out, float* tor_out, ddmi_stream stream);
+
+/* crop_beyond(graph, cutoff) -- utils/utils.py:388-413 as applied by sampling() before each model call
+ * (utils/sampling.py:104-109): subsequent ddmi_forward calls drop the residues farther than `cutoff` from every
+ * ligand atom of their graph, with the contact edges touching them.  cutoff <= 0 switches cropping off. */
+int ddmi_set_crop_cutoff(ddmi_model* m, float cutoff);
 
 /* modify_conformer_batch -- utils/diffusion_utils.py:60-78.  pos [n_lig,3] updated in place;
  * tr_update [B,3], rot_update [B,3], tor_update [n_tor] or NULL. */

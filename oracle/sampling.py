@@ -3,9 +3,11 @@
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Differences from the reference,
 all input-side: (a) the Gaussian draws z_tr / z_rot / z_tor are injected (the reference
 consumes the global torch RNG, sampling.py:140-154), (b) confidence model, visualisation
-and crop_beyond (sampling.py:104-109, a "next" row) are not restated.
+are not restated.  Per-step receptor cropping (sampling.py:104-109 + crop_beyond, utils/utils.py:388-413) is.
 Per-step update formulas: sampling.py:133-186; pose update: oracle/conformer.py.
 """
+import copy
+
 import numpy as np
 import torch
 
@@ -80,6 +82,22 @@ def nan_guard(tr_score, rot_score, tor_score):
     return tr_score, rot_score, tor_score
 
 
+def crop_beyond(graph, cutoff):
+    """utils/utils.py:388-413 (CG model): keep the residues within `cutoff` of ANY ligand atom; receptor contact
+    edges survive iff both ends do (torch_geometric.utils.subgraph with relabel_nodes=True)."""
+    lig, rec = graph["ligand"].pos, graph["receptor"].pos
+    keep = torch.any(torch.sum((lig.unsqueeze(0) - rec.unsqueeze(1)) ** 2, -1) < cutoff ** 2, dim=1)
+    graph["receptor"].pos = rec[keep]
+    graph["receptor"].x = graph["receptor"].x[keep]
+    if "side_chain_vecs" in graph["receptor"]:
+        graph["receptor"].side_chain_vecs = graph["receptor"].side_chain_vecs[keep]
+    ei = graph["receptor", "receptor"].edge_index
+    ok = keep[ei[0]] & keep[ei[1]]
+    remap = torch.cumsum(keep.long(), 0) - 1
+    graph["receptor", "receptor"].edge_index = remap[ei[:, ok]]
+    return graph
+
+
 def rot_edges_of(batch, B):
     M = batch["ligand", "ligand"].num_edges // B
     ei = batch["ligand", "ligand"].edge_index[:, :M]
@@ -108,8 +126,15 @@ def sampling(data_list, model, inference_steps, cfg, noise, schedules=None, batc
             rot_edges = rot_edges_of(batch, b)
             for t_idx in range(inference_steps):
                 t_tr, t_rot, t_tor = (s[t_idx] for s in schedules)
-                set_time(batch, t_tr, t_rot, t_tor, b)
-                tr_score, rot_score, tor_score = model(batch)[:3]
+                mod_batch = batch
+                if getattr(cfg, "crop_beyond", None) is not None:      # sampling.py:104-109
+                    tr_sigma = t_to_sigma(cfg, t_tr, t_rot, t_tor)[0]
+                    graphs = copy.deepcopy(batch).to_data_list()
+                    for g in graphs:
+                        crop_beyond(g, tr_sigma * 3 + cfg.crop_beyond)
+                    mod_batch = HeteroBatch.from_data_list(graphs)
+                set_time(mod_batch, t_tr, t_rot, t_tor, b)
+                tr_score, rot_score, tor_score = model(mod_batch)[:3]
                 tr_score, rot_score, tor_score = nan_guard(tr_score, rot_score, tor_score)
                 zs = (z_tr[t_idx, lo:lo + b], z_rot[t_idx, lo:lo + b],
                       z_tor[t_idx, lo * R:(lo + b) * R] if R > 0 else tor_score)

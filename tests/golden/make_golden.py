@@ -128,6 +128,8 @@ def main():
         "tiny_l2_fixedcenter": dict(cfg=TINY.replace(sh_lmax=2, fixed_center_conv=True, dynamic_max_cross=False,
                                                       cross_max_distance=30.0, reduce_pseudoscalars=True),
                                     n_res=32, n_lig=11, n_samples=2, seed=3, t=0.5),
+        # per-step receptor cropping (utils/sampling.py:104-109): cutoff 3*sigma_tr + 6 A shrinks from 21 A to 7 A
+        "tiny_l2_crop": dict(cfg=TINY.replace(sh_lmax=2, crop_beyond=6.0), n_res=44, n_lig=12, n_samples=3, seed=4, t=0.3),
     }
     for name, c in cases.items():
         print("case", name, flush=True)
@@ -188,8 +190,8 @@ def main():
     g = make_complex(seed=5, n_res=60, n_lig=10)
     d = make_pose_list(g, 1, seed=11)[0]
     dd = copy.deepcopy(d)
-    crop_beyond(dd, 18.0, False)
-    torch.save({"graph": graph_to_dict(d), "cutoff": 18.0, "rec_pos": dd["receptor"].pos,
+    crop_beyond(dd, 9.0, False)
+    torch.save({"graph": graph_to_dict(d), "cutoff": 9.0, "rec_pos": dd["receptor"].pos,
                 "rec_edge_index": dd["receptor", "receptor"].edge_index}, os.path.join(HERE, "crop_beyond.pt"))
 
     # ---- geometry / torsion / FasterTensorProduct unit fixtures straight from the reference

@@ -56,7 +56,7 @@ def test_forward_matches_reference_fixture(name, emu_lib):
     assert int(m.debug_buffer("offs_l")[-1]) == inter["edge_counts"][1] == int(m.debug_buffer("offs_r")[-1])
 
 
-@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2"])
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop"])
 def test_device_loop_matches_reference_trajectory(name, emu_lib):
     fx, cfg, data_list = fixture_case(name)
     m = make_model(cfg, fx["state_dict"], emu_lib)
@@ -65,8 +65,11 @@ def test_device_loop_matches_reference_trajectory(name, emu_lib):
     noise = split_draws(s["draws"], s["steps"], B, R)
     sched = get_t_schedule(s["steps"])
     pos = m.sample_batch(HeteroBatch.from_data_list(data_list), s["steps"], (sched, sched, sched), noise=noise,
-                         no_final_step_noise=True, **s["temp"])
+                         no_final_step_noise=True, crop_beyond=cfg.crop_beyond, **s["temp"])
     assert (pos.reshape(B, -1, 3) - s["final_pos"]).abs().max() < 2e-3   # Angstrom, 4 chaotic fp32 steps
+    if cfg.crop_beyond is not None:   # the last step really cropped: fewer residues kept than present
+        keep = m.debug_buffer("crop_keep")
+        assert 0 < keep.sum() < keep.size
 
 
 def test_modify_conformer_matches_reference(emu_lib):
@@ -126,3 +129,25 @@ def test_errors_are_python_exceptions(emu_lib):
     with pytest.raises(DdmiError):
         m.load_state_dict(bad)                                                  # shape mismatch
     assert set(m.expected_keys()) == set(sd)
+
+
+def test_crop_with_embedding_layers_matches_oracle(emu_lib):
+    """crop_beyond + receptor embedding layers: the reference re-embeds the CROPPED receptor each step."""
+    from oracle.sampling import sampling as oracle_sampling
+    fx, cfg, data_list = fixture_case("tiny_l1_1group_emb")
+    cfg = cfg.replace(crop_beyond=9.0)
+    so3_t, tor_t = tables()
+    B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
+    g = torch.Generator().manual_seed(1)
+    steps = 3
+    noise = (torch.randn(steps, B, 3, generator=g), torch.randn(steps, B, 3, generator=g), torch.randn(steps, B * R, generator=g))
+    ref = oracle_sampling([d.clone() for d in data_list], CGModelOracle(cfg, fx["state_dict"], so3_t, tor_t), steps, cfg, noise,
+                          batch_size=B, no_final_step_noise=True)
+    ref = torch.stack([d["ligand"].pos for d in ref])
+    m = make_model(cfg, fx["state_dict"], emu_lib)
+    sched = get_t_schedule(steps)
+    pos = m.sample_batch(HeteroBatch.from_data_list(data_list), steps, (sched, sched, sched), noise=noise,
+                         no_final_step_noise=True, crop_beyond=cfg.crop_beyond)
+    keep = m.debug_buffer("crop_keep")
+    assert 0 < keep.sum() < keep.size
+    assert (pos.reshape(B, -1, 3) - ref).abs().max() < 2e-3

@@ -18,7 +18,7 @@ from util import fixture_case, graph_from_dict, load_fixture, rel_err, split_dra
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter"]
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop"]
 
 
 def gpu_model(cfg, sd):
@@ -50,7 +50,7 @@ def test_forward_matches_reference_fixture(name):
             assert rel_err(mine[:n, :ref_nodes.shape[1]], ref_nodes[:n]) < REL, l
 
 
-@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2"])
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop"])
 def test_device_loop_matches_reference_trajectory(name):
     fx, cfg, data_list = fixture_case(name)
     m = gpu_model(cfg, fx["state_dict"])
@@ -59,8 +59,11 @@ def test_device_loop_matches_reference_trajectory(name):
     noise = split_draws(s["draws"], s["steps"], B, R)
     sched = get_t_schedule(s["steps"])
     pos = m.sample_batch(to_gpu(HeteroBatch.from_data_list(data_list)), s["steps"], (sched, sched, sched), noise=noise,
-                         no_final_step_noise=True, **s["temp"])
+                         no_final_step_noise=True, crop_beyond=cfg.crop_beyond, **s["temp"])
     assert (pos.cpu().reshape(B, -1, 3) - s["final_pos"]).abs().max() < 2e-3   # Angstrom after 4 chaotic fp32 steps
+    if cfg.crop_beyond is not None:
+        keep = m.debug_buffer("crop_keep")
+        assert 0 < keep.sum() < keep.size
 
 
 def test_modify_conformer_matches_reference():
@@ -150,3 +153,29 @@ def test_sharded_sampling_is_sample_invariant():
         parts.append(m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl[lo:lo + 4])), 5, (sched, sched, sched), seed=123,
                                     sample_ids=list(range(lo, lo + 4)), no_final_step_noise=True).cpu().reshape(4, -1, 3))
     assert (torch.cat(parts) - full).abs().max() < 1e-3
+
+
+def test_ddl_synth_cropped_forward_matches_oracle():
+    """crop_beyond at benchmark scale: one forward of the cropped batch (oracle crops the PyG-style batch on the host,
+    the library masks residues and re-compacts the contact graph on the device)."""
+    import copy
+    from oracle.sampling import crop_beyond
+    cfg = DDL_SYNTH
+    sd = init_state_dict(cfg, seed=1234)
+    g = make_complex(seed=6, n_res=300, n_lig=30)
+    dl = make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=7, initial_noise_std_proportion=0.4)
+    cutoff = 14.0
+    cropped = [crop_beyond(copy.deepcopy(d), cutoff) for d in dl]
+    assert all(0 < c["receptor"].pos.shape[0] < 300 for c in cropped)
+    ob = HeteroBatch.from_data_list(cropped)
+    set_time(ob, 0.2, 0.2, 0.2, 2)
+    so3_t, tor_t = tables()
+    tr, rot, tor, _ = CGModelOracle(cfg, sd, so3_t, tor_t)(ob)
+    m = gpu_model(cfg, sd)
+    batch = HeteroBatch.from_data_list(dl)
+    set_time(batch, 0.2, 0.2, 0.2, 2)
+    m.set_crop_cutoff(cutoff)
+    tr2, rot2, tor2, _ = m(to_gpu(batch))
+    m.set_crop_cutoff(None)
+    assert int(m.debug_buffer("crop_keep").sum()) == sum(c["receptor"].pos.shape[0] for c in cropped)
+    assert rel_err(tr2.cpu(), tr) < REL and rel_err(rot2.cpu(), rot) < REL and rel_err(tor2.cpu(), tor) < REL

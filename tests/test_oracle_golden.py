@@ -13,7 +13,7 @@ from oracle.layers import faster_tensor_product, gaussian_smearing
 from oracle.sampling import sampling
 from util import fixture_case, load_fixture, rel_err, split_draws, tables, graph_from_dict
 
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter"]
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -65,3 +65,15 @@ def test_unit_fixtures():
     assert torch.allclose(oc.sinusoidal_embedding(1000.0 * u["sin_t"], 16), u["sin_emb"], atol=1e-6)
     assert torch.allclose(gaussian_smearing(torch.linspace(0, 5, 16), u["gs_dist"]), u["gs_out"], atol=1e-7)
     assert np.allclose(oc.get_t_schedule(20), u["t_schedule_20"].numpy())
+
+
+def test_crop_beyond_matches_reference():
+    """utils/utils.py:388-413 executed by the reference on one complex (fixture) vs the restated crop."""
+    from oracle.sampling import crop_beyond
+    fx = load_fixture("crop_beyond")
+    g = graph_from_dict(fx["graph"])
+    n_before = g["receptor"].pos.shape[0]
+    crop_beyond(g, fx["cutoff"])
+    assert 0 < g["receptor"].pos.shape[0] < n_before      # the fixture really crops
+    assert torch.equal(g["receptor"].pos, fx["rec_pos"])
+    assert torch.equal(g["receptor", "receptor"].edge_index, fx["rec_edge_index"])

@@ -73,8 +73,22 @@ def test_sampling_signature_native_and_stepwise(emu_lib):
         outs.append(torch.stack([d["ligand"].pos for d in out]))
     assert (outs[0] - s["final_pos"]).abs().max() < 2e-3
     assert (outs[1] - s["final_pos"]).abs().max() < 2e-3
-    with pytest.raises(NotImplementedError):
-        sampling(data_list, m, 1, sched, sched, sched, "cpu", None, cfg.replace(crop_beyond=20.0))
+
+
+def test_sampling_with_crop_beyond_native_and_stepwise(emu_lib):
+    """model_args.crop_beyond (utils/sampling.py:104-109) through both loops against the reference trajectory."""
+    fx, cfg, data_list = fixture_case("tiny_l2_crop")
+    s = fx["sampling"]
+    B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
+    noise = split_draws(s["draws"], s["steps"], B, R)
+    sched = get_t_schedule(s["steps"])
+    for native in (True, False):
+        m = MIScoreModel(cfg, device="cpu", lib_path=emu_lib)
+        m.load_state_dict(fx["state_dict"])
+        m.set_tables(*tables())
+        out, _ = sampling([d.clone() for d in data_list], m, s["steps"], sched, sched, sched, "cpu", None, cfg, batch_size=8,
+                          noise=noise, no_final_step_noise=True, native_loop=native)
+        assert (torch.stack([d["ligand"].pos for d in out]) - s["final_pos"]).abs().max() < 2e-3
 
 
 WORKER = r"""
