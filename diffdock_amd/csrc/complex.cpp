@@ -144,7 +144,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       const int n = std::min(chunk, g.gcount - d0);
       {
         PhaseTimer t(m, "k_node_contract", s);
-        launch_node_contract(Xin, g.gbase + d0, n, L.wpack[wg], L.nc_items, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, c.Y, s);
+        launch_node_contract(Xin, g.gbase + d0, n, L.wpack[wg], L.nc_units, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, c.Y, s);
       }
       a.gcount = n; a.goff = g.goff + d0; a.Q = c.Q + (size_t)d0 * H;
       PhaseTimer t(m, "k_edge_conv", s);

@@ -29,93 +29,93 @@ constexpr int NC_NODES = 16, NC_KC = 15, NC_XS = XS + 1;
 // Ablation mask for profiling (env DDMI_ABLATE, 0 in production): lets bench runs switch off individual phases.
 static int ablate_mask() { static int m = getenv("DDMI_ABLATE") ? atoi(getenv("DDMI_ABLATE")) : 0; return m; }
 
-// one (path, 16-wide w tile): all A (LDS) and B (L2) fragments are requested before the MFMA chain starts
-template <int DIN>
-__device__ __forceinline__ void nc_item(const NcItem& I, const float* __restrict__ slab, const float* __restrict__ xbuf,
-                                        float* __restrict__ obuf, int OS, int lr, int lq, int dbg) {
-  f32x4 acc[DIN];
+// One slot (= one column of every item of the unit): sum_u x[node][u, comp] * W2[k][path][u][w] for 16 nodes x 16 w.
+__device__ __forceinline__ f32x4 nc_slot(const NcSlot S, const float* __restrict__ slab, const float* __restrict__ xbuf,
+                                         int w0, int lr, int lq, int dbg) {
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (S.din == 0) return acc;
+  const float* __restrict__ bp = slab + S.wk_off + (size_t)lq * S.w_pad + w0 + lr;
+  const float* __restrict__ xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
+  for (int ub = 0; ub < S.u_pad; ub += 32) {
+    float bv[8], av[8];
 #pragma unroll
-  for (int i = 0; i < DIN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* __restrict__ bp = slab + I.wk_off + (size_t)lq * I.w_pad + I.w0 + lr;
-  const float* __restrict__ xp = xbuf + lr * NC_XS + I.x_off + lq * DIN;
-  for (int ub = 0; ub < I.u_pad; ub += 32) {
-    float bv[8], av[8][DIN];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 8; ++j) {     // all fragments of the block are requested before the MFMA chain starts
       const int u = ub + 4 * j;
-      bv[j] = (u < I.u_pad && !(dbg & 256)) ? bp[(size_t)u * I.w_pad] : 0.f;
-      const bool ok = (u + lq) < I.mul_in;
-#pragma unroll
-      for (int i = 0; i < DIN; ++i) av[j][i] = ok ? xp[u * DIN + i] : 0.f;
+      bv[j] = (u < S.u_pad && !(dbg & 256)) ? bp[(size_t)u * S.w_pad] : 0.f;
+      av[j] = (u + lq) < S.mul_in ? xp[u * S.din] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (ub + 4 * j >= I.u_pad || (dbg & 512)) break;
-#pragma unroll
-      for (int i = 0; i < DIN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][i], bv[j], acc[i], 0, 0, 0);
+      if (ub + 4 * j >= S.u_pad || (dbg & 512)) break;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
     }
   }
-  if (lr < I.n_w && !(dbg & 1024)) {
-    float* __restrict__ op = obuf + I.col_base + (I.w0 + lr) * I.itemw;
+  return acc;
+}
+
+// Workgroup = 16 gather nodes x KC consecutive k.  The x rows sit in LDS (read-only after the prologue: no barriers
+// in the main loop).  Each wave owns whole (output block, 16-w tile) units: because the columns are item-major, the
+// accumulators of 4 consecutive slots of a lane ARE 4 consecutive columns of Y, so every lane stores 16-B pieces
+// and 16 lanes cover a 256-B run of one node row -- straight from the MFMA result registers, no staging.
+template <int ITEMW>
+__device__ __forceinline__ void nc_unit(const NcUnit& U, const float* __restrict__ slab, const float* __restrict__ xbuf,
+                                        float* __restrict__ Yk, size_t node_stride, int HKp, int n_live, int lr, int lq,
+                                        int dbg) {
+  const int col = U.col_base + (U.w0 + lr) * ITEMW;
 #pragma unroll
-    for (int i = 0; i < DIN; ++i)
+  for (int q = 0; q < ITEMW / 4; ++q) {
+    const f32x4 a0 = nc_slot(U.slot[4 * q + 0], slab, xbuf, U.w0, lr, lq, dbg);
+    const f32x4 a1 = nc_slot(U.slot[4 * q + 1], slab, xbuf, U.w0, lr, lq, dbg);
+    const f32x4 a2 = nc_slot(U.slot[4 * q + 2], slab, xbuf, U.w0, lr, lq, dbg);
+    const f32x4 a3 = nc_slot(U.slot[4 * q + 3], slab, xbuf, U.w0, lr, lq, dbg);
+    if (lr < U.n_w && !(dbg & 2048)) {
+      const int c = col + 4 * q;
+      float* __restrict__ yp = Yk + ((size_t)(c >> 6) * HKp) * 64 + (c & 63);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) op[(4 * lq + r) * OS + i] = acc[i][r];
+      for (int r = 0; r < 4; ++r)
+        if (4 * lq + r < n_live)
+          *reinterpret_cast<float4*>(yp + (size_t)(4 * lq + r) * node_stride) = make_float4(a0[r], a1[r], a2[r], a3[r]);
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
                                                        const float* __restrict__ wpack,
-                                                       const NcItem* __restrict__ items, int n_items, int KS, int HK,
+                                                       const NcUnit* __restrict__ units, int n_units, int KS, int HK,
                                                        int HKp, int NTs, float* __restrict__ Y, int dbg) {
   DDMI_DYN_SMEM(float, smem);
   float* xbuf = smem;                                   // [16][XS+1]
-  float* obuf = smem + ((NC_NODES * NC_XS + 3) & ~3);   // [16][NTs + 4] (row shift of 4 banks)
-  const int OS = NTs + 4;
-  NcItem* sitems = reinterpret_cast<NcItem*>(obuf + NC_NODES * OS);   // [n_items]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int node0 = blockIdx.x * NC_NODES;
-  const int n_super = NTs >> 6, NQ = NTs >> 2;
+  const int n_super = NTs >> 6;
   for (int idx = tid; idx < NC_NODES * XS; idx += 256) {
     const int nl = idx / XS, c = idx - nl * XS;
     xbuf[nl * NC_XS + c] = (node0 + nl) < gcount ? X[(size_t)(gbase + node0 + nl) * XS + c] : 0.f;
   }
-  for (int idx = tid; idx < NC_NODES * OS; idx += 256) obuf[idx] = 0.f;
-  for (int idx = tid; idx < n_items; idx += 256) sitems[idx] = items[idx];
   __syncthreads();
   const int lr = lane & 15, lq = lane >> 4;
+  const int n_live = min(NC_NODES, gcount - node0);
+  const size_t node_stride = (size_t)n_super * HKp * 64;
   const int k_end = min((int)(blockIdx.y + 1) * NC_KC, HK);
   for (int k = blockIdx.y * NC_KC; k < k_end; ++k) {
     const float* __restrict__ slab = wpack + (size_t)k * KS;
-    for (int it = wave; it < n_items; it += 4) {
-      const NcItem I = sitems[it];
-      if (I.din == 1) nc_item<1>(I, slab, xbuf, obuf, OS, lr, lq, dbg);
-      else if (I.din == 3) nc_item<3>(I, slab, xbuf, obuf, OS, lr, lq, dbg);
-      else nc_item<5>(I, slab, xbuf, obuf, OS, lr, lq, dbg);
+    float* __restrict__ Yk = Y + (size_t)node0 * node_stride + (size_t)k * 64;
+    for (int it = wave; it < n_units; it += 4) {
+      const NcUnit& U = units[it];
+      if (U.n_w == 0) continue;
+      if (U.itemw == 4) nc_unit<4>(U, slab, xbuf, Yk, node_stride, HKp, n_live, lr, lq, dbg);
+      else if (U.itemw == 8) nc_unit<8>(U, slab, xbuf, Yk, node_stride, HKp, n_live, lr, lq, dbg);
+      else nc_unit<16>(U, slab, xbuf, Yk, node_stride, HKp, n_live, lr, lq, dbg);
     }
-    __syncthreads();
-    // stream the 16 finished rows out: thread q owns one float4 column group, 256-B runs per (node, super-tile)
-    if (!(dbg & 2048)) {
-      for (int q = tid; q < NQ; q += 256) {
-        const int col = q << 2, st = col >> 6, c = col & 63;
-        float* __restrict__ yq = Y + (((size_t)node0 * n_super + st) * HKp + k) * 64 + c;
-        const size_t node_stride = (size_t)n_super * HKp * 64;
-#pragma unroll 4
-        for (int nl = 0; nl < NC_NODES; ++nl)
-          if (node0 + nl < gcount)
-            *reinterpret_cast<float4*>(yq + nl * node_stride) = *reinterpret_cast<const float4*>(obuf + nl * OS + col);
-      }
-    }
-    __syncthreads();
   }
 }
 
-void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcItem* items, int n_items,
+void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcUnit* units, int n_units,
                           int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s) {
-  if (gcount <= 0 || n_items <= 0) return;
-  const size_t smem = (size_t)(((NC_NODES * NC_XS + 3) & ~3) + NC_NODES * (NTs + 4)) * sizeof(float) + n_items * sizeof(NcItem);
+  if (gcount <= 0 || n_units <= 0) return;
+  const size_t smem = (size_t)(NC_NODES * NC_XS) * sizeof(float);
   dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, NC_KC));
-  hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, items, n_items, KS, HK, HKp, NTs, Y,
+  hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, units, n_units, KS, HK, HKp, NTs, Y,
                      ablate_mask());
   DDMI_CHECK_HIP(hipGetLastError());
 }

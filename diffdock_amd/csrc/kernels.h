@@ -33,12 +33,14 @@ struct DevPath {    // coupling descriptor of one tensor-product path
 };
 struct GEntry { int c_idx, s_off, ds, dout; };              // G[g] = sum_j ctab[c_idx + j*dout] * sh[s_off + j]
 struct CgItem { int path_begin, path_end, o_off, dout, w; };  // (output block, w) work item of k_tp_apply
-struct NcItem {     // one (path, 16-wide w tile) unit of work of the node contraction
-  int x_off, din, mul_in, u_pad, w0, n_w, w_pad, wk_off, col_base, itemw;
+struct NcSlot { int x_off, din, comp, mul_in, u_pad, w_pad, wk_off; };   // one column of an item: (path, input component)
+struct NcUnit {     // one (output block, 16-wide w tile) unit of the node contraction: n_w items x itemw columns
+  int col_base, itemw, w0, n_w;
+  NcSlot slot[16];  // slot[s].din == 0 -> padding column (written as 0)
 };
 
 // Y[node][st][k][64] (st = 64-column super-tile) = sum_u x[node][x_off + u*din + i] * W2pack[k][path][u][w]
-void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcItem* items, int n_items,
+void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcUnit* units, int n_units,
                           int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s);
 
 struct EdgeConvArgs {

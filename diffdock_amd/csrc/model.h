@@ -44,7 +44,7 @@ struct ConvW {  // one TensorProductConvLayer
   TPTable table;
   int n_edge = 0, H = 0, HK = 0, HKp = 0, D_in = 0, D_out = 0, NT = 0, NTs = 0, sh_dim = 0, Wn = 0;
   std::vector<float*> W1, b1, W2, b2, wpack;
-  NcItem* nc_items = nullptr; int n_nc = 0, KS = 0;          // node-contraction work list, k-slab size of wpack
+  NcUnit* nc_units = nullptr; int n_nc = 0, KS = 0;          // node-contraction work list, k-slab size of wpack
   ObInfo* obs = nullptr; int n_ob = 0; QuadDesc* qdesc = nullptr; GEntry* gmap = nullptr; int GN = 0, maxd = 1;
   DevPath* paths = nullptr; float* ctab = nullptr; CgItem* items = nullptr; int n_items = 0;
   float *bn_mean = nullptr, *bn_scale = nullptr, *bn_bias = nullptr;

@@ -266,19 +266,47 @@ static void commit_conv(Model& m, ConvW& L) {
     L.wpack.push_back(m.wpool.upload(pack));
   }
   if (L.yform) {
-    // work list of the node contraction: (path, 16-wide w tile), heaviest first so the 4 waves balance
-    std::vector<NcItem> nc;
-    for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
-      const TPPath& p = L.table.paths[pi];
-      const ObInfo& O = obs[p.out_block];
-      const int wpad = (int)round_up(p.mul_out, 16), upad = (int)round_up(p.mul_in, 4);
-      for (int w0 = 0; w0 < p.mul_out; w0 += 16)
-        nc.push_back({p.i_off, p.din, p.mul_in, upad, w0, std::min(16, p.mul_out - w0), wpad, wk_off[pi],
-                      O.base + slot_base[pi], O.itemw});
+    // work list of the node contraction: (output block, 16-wide w tile) units, heaviest first so the 4 waves balance
+    std::vector<NcUnit> nc;
+    std::vector<long> cost;
+    for (int ob = 0; ob < (int)obs.size(); ++ob) {
+      const ObInfo& O = obs[ob];
+      for (int w0 = 0; w0 < O.mul; w0 += 16) {
+        NcUnit U{};
+        U.col_base = O.base; U.itemw = O.itemw; U.w0 = w0; U.n_w = std::min(16, O.mul - w0);
+        long c = 0;
+        for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
+          const TPPath& p = L.table.paths[pi];
+          if (p.out_block != ob) continue;
+          for (int i = 0; i < p.din; ++i) {
+            U.slot[slot_base[pi] + i] = {p.i_off, p.din, i, p.mul_in, (int)round_up(p.mul_in, 4),
+                                         (int)round_up(p.mul_out, 16), wk_off[pi]};
+            c += round_up(p.mul_in, 4) / 4;
+          }
+        }
+        nc.push_back(U);
+        cost.push_back(c);
+      }
     }
-    std::stable_sort(nc.begin(), nc.end(), [](const NcItem& a, const NcItem& b) { return a.u_pad * a.din > b.u_pad * b.din; });
-    L.nc_items = m.wpool.upload(nc);
-    L.n_nc = (int)nc.size();
+    std::vector<int> order(nc.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    // snake assignment: position j of the sorted list goes to wave (j % 8 < 4 ? j % 4 : 3 - j % 4); the kernel walks
+    // its units with stride 4, so store them in that interleaved order
+    std::vector<std::vector<NcUnit>> per_wave(4);
+    for (size_t j = 0; j < order.size(); ++j) per_wave[(j % 8 < 4) ? (j % 4) : (3 - j % 4)].push_back(nc[order[j]]);
+    std::vector<NcUnit> flat;
+    size_t rounds = 0;
+    for (auto& v : per_wave) rounds = std::max(rounds, v.size());
+    for (size_t r = 0; r < rounds; ++r)
+      for (int w = 0; w < 4; ++w) {
+        NcUnit U{};
+        U.n_w = 0;   // empty filler keeps the stride-4 walk aligned
+        if (r < per_wave[w].size()) U = per_wave[w][r];
+        flat.push_back(U);
+      }
+    L.nc_units = m.wpool.upload(flat);
+    L.n_nc = (int)flat.size();
   }
   // batch norm (e3nn.nn.BatchNorm eval, eps 1e-5): per-column mean / scale / bias ---------
   if (L.has_bn) {
