@@ -30,26 +30,39 @@ constexpr int NC_NODES = 16, NC_KC = 15, NC_XS = XS + 1;
 static int ablate_mask() { static int m = getenv("DDMI_ABLATE") ? atoi(getenv("DDMI_ABLATE")) : 0; return m; }
 
 // One slot (= one column of every item of the unit): sum_u x[node][u, comp] * W2[k][path][u][w] for 16 nodes x 16 w.
+// NSTEPS = u_pad / 4 MFMA steps, fully unrolled: all A (LDS) and B (L2) fragments are requested first, then the chain.
+// Rows u >= mul_in of the packed weights are zero, so the x fragment needs no predicate there (it reads the
+// neighbouring block of the finite x row).
+template <int NSTEPS>
+__device__ __forceinline__ f32x4 nc_chain(const float* __restrict__ bp, int bstride, const float* __restrict__ xp,
+                                          int xstride, f32x4 acc, int dbg) {
+  float bv[NSTEPS], av[NSTEPS];
+#pragma unroll
+  for (int j = 0; j < NSTEPS; ++j) {
+    bv[j] = (dbg & 256) ? 0.f : bp[(size_t)j * bstride];
+    av[j] = xp[j * xstride];
+  }
+  if (!(dbg & 512)) {
+#pragma unroll
+    for (int j = 0; j < NSTEPS; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 __device__ __forceinline__ f32x4 nc_slot(const NcSlot S, const float* __restrict__ slab, const float* __restrict__ xbuf,
                                          int w0, int lr, int lq, int dbg) {
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   if (S.din == 0) return acc;
   const float* __restrict__ bp = slab + S.wk_off + (size_t)lq * S.w_pad + w0 + lr;
   const float* __restrict__ xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
-  for (int ub = 0; ub < S.u_pad; ub += 32) {
-    float bv[8], av[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {     // all fragments of the block are requested before the MFMA chain starts
-      const int u = ub + 4 * j;
-      bv[j] = (u < S.u_pad && !(dbg & 256)) ? bp[(size_t)u * S.w_pad] : 0.f;
-      av[j] = (u + lq) < S.mul_in ? xp[u * S.din] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (ub + 4 * j >= S.u_pad || (dbg & 512)) break;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
-    }
-  }
+  const int bstride = 4 * S.w_pad, xstride = 4 * S.din;
+  int steps = S.u_pad >> 2;
+  while (steps >= 12) { acc = nc_chain<12>(bp, bstride, xp, xstride, acc, dbg); bp += 12 * (size_t)bstride; xp += 12 * xstride; steps -= 12; }
+  if (steps >= 8) { acc = nc_chain<8>(bp, bstride, xp, xstride, acc, dbg); bp += 8 * (size_t)bstride; xp += 8 * xstride; steps -= 8; }
+  if (steps >= 4) { acc = nc_chain<4>(bp, bstride, xp, xstride, acc, dbg); bp += 4 * (size_t)bstride; xp += 4 * xstride; steps -= 4; }
+  if (steps == 3) acc = nc_chain<3>(bp, bstride, xp, xstride, acc, dbg);
+  else if (steps == 2) acc = nc_chain<2>(bp, bstride, xp, xstride, acc, dbg);
+  else if (steps == 1) acc = nc_chain<1>(bp, bstride, xp, xstride, acc, dbg);
   return acc;
 }
 
