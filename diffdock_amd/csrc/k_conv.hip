@@ -24,80 +24,73 @@ namespace ddmi {
 // B = the k-th slab of the packed second-layer weights (L2-resident, 4 MB per edge group), v_mfma_f32_16x16x4_f32,
 // results scattered into an LDS row image in the item-major column order and then streamed out as 256-B runs
 // Y[node][super-tile][k][64] -- the exact order k_edge_conv reads them back.
-constexpr int NC_NODES = 16, NC_KC = 15, NC_XS = XS + 1;
+constexpr int NC_NODES = 32, NC_KC = 15, NC_XS = XS + 1;
 
 // Ablation mask for profiling (env DDMI_ABLATE, 0 in production): lets bench runs switch off individual phases.
 static int ablate_mask() { static int m = getenv("DDMI_ABLATE") ? atoi(getenv("DDMI_ABLATE")) : 0; return m; }
 
-// One slot (= one column of every item of the unit): sum_u x[node][u, comp] * W2[k][path][u][w] for 16 nodes x 16 w.
-// NSTEPS = u_pad / 4 MFMA steps, fully unrolled: all A (LDS) and B (L2) fragments are requested first, then the chain.
-// Rows u >= mul_in of the packed weights are zero, so the x fragment needs no predicate there (it reads the
+// One slot (= one column of every item of the unit) for TWO 16-node sub-tiles sharing the weight fragments:
+//   acc[t] += sum_u x[node_t][u, comp] * W2[k][path][u][w]        (16 nodes x 16 w each, v_mfma_f32_16x16x4_f32)
+// NSTEPS = MFMA steps per chain, fully unrolled: all B (L2) and A (LDS) fragments are requested first, then the chains.
+// Rows u >= mul_in of the packed weights are zero, so the x fragments need no predicate there (they read the
 // neighbouring block of the finite x row).
 template <int NSTEPS>
-__device__ __forceinline__ f32x4 nc_chain(const float* __restrict__ bp, int bstride, const float* __restrict__ xp,
-                                          int xstride, f32x4 acc, int dbg) {
-  float bv[NSTEPS], av[NSTEPS];
+__device__ __forceinline__ void nc_chain(const float* __restrict__ bp, int bstride, const float* __restrict__ xp,
+                                         int xstride, f32x4& acc0, f32x4& acc1, int dbg) {
+  float bv[NSTEPS], a0[NSTEPS], a1[NSTEPS];
 #pragma unroll
   for (int j = 0; j < NSTEPS; ++j) {
     bv[j] = (dbg & 256) ? 0.f : bp[(size_t)j * bstride];
-    av[j] = xp[j * xstride];
+    a0[j] = xp[j * xstride];
+    a1[j] = xp[16 * NC_XS + j * xstride];
   }
   if (!(dbg & 512)) {
 #pragma unroll
-    for (int j = 0; j < NSTEPS; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
-  }
-  return acc;
-}
-
-__device__ __forceinline__ f32x4 nc_slot(const NcSlot S, const float* __restrict__ slab, const float* __restrict__ xbuf,
-                                         int w0, int lr, int lq, int dbg) {
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (S.din == 0) return acc;
-  const float* __restrict__ bp = slab + S.wk_off + (size_t)lq * S.w_pad + w0 + lr;
-  const float* __restrict__ xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
-  const int bstride = 4 * S.w_pad, xstride = 4 * S.din;
-  int steps = S.u_pad >> 2;
-  while (steps >= 12) { acc = nc_chain<12>(bp, bstride, xp, xstride, acc, dbg); bp += 12 * (size_t)bstride; xp += 12 * xstride; steps -= 12; }
-  if (steps >= 8) { acc = nc_chain<8>(bp, bstride, xp, xstride, acc, dbg); bp += 8 * (size_t)bstride; xp += 8 * xstride; steps -= 8; }
-  if (steps >= 4) { acc = nc_chain<4>(bp, bstride, xp, xstride, acc, dbg); bp += 4 * (size_t)bstride; xp += 4 * xstride; steps -= 4; }
-  if (steps == 3) acc = nc_chain<3>(bp, bstride, xp, xstride, acc, dbg);
-  else if (steps == 2) acc = nc_chain<2>(bp, bstride, xp, xstride, acc, dbg);
-  else if (steps == 1) acc = nc_chain<1>(bp, bstride, xp, xstride, acc, dbg);
-  return acc;
-}
-
-// Workgroup = 16 gather nodes x KC consecutive k.  The x rows sit in LDS (read-only after the prologue: no barriers
-// in the main loop).  Each wave owns whole (output block, 16-w tile) units: because the columns are item-major, the
-// accumulators of 4 consecutive slots of a lane ARE 4 consecutive columns of Y, so every lane stores 16-B pieces
-// and 16 lanes cover a 256-B run of one node row -- straight from the MFMA result registers, no staging.
-template <int ITEMW>
-__device__ __forceinline__ void nc_unit(const NcUnit& U, const float* __restrict__ slab, const float* __restrict__ xbuf,
-                                        float* __restrict__ Yk, size_t node_stride, int HKp, int n_live, int lr, int lq,
-                                        int dbg) {
-  const int col = U.col_base + (U.w0 + lr) * ITEMW;
-#pragma unroll
-  for (int q = 0; q < ITEMW / 4; ++q) {
-    const f32x4 a0 = nc_slot(U.slot[4 * q + 0], slab, xbuf, U.w0, lr, lq, dbg);
-    const f32x4 a1 = nc_slot(U.slot[4 * q + 1], slab, xbuf, U.w0, lr, lq, dbg);
-    const f32x4 a2 = nc_slot(U.slot[4 * q + 2], slab, xbuf, U.w0, lr, lq, dbg);
-    const f32x4 a3 = nc_slot(U.slot[4 * q + 3], slab, xbuf, U.w0, lr, lq, dbg);
-    if (lr < U.n_w && !(dbg & 2048)) {
-      const int c = col + 4 * q;
-      float* __restrict__ yp = Yk + ((size_t)(c >> 6) * HKp) * 64 + (c & 63);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * lq + r < n_live)
-          *reinterpret_cast<float4*>(yp + (size_t)(4 * lq + r) * node_stride) = make_float4(a0[r], a1[r], a2[r], a3[r]);
+    for (int j = 0; j < NSTEPS; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bv[j], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bv[j], acc1, 0, 0, 0);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
+struct NcSlotRt { const float* bp; const float* xp; int bstride, xstride, steps; };   // per-lane, k-invariant part
+
+__device__ __forceinline__ NcSlotRt nc_slot_setup(const NcSlot S, const float* __restrict__ wpack, const float* __restrict__ xbuf,
+                                                  int w0, int lr, int lq) {
+  NcSlotRt R;
+  R.steps = S.din == 0 ? 0 : (S.u_pad >> 2);
+  R.bp = wpack + S.wk_off + (size_t)lq * S.w_pad + w0 + lr;
+  R.xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
+  R.bstride = 4 * S.w_pad;
+  R.xstride = 4 * S.din;
+  return R;
+}
+
+__device__ __forceinline__ void nc_slot(const NcSlotRt& R, size_t koff, f32x4& acc0, f32x4& acc1, int dbg) {
+  acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ bp = R.bp + koff;
+  const float* __restrict__ xp = R.xp;
+  int steps = R.steps;
+  while (steps >= 12) { nc_chain<12>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg); bp += 12 * (size_t)R.bstride; xp += 12 * R.xstride; steps -= 12; }
+  if (steps >= 8) { nc_chain<8>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg); bp += 8 * (size_t)R.bstride; xp += 8 * R.xstride; steps -= 8; }
+  if (steps >= 4) { nc_chain<4>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg); bp += 4 * (size_t)R.bstride; xp += 4 * R.xstride; steps -= 4; }
+  if (steps == 3) nc_chain<3>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg);
+  else if (steps == 2) nc_chain<2>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg);
+  else if (steps == 1) nc_chain<1>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg);
+}
+
+// Workgroup = 32 gather nodes (two 16-row MFMA sub-tiles) x KC consecutive k.  The x rows sit in LDS (read-only after
+// the prologue: no barriers in the main loop).  Each wave owns whole (output block, 16-w tile) units and, per quad of
+// item columns, walks the k range with all addresses hoisted: because the columns are item-major, the accumulators of
+// 4 consecutive slots of a lane ARE 4 consecutive columns of Y, so every lane stores 16-B pieces and 16 lanes cover a
+// 256-B run of one node row -- straight from the MFMA result registers, no staging.
+__global__ __launch_bounds__(256, 3) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
                                                        const float* __restrict__ wpack,
                                                        const NcUnit* __restrict__ units, int n_units, int KS, int HK,
                                                        int HKp, int NTs, float* __restrict__ Y, int dbg) {
   DDMI_DYN_SMEM(float, smem);
-  float* xbuf = smem;                                   // [16][XS+1]
+  float* xbuf = smem;                                   // [32][XS+1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int node0 = blockIdx.x * NC_NODES;
   const int n_super = NTs >> 6;
@@ -109,16 +102,36 @@ __global__ __launch_bounds__(256) void k_node_contract(const float* __restrict__
   const int lr = lane & 15, lq = lane >> 4;
   const int n_live = min(NC_NODES, gcount - node0);
   const size_t node_stride = (size_t)n_super * HKp * 64;
-  const int k_end = min((int)(blockIdx.y + 1) * NC_KC, HK);
-  for (int k = blockIdx.y * NC_KC; k < k_end; ++k) {
-    const float* __restrict__ slab = wpack + (size_t)k * KS;
-    float* __restrict__ Yk = Y + (size_t)node0 * node_stride + (size_t)k * 64;
-    for (int it = wave; it < n_units; it += 4) {
-      const NcUnit& U = units[it];
-      if (U.n_w == 0) continue;
-      if (U.itemw == 4) nc_unit<4>(U, slab, xbuf, Yk, node_stride, HKp, n_live, lr, lq, dbg);
-      else if (U.itemw == 8) nc_unit<8>(U, slab, xbuf, Yk, node_stride, HKp, n_live, lr, lq, dbg);
-      else nc_unit<16>(U, slab, xbuf, Yk, node_stride, HKp, n_live, lr, lq, dbg);
+  const int k_begin = blockIdx.y * NC_KC, k_end = min(k_begin + NC_KC, HK);
+  for (int it = wave; it < n_units; it += 4) {
+    const NcUnit& U = units[it];
+    if (U.n_w == 0) continue;
+    const int col = U.col_base + (U.w0 + lr) * U.itemw;
+    for (int q = 0; q < (U.itemw >> 2); ++q) {
+      const NcSlotRt s0 = nc_slot_setup(U.slot[4 * q + 0], wpack, xbuf, U.w0, lr, lq);
+      const NcSlotRt s1 = nc_slot_setup(U.slot[4 * q + 1], wpack, xbuf, U.w0, lr, lq);
+      const NcSlotRt s2 = nc_slot_setup(U.slot[4 * q + 2], wpack, xbuf, U.w0, lr, lq);
+      const NcSlotRt s3 = nc_slot_setup(U.slot[4 * q + 3], wpack, xbuf, U.w0, lr, lq);
+      const int c = col + 4 * q;
+      float* __restrict__ yp = Y + (size_t)node0 * node_stride + ((size_t)(c >> 6) * HKp) * 64 + (c & 63);
+      for (int k = k_begin; k < k_end; ++k) {
+        const size_t koff = (size_t)k * KS;
+        f32x4 a00, a01, a10, a11, a20, a21, a30, a31;
+        nc_slot(s0, koff, a00, a01, dbg);
+        nc_slot(s1, koff, a10, a11, dbg);
+        nc_slot(s2, koff, a20, a21, dbg);
+        nc_slot(s3, koff, a30, a31, dbg);
+        if (lr < U.n_w && !(dbg & 2048)) {
+          float* __restrict__ yk = yp + (size_t)k * 64;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n0 = 4 * lq + r;
+            if (n0 < n_live) *reinterpret_cast<float4*>(yk + (size_t)n0 * node_stride) = make_float4(a00[r], a10[r], a20[r], a30[r]);
+            if (n0 + 16 < n_live)
+              *reinterpret_cast<float4*>(yk + (size_t)(n0 + 16) * node_stride) = make_float4(a01[r], a11[r], a21[r], a31[r]);
+          }
+        }
+      }
     }
   }
 }
