@@ -23,6 +23,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
   type* name = reinterpret_cast<type*>(ddmi_dyn_smem_)
 #endif
 
+// streaming (read-once / write-once) accesses of the contracted rows Y: keep them from evicting the L2-resident
+// operands (packed weights, first-layer rows) -- `nt` cache policy on gfx950
+#ifdef DDMI_HIPEMU
+#define DDMI_NT_STORE(val, ptr) (*(ptr) = (val))
+#define DDMI_NT_LOAD(ptr) (*(ptr))
+#else
+#define DDMI_NT_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
+#define DDMI_NT_LOAD(ptr) __builtin_nontemporal_load((ptr))
+#endif
+
 namespace ddmi {
 
 constexpr int WAVE = 64;

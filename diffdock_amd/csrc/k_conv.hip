@@ -29,6 +29,16 @@ constexpr int NC_NODES = 32, NC_KC = 15, NC_XS = XS + 1;
 // Ablation mask for profiling (env DDMI_ABLATE, 0 in production): lets bench runs switch off individual phases.
 static int ablate_mask() { static int m = getenv("DDMI_ABLATE") ? atoi(getenv("DDMI_ABLATE")) : 0; return m; }
 
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float* p, float a, float b, float c, float d) {
+  vf4 v = {a, b, c, d};
+  DDMI_NT_STORE(v, reinterpret_cast<vf4*>(p));
+}
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const vf4 v = DDMI_NT_LOAD(reinterpret_cast<const vf4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // One slot (= one column of every item of the unit) for TWO 16-node sub-tiles sharing the weight fragments:
 //   acc[t] += sum_u x[node_t][u, comp] * W2[k][path][u][w]        (16 nodes x 16 w each, v_mfma_f32_16x16x4_f32)
 // NSTEPS = MFMA steps per chain, fully unrolled: all B (L2) and A (LDS) fragments are requested first, then the chains.
@@ -85,7 +95,7 @@ __device__ __forceinline__ void nc_slot(const NcSlotRt& R, size_t koff, f32x4& a
 // item columns, walks the k range with all addresses hoisted: because the columns are item-major, the accumulators of
 // 4 consecutive slots of a lane ARE 4 consecutive columns of Y, so every lane stores 16-B pieces and 16 lanes cover a
 // 256-B run of one node row -- straight from the MFMA result registers, no staging.
-__global__ __launch_bounds__(256, 3) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
+__global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
                                                        const float* __restrict__ wpack,
                                                        const NcUnit* __restrict__ units, int n_units, int KS, int HK,
                                                        int HKp, int NTs, float* __restrict__ Y, int dbg) {
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(256, 3) void k_node_contract(const float* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int node0 = blockIdx.x * NC_NODES;
   const int n_super = NTs >> 6;
+  const int k_begin = blockIdx.y * NC_KC, k_end = min(k_begin + NC_KC, HK);
   for (int idx = tid; idx < NC_NODES * XS; idx += 256) {
     const int nl = idx / XS, c = idx - nl * XS;
     xbuf[nl * NC_XS + c] = (node0 + nl) < gcount ? X[(size_t)(gbase + node0 + nl) * XS + c] : 0.f;
@@ -102,7 +113,6 @@ __global__ __launch_bounds__(256, 3) void k_node_contract(const float* __restric
   const int lr = lane & 15, lq = lane >> 4;
   const int n_live = min(NC_NODES, gcount - node0);
   const size_t node_stride = (size_t)n_super * HKp * 64;
-  const int k_begin = blockIdx.y * NC_KC, k_end = min(k_begin + NC_KC, HK);
   for (int it = wave; it < n_units; it += 4) {
     const NcUnit& U = units[it];
     if (U.n_w == 0) continue;
@@ -126,9 +136,8 @@ __global__ __launch_bounds__(256, 3) void k_node_contract(const float* __restric
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int n0 = 4 * lq + r;
-            if (n0 < n_live) *reinterpret_cast<float4*>(yk + (size_t)n0 * node_stride) = make_float4(a00[r], a10[r], a20[r], a30[r]);
-            if (n0 + 16 < n_live)
-              *reinterpret_cast<float4*>(yk + (size_t)(n0 + 16) * node_stride) = make_float4(a01[r], a11[r], a21[r], a31[r]);
+            if (n0 < n_live) nt_store4(yk + (size_t)n0 * node_stride, a00[r], a10[r], a20[r], a30[r]);
+            if (n0 + 16 < n_live) nt_store4(yk + (size_t)(n0 + 16) * node_stride, a01[r], a11[r], a21[r], a31[r]);
           }
         }
       }
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
       const int el = idx / H4, k4 = idx - el * H4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (el < ne && !(a.dbg & 1)) {
-        const float4 x = *reinterpret_cast<const float4*>(a.HE + (size_t)ibuf[el * 3] * a.H + 4 * k4);
+        const float4 x = nt_load4(a.HE + (size_t)ibuf[el * 3] * a.H + 4 * k4);
         const float4 p = *reinterpret_cast<const float4*>(a.P + (size_t)ibuf[el * 3 + 1] * a.H + 4 * k4);
         const float4 q = *reinterpret_cast<const float4*>(Qd + 4 * k4);
         v.x = fmaxf(x.x + p.x + q.x, 0.f); v.y = fmaxf(x.y + p.y + q.y, 0.f);
@@ -256,11 +265,11 @@ __global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
       const int nsteps = a.HKp >> 2;
       float4 cur[4], nxt[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) cur[j] = (j < nsteps && !(a.dbg & 2)) ? *reinterpret_cast<const float4*>(yp + (size_t)j * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < 4; ++j) cur[j] = (j < nsteps && !(a.dbg & 2)) ? nt_load4(yp + (size_t)j * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
       for (int s0 = 0; s0 < nsteps; s0 += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          nxt[j] = ((s0 + 4 + j) < nsteps && !(a.dbg & 2)) ? *reinterpret_cast<const float4*>(yp + (size_t)(s0 + 4 + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+          nxt[j] = ((s0 + 4 + j) < nsteps && !(a.dbg & 2)) ? nt_load4(yp + (size_t)(s0 + 4 + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (s0 + j >= nsteps || (a.dbg & 4)) break;
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
     // ---- phase 3
     for (int idx = tid; idx < ne * a.D_out && !(a.dbg & 16); idx += nthr) {
       const int el = idx / a.D_out, c = idx - el * a.D_out;
-      a.msg[(size_t)ibuf[el * 3 + 2] * XS + c] = mbuf[el * MS + c];
+      DDMI_NT_STORE(mbuf[el * MS + c], a.msg + (size_t)ibuf[el * 3 + 2] * XS + c);
     }
     __syncthreads();
   }
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(192) void k_reduce_bn(const ReduceGroup* __restrict
     const int b = G.toff[sl], e = G.toff[sl + 1];
     cnt += e - b;
     if (c < D_out)
-      for (int r = b; r < e; ++r) acc += G.msg[(size_t)r * XS + c];
+      for (int r = b; r < e; ++r) acc += DDMI_NT_LOAD(G.msg + (size_t)r * XS + c);
   }
   if (c >= out_stride) return;
   float v = 0.f;
