@@ -226,6 +226,9 @@ def main():
                 "sin_t": ts, "sin_emb": sinusoidal_embedding(1000.0 * ts, 16),
                 "gs_dist": dist, "gs_out": gs(dist), "t_schedule_20": torch.from_numpy(get_t_schedule("expbeta", 20))},
                os.path.join(HERE, "units.pt"))
+    for f in (".p.npy", ".score.npy"):      # 0.4 GB of torus caches: do not leave them in the tree
+        if os.path.exists(f):
+            os.remove(f)
     print("done")
 
 

@@ -196,7 +196,7 @@ def test_large_pocket_stress_config():
     set_time(batch, 0.5, 0.5, 0.5, B)
     tr, rot, tor, _ = m(to_gpu(batch))
     assert torch.isfinite(tr).all() and torch.isfinite(rot).all() and torch.isfinite(tor).all()
-    d = torch.cdist(batch["ligand"].pos.reshape(B, 80, 3), g["receptor"].pos[None].expand(B, -1, -1))
+    d = torch.cdist(batch["ligand"].pos.cpu().reshape(B, 80, 3), g["receptor"].pos.cpu()[None].expand(B, -1, -1))
     assert int(m.debug_buffer("offs_l")[-1]) == int((d < 80.0).sum())
     tr_b, rot_b, tor_b, _ = m(to_gpu(batch))
     assert torch.equal(tr, tr_b) and torch.equal(tor, tor_b)
