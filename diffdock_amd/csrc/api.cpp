@@ -1,4 +1,5 @@
 // extern "C" surface of libddmi.so (include/ddmi.h).
+#include <cstdlib>
 #include <cstring>
 
 #include "model.h"
@@ -27,6 +28,10 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     h->m.cfg = *cfg;
     h->m.device = device;
     try { build_weight_spec(h->m); } catch (...) { delete h; throw; }
+    if (const char* e = getenv("DDMI_STREAMS")) h->m.two_streams = atoi(e) != 1;
+    DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));
+    DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_fork));
+    DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_join));
     *out = h;
   });
 }

@@ -37,6 +37,7 @@ struct Model::Cx {
   int *pairrank, *cnt_l, *cnt_r, *offs_l, *offs_r, *g1_tgt, *g1_tslot, *g3_tgt, *g3_tslot, *pbatch;
   float *pdist, *pnvec, *pew, *cross_ea;
   float *HE, *P, *Q, *Y; float* msg[4];
+  float *HE_b, *P_b, *Q_b, *Y_b, *rowbias_b;   // second scratch set: ligand-gather groups on the side stream
   ReduceGroup *rg_all, *rg_lig, *rg_ll, *rg_rr;
   // read-outs
   float *c_dist, *c_nvec, *c_ea, *c_attr, *c_hid, *c_W, *c_sh, *c_out, *gp;
@@ -116,40 +117,60 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
               const float* Xin, float* Xout, int nbase, int ncount, hipStream_t s) {
   Cx& c = *m.cx;
   const int ns = m.ns, H = L.H;
+  // Groups whose gather nodes are ligand atoms (few nodes, many edges each: MFMA-bound) run on the side stream with
+  // their own scratch, concurrently with the receptor-gather groups (HBM-bound on the contracted rows).
+  bool forked = false;
+  if (m.two_streams && m.side_stream && groups.size() > 1) {
+    for (auto& g : groups) forked = forked || (g.gbase == 0 && g.gcount == c.nL && c.nR > 0);
+    bool any_main = false;
+    for (auto& g : groups) any_main = any_main || !(g.gbase == 0 && g.gcount == c.nL);
+    forked = forked && any_main;
+  }
+  if (forked) {
+    DDMI_CHECK_HIP(hipEventRecord(m.ev_fork, s));
+    DDMI_CHECK_HIP(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0));
+  }
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const RunGroup& g = groups[gi];
+    const bool side = forked && g.gbase == 0 && g.gcount == c.nL;
+    hipStream_t gs = side ? m.side_stream : s;
+    float *HE = side ? c.HE_b : c.HE, *P = side ? c.P_b : c.P, *Q = side ? c.Q_b : c.Q, *Y = side ? c.Y_b : c.Y;
+    float* rowbias = side ? c.rowbias_b : c.rr_rowbias;
     const int wg = std::min<int>((int)gi, L.G - 1);
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
     {
-      PhaseTimer t(m, "conv_fc1_gemms", s);
+      PhaseTimer t(m, "conv_fc1_gemms", gs);
       if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]
-        gemm(g.sig, ns, W1, L.n_edge, nullptr, c.rr_rowbias, H, c.B, H, ns, 0, s);
-        rb = c.rr_rowbias;
+        gemm(g.sig, ns, W1, L.n_edge, nullptr, rowbias, H, c.B, H, ns, 0, gs);
+        rb = rowbias;
       }
-      gemm(g.ea, ns, W1, L.n_edge, nullptr, c.HE, H, g.ea_rows, H, ns, 0, s, g.ea_rows_dev, rb, g.sig_idx, H);
-      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, c.P, H, g.tcount, H, ns, 0, s);
-      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], c.Q, H, g.gcount, H, ns, 0, s);
+      gemm(g.ea, ns, W1, L.n_edge, nullptr, HE, H, g.ea_rows, H, ns, 0, gs, g.ea_rows_dev, rb, g.sig_idx, H);
+      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
+      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
     }
     EdgeConvArgs a{};
     a.tgt = g.tgt; a.tslot = g.tslot; a.arow = g.arow; a.tbase = g.tbase;
-    a.HE = c.HE; a.P = c.P; a.Y = c.Y; a.nvec = g.nvec; a.ew = g.ew; a.sgn = g.sgn;
+    a.HE = HE; a.P = P; a.Y = Y; a.nvec = g.nvec; a.ew = g.ew; a.sgn = g.sgn;
     a.H = H; a.HKp = L.HKp; a.NTs = L.NTs; a.sh_lmax = m.cfg.sh_lmax; a.D_out = L.D_out; a.GN = L.GN; a.n_ob = L.n_ob;
     a.maxd = L.maxd; a.obs = L.obs; a.qdesc = L.qdesc; a.paths = L.paths; a.ctab = L.ctab; a.gmap = L.gmap; a.msg = g.msg;
     a.esplit = g.esplit > 0 ? g.esplit : 1;
-    // gather nodes are processed in chunks whose contracted rows (341 KB each at ns=48) fit the scratch Y buffer;
-    // with a chunk below the 256 MB Infinity Cache the rows are consumed while still on-die
+    // gather nodes are processed in chunks whose contracted rows (341 KB each at ns=48) fit the scratch Y buffer
     const int chunk = c.y_chunk > 0 ? std::min(c.y_chunk, g.gcount) : g.gcount;
     for (int d0 = 0; d0 < g.gcount; d0 += chunk) {
       const int n = std::min(chunk, g.gcount - d0);
       {
-        PhaseTimer t(m, "k_node_contract", s);
-        launch_node_contract(Xin, g.gbase + d0, n, L.wpack[wg], L.nc_units, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, c.Y, s);
+        PhaseTimer t(m, "k_node_contract", gs);
+        launch_node_contract(Xin, g.gbase + d0, n, L.wpack[wg], L.nc_units, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, Y, gs);
       }
-      a.gcount = n; a.goff = g.goff + d0; a.Q = c.Q + (size_t)d0 * H;
-      PhaseTimer t(m, "k_edge_conv", s);
-      launch_edge_conv(a, s);
+      a.gcount = n; a.goff = g.goff + d0; a.Q = Q + (size_t)d0 * H;
+      PhaseTimer t(m, "k_edge_conv", gs);
+      launch_edge_conv(a, gs);
     }
+  }
+  if (forked) {
+    DDMI_CHECK_HIP(hipEventRecord(m.ev_join, m.side_stream));
+    DDMI_CHECK_HIP(hipStreamWaitEvent(s, m.ev_join, 0));
   }
   PhaseTimer t(m, "k_reduce_bn", s);
   launch_reduce_bn(rg_dev, n_rg, nbase, ncount, L.D_in, L.D_out, L.has_bn ? L.bn_mean : nullptr,
@@ -321,6 +342,8 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.cross_ea = dalloc<float>(m, "cross_ea", {c.Elr_cap, ns});
   const int max_rows = std::max(std::max(c.Ell_cap, c.Elr_cap), c.Err);
   c.HE = dalloc<float>(m, nullptr, {max_rows, H}); c.P = dalloc<float>(m, nullptr, {N, H}); c.Q = dalloc<float>(m, nullptr, {N, H});
+  c.HE_b = dalloc<float>(m, nullptr, {std::max(c.Ell_cap, c.Elr_cap), H}); c.P_b = dalloc<float>(m, nullptr, {N, H});
+  c.Q_b = dalloc<float>(m, nullptr, {N, H}); c.rowbias_b = dalloc<float>(m, nullptr, {B, H});
   int HKp = 0, NTs = 0;
   auto upd = [&](const ConvW& L) { HKp = std::max(HKp, L.HKp); NTs = std::max(NTs, L.NTs); };
   for (auto& L : m.conv_layers) upd(L);
@@ -330,6 +353,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   if (const char* e = getenv("DDMI_ESPLIT")) c.esplit_lig = std::max(0, atoi(e));
   const int y_nodes = c.y_chunk > 0 ? std::min(c.y_chunk, std::max(nL, nR)) : std::max(nL, nR);
   c.Y = dalloc<float>(m, nullptr, {y_nodes, HKp, NTs}, true);
+  c.Y_b = dalloc<float>(m, nullptr, {c.y_chunk > 0 ? std::min(c.y_chunk, nL) : nL, HKp, NTs}, true);
   const int ecap[4] = {c.Ell_cap, c.Elr_cap, c.Err, c.Elr_cap};
   for (int g = 0; g < 4; ++g) c.msg[g] = dalloc<float>(m, nullptr, {ecap[g], XS});
   {

@@ -78,6 +78,9 @@ struct Model {
   float *so3_table = nullptr, *torus_table = nullptr; int so3_n = 0, torus_n = 0;
   // ---- complex + workspace
   bool has_complex = false;
+  hipStream_t side_stream = nullptr;   // ligand-gather edge groups run here, concurrently with the receptor-gather ones
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool two_streams = true;
   double crop_cutoff = 0.0;  // > 0: receptor cropped to this distance from the ligand in ddmi_forward (crop_beyond)
   DevicePool cpool;
   struct Cx;  // defined in complex.cpp

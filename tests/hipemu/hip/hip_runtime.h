@@ -64,6 +64,10 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum { hipStreamNonBlocking = 1 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);
