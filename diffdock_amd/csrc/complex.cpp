@@ -38,6 +38,13 @@ struct Model::Cx {
   float *pdist, *pnvec, *pew, *cross_ea;
   float *HE, *P, *Q, *Y; float* msg[4];
   float *HE_b, *P_b, *Q_b, *Y_b, *rowbias_b;   // second scratch set: ligand-gather groups on the side stream
+  // fused form (k_conv_fused): virtual-node lists of the two receptor-gather topologies (0 = lig<-rec cross, 1 = rec-rec),
+  // rebuilt when the edge list they were built for changes (once per forward), and the hidden-row scratch
+  struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr;
+                 const int* built_goff = nullptr; long epoch = -1; };
+  VnSet vn[2];
+  long epoch = 0;
+  float* Hb = nullptr;
   ReduceGroup *rg_all, *rg_lig, *rg_ll, *rg_rr;
   // read-outs
   float *c_dist, *c_nvec, *c_ea, *c_attr, *c_hid, *c_W, *c_sh, *c_out, *gp;
@@ -110,6 +117,7 @@ struct RunGroup {
   const float *nvec, *ew; float sgn;
   float* msg;
   int esplit = 1;
+  int vn = -1;     // >= 0: receptor-gather topology id -> eligible for the fused kernel
 };
 
 // One TensorProductConvLayer in the node-contracted form (k_conv.hip).
@@ -148,6 +156,36 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       gemm(g.ea, ns, W1, L.n_edge, nullptr, HE, H, g.ea_rows, H, ns, 0, gs, g.ea_rows_dev, rb, g.sig_idx, H);
       gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
       gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
+    }
+    if (m.fused && g.vn >= 0 && !side && L.n_fgran > 0 && c.Hb) {
+      Cx::VnSet& vs = c.vn[g.vn];
+      if (vs.built_goff != g.goff || vs.epoch != c.epoch) {
+        PhaseTimer t(m, "vn_build", gs);
+        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, gs);
+        vs.built_goff = g.goff; vs.epoch = c.epoch;
+      }
+      const int* nvn = vs.voff + g.gcount;
+      {
+        PhaseTimer t(m, "k_edge_hidden", gs);
+        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, c.Hb, gs);
+      }
+      FusedConvArgs f{};
+      f.nvn = nvn; f.vcap = vs.vcap; f.vn_node = vs.node; f.vn_e0 = vs.e0; f.goff = g.goff; f.tslot = g.tslot; f.arow = g.arow;
+      f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = c.Hb; f.NG8 = L.HKq / 8;
+      f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.gmap = L.gmap;
+      f.ctab = L.ctab; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
+      const int ys = std::max(1, std::min(std::min(m.fused_ysplit, 8), L.n_fgran));
+      f.ysplit = ys;
+      f.gsplit[0] = 0;
+      for (int y = 1; y < ys; ++y) {   // split points at unit boundaries (later granules of a unit add to the first one's stores)
+        int b = L.n_fgran * y / ys;
+        while (b < L.n_fgran && b > 0 && L.fgran_unit[b] == L.fgran_unit[b - 1]) ++b;
+        f.gsplit[y] = std::max(b, f.gsplit[y - 1]);
+      }
+      f.gsplit[ys] = L.n_fgran;
+      PhaseTimer t(m, "k_conv_fused", gs);
+      launch_conv_fused(f, gs);
+      continue;
     }
     EdgeConvArgs a{};
     a.tgt = g.tgt; a.tslot = g.tslot; a.arow = g.arow; a.tbase = g.tbase;
@@ -354,6 +392,21 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   const int y_nodes = c.y_chunk > 0 ? std::min(c.y_chunk, std::max(nL, nR)) : std::max(nL, nR);
   c.Y = dalloc<float>(m, nullptr, {y_nodes, HKp, NTs}, true);
   c.Y_b = dalloc<float>(m, nullptr, {c.y_chunk > 0 ? std::min(c.y_chunk, nL) : nL, HKp, NTs}, true);
+  if (m.fused) {
+    int HKq = 0;
+    for (auto& L : m.conv_layers) HKq = std::max(HKq, L.HKq);
+    for (auto& L : m.rec_emb_layers) HKq = std::max(HKq, L.HKq);
+    const int ecap_v[2] = {c.Elr_cap, c.Err};
+    int vmax = 0;
+    for (int i = 0; i < 2; ++i) {
+      Cx::VnSet& vs = c.vn[i];
+      vs.vcap = nR + ecap_v[i] / 32 + 1;
+      vs.cnt = dalloc<int>(m, nullptr, {nR + 1}); vs.voff = dalloc<int>(m, i == 0 ? "vn_off_cross" : "vn_off_rr", {nR + 1});
+      vs.node = dalloc<int>(m, nullptr, {vs.vcap}); vs.e0 = dalloc<int>(m, nullptr, {vs.vcap});
+      vmax = std::max(vmax, vs.vcap);
+    }
+    c.Hb = HKq > 0 ? dalloc<float>(m, nullptr, {vmax, 32, HKq}) : nullptr;
+  }
   const int ecap[4] = {c.Ell_cap, c.Elr_cap, c.Err, c.Elr_cap};
   for (int g = 0; g < 4; ++g) c.msg[g] = dalloc<float>(m, nullptr, {ecap[g], XS});
   {
@@ -426,6 +479,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
       const ConvW& L = m.rec_emb_layers[i];
       RunGroup g{0, nR, 0, nR, c.rr_goff, tl, c.rr_tslot, c.rr_arow, c.rec_edge_base, c.Err, nullptr, nullptr, nullptr,
                  c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
+      g.vn = 1;
       float* xout = (xin == c.rec_node_base) ? xa : c.rec_node_base;
       run_conv(m, L, {g}, c.rg_rr, 1, xin, xout, 0, nR, s);
       xin = xout;
@@ -447,6 +501,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   Cx& c = *m.cx;
   const ddmi_config& cfg = m.cfg;
   const int ns = m.ns, sd = m.sd, B = c.B, nL = c.nL, nR = c.nR;
+  ++c.epoch;
   PhaseTimer t_fwd(m, "forward_total", s);
   std::unique_ptr<PhaseTimer> t_phase(new PhaseTimer(m, "embed_and_graphs", s));
   // ---- per-graph time terms
@@ -496,8 +551,9 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   if (crop && !m.rec_emb_layers.empty()) {
     // the reference re-embeds the CROPPED receptor every step (the cache lives on the discarded deep copy)
     launch_add_rowvec(c.X[0] + (size_t)nL * XS, XS, c.rec_node_enc, XS, nullptr, 0, nullptr, nR, ns, 0, s);
-    const RunGroup g_rr0{nL, nR, nL, nR, c.goff2, c.tgt2, c.tslot2, c.arow2, c.rec_edge_base, c.Err, nullptr, nullptr,
-                         nullptr, c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
+    RunGroup g_rr0{nL, nR, nL, nR, c.goff2, c.tgt2, c.tslot2, c.arow2, c.rec_edge_base, c.Err, nullptr, nullptr,
+                   nullptr, c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
+    g_rr0.vn = 1;
     for (size_t i = 0; i < m.rec_emb_layers.size(); ++i)
       run_conv(m, m.rec_emb_layers[i], {g_rr0}, c.rg_rr_crop, 1, c.X[i], c.X[i + 1], nL, nR, s);
     launch_add_rowvec(c.X[xi] + (size_t)nL * XS, XS, c.X[xi] + (size_t)nL * XS, XS, c.rec_sig, ns, c.rec_batch, nR,
@@ -521,13 +577,14 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   launch_edge_mlp(mlp_args(m.cross_edge, ns, c.Elr_cap, c.offs_l + nL, c.pdist, m.off_cross, m.Dc, m.coeff_cross, sd,
                            c.cross_gvec, c.pbatch, c.cross_ea), s);
   // ---- interaction layers over [ll ; lig<-rec ; rec-rec ; rec<-lig]  (cg_model.py:329-349)
-  const RunGroup g_lr{nL, nR, 0, nL, c.offs_r, c.g1_tgt, c.g1_tslot, c.g1_tslot, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
+  RunGroup g_lr{nL, nR, 0, nL, c.offs_r, c.g1_tgt, c.g1_tslot, c.g1_tslot, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                       nullptr, c.pnvec, c.pew, 1.f, c.msg[1]};
-  const RunGroup g_rr{nL, nR, nL, nR, crop ? c.goff2 : c.rr_goff, crop ? c.tgt2 : c.rr_tgt, crop ? c.tslot2 : c.rr_tslot,
+  RunGroup g_rr{nL, nR, nL, nR, crop ? c.goff2 : c.rr_goff, crop ? c.tgt2 : c.rr_tgt, crop ? c.tslot2 : c.rr_tslot,
                       crop ? c.arow2 : c.rr_arow, c.rec_edge_base, c.Err, nullptr, c.rec_sig, c.rr_batch, c.rr_nvec, c.rr_ew,
                       1.f, c.msg[2]};
   RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                 nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
+  g_lr.vn = 0; g_rr.vn = 1;
   // ligand gather nodes carry up to Nr edges each: their 32-edge passes are dealt over several workgroups
   g_rl.esplit = c.esplit_lig > 0 ? c.esplit_lig : std::max(1, std::min(8, (c.Elr_cap / std::max(nL, 1) + 63) / 64));
   const int Lc = (int)m.conv_layers.size();

@@ -369,6 +369,396 @@ void launch_edge_conv(const EdgeConvArgs& a_in, hipStream_t s) {
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------ fused contraction + edge kernel
+// Virtual nodes: gather node d with edges [goff[d], goff[d+1]) becomes ceil(deg/32) entries (d, first edge).
+__global__ void k_vn_count(const int* __restrict__ goff, int gcount, int* __restrict__ cnt) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < gcount) cnt[d] = (goff[d + 1] - goff[d] + 31) >> 5;
+}
+__global__ void k_vn_fill(const int* __restrict__ goff, const int* __restrict__ voff, int gcount, int* __restrict__ vn_node,
+                          int* __restrict__ vn_e0) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= gcount) return;
+  const int v0 = voff[d], n = voff[d + 1] - v0, e0 = goff[d];
+  for (int b = 0; b < n; ++b) { vn_node[v0 + b] = d; vn_e0[v0 + b] = e0 + 32 * b; }
+}
+void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s) {
+  if (gcount <= 0) return;
+  hipLaunchKernelGGL(k_vn_count, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, gcount, cnt_tmp);
+  launch_exclusive_scan(cnt_tmp, voff, gcount, s);
+  hipLaunchKernelGGL(k_vn_fill, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, voff, gcount, vn_node, vn_e0);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
+// Hidden rows of the edge MLP in virtual-node order and in the A-fragment order of k_conv_fused:
+//   Hb[v][rt][g][lane = 16q + r][sub] = relu(HE[arow] + P[tgt] + Q[d])[k = 8g + 2q + sub]   for edge row el = 16rt + r
+// (zero for k >= H and for the padding rows el >= ne), so that a wave fetches one (row tile, 8-k group) as 512 contiguous bytes.
+__global__ __launch_bounds__(256) void k_edge_hidden(const int* __restrict__ nvn, const int* __restrict__ vn_node,
+                                                    const int* __restrict__ vn_e0, const int* __restrict__ goff,
+                                                    const int* __restrict__ arow, const int* __restrict__ tgt, int tbase,
+                                                    const float* __restrict__ HE, const float* __restrict__ P,
+                                                    const float* __restrict__ Q, int H, int NG8, float* __restrict__ Hb) {
+  const int v = blockIdx.x;
+  if (v >= *nvn) return;
+  const int d = vn_node[v], e0 = vn_e0[v];
+  const int ne = min(32, goff[d + 1] - e0);
+  const int q4 = 2 * NG8;
+  for (int idx = threadIdx.x; idx < 32 * q4; idx += blockDim.x) {
+    const int el = idx / q4, k = 4 * (idx - el * q4);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (el < ne && k < H) {
+      const int e = e0 + el;
+      const int ar = arow ? arow[e] : e;
+      const float4 x = nt_load4(HE + (size_t)ar * H + k);
+      const float4 p = *reinterpret_cast<const float4*>(P + (size_t)(tgt[e] - tbase) * H + k);
+      const float4 q = *reinterpret_cast<const float4*>(Q + (size_t)d * H + k);
+      o.x = fmaxf(x.x + p.x + q.x, 0.f); o.y = fmaxf(x.y + p.y + q.y, 0.f);
+      o.z = fmaxf(x.z + p.z + q.z, 0.f); o.w = fmaxf(x.w + p.w + q.w, 0.f);
+    }
+    const int rt = el >> 4, r = el & 15, g = k >> 3, q0 = (k & 7) >> 1;
+    float* hp = Hb + ((((size_t)v * 2 + rt) * NG8 + g) * 64 + q0 * 16 + r) * 2;
+    *reinterpret_cast<float2*>(hp) = make_float2(o.x, o.y);
+    *reinterpret_cast<float2*>(hp + 32) = make_float2(o.z, o.w);
+  }
+}
+void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
+                        const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
+                        float* Hb, hipStream_t s) {
+  if (vcap <= 0) return;
+  hipLaunchKernelGGL(k_edge_hidden, dim3(vcap), dim3(256), 0, s, nvn, vn_node, vn_e0, goff, arow, tgt, tbase, HE, P, Q, H,
+                     NG8, Hb);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
+constexpr int FC_VN = 16, FC_KC = 8, FC_WAVES = 8, FC_CAP0 = 12, FC_CAPN = 4;
+// chunk buffer in LDS: [16 nodes][8 rows][64 columns], column = 16*slot + w; padded strides keep the transposing stores
+// (lanes = 16 w x 4 node quarters) and the B-fragment loads (lanes = 16 w x rows 2q + sub) on 64 distinct banks
+constexpr int FC_YROW = 72, FC_YVN = FC_KC * FC_YROW + 4, FC_YB = FC_VN * FC_YVN;
+
+// k-invariant per-lane part of one slot chain: uniform weight base + 32-bit lane offset (scalar-base global loads)
+struct FcSlotRt { const float* wb; const float* xp; int loff, bstride, xstride, steps; };
+__device__ __forceinline__ FcSlotRt fc_slot_setup(const NcSlot S, const float* __restrict__ wpack, const float* __restrict__ xbuf,
+                                                  int w0, int lr, int lq) {
+  FcSlotRt R;
+  R.steps = S.din == 0 ? 0 : (S.u_pad >> 2);
+  R.wb = wpack + S.wk_off;
+  R.loff = lq * S.w_pad + w0 + lr;
+  R.xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
+  R.bstride = 4 * S.w_pad;
+  R.xstride = 4 * S.din;
+  return R;
+}
+// Weight fragments of one node-contraction item (4 slot chains), fetched one chunk ahead of their MFMAs.  Slot 0 is the
+// longest chain of the granule (host-sorted).  Granules whose chain lengths match one of the static shapes
+// (12,3,3,3) / (3,3,3,3) / (12,-,-,-) run fully unrolled code (a shorter chain of such a shape is a padding column: its
+// fragments are finite and its result is never read); anything else takes the predicated generic path.
+struct FcPre { float b0[FC_CAP0], b1[FC_CAPN], b2[FC_CAPN], b3[FC_CAPN]; };
+
+template <int N>
+__device__ __forceinline__ void fc_fetch_n(const FcSlotRt& R, size_t koff, float* bv) {
+  const float* __restrict__ wb = R.wb + koff;
+#pragma unroll
+  for (int j = 0; j < N; ++j) bv[j] = (wb + (size_t)j * R.bstride)[R.loff];
+}
+template <int N>
+__device__ __forceinline__ f32x4 fc_apply_n(const FcSlotRt& R, const float* bv) {
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ xp = R.xp;
+#pragma unroll
+  for (int j = 0; j < N; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], bv[j], acc, 0, 0, 0);
+  return acc;
+}
+template <int CAP>
+__device__ __forceinline__ void fc_fetch(const FcSlotRt& R, size_t koff, float* bv) {
+  const float* __restrict__ wb = R.wb + koff;
+#pragma unroll
+  for (int j = 0; j < CAP; ++j)
+    if (j < R.steps) bv[j] = (wb + (size_t)j * R.bstride)[R.loff];
+}
+template <int CAP>
+__device__ __forceinline__ f32x4 fc_apply(const FcSlotRt& R, size_t koff, const float* bv) {
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ xp = R.xp;
+#pragma unroll
+  for (int j = 0; j < CAP; ++j)
+    if (j < R.steps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], bv[j], acc, 0, 0, 0);
+  for (int j = CAP; j < R.steps; ++j)   // chains longer than the prefetch capacity (ns > 48)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], (R.wb + koff + (size_t)j * R.bstride)[R.loff], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x4 fc_direct(const FcSlotRt& R, size_t koff) {   // un-prefetched chain (bias row)
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < R.steps; ++j)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(R.xp[j * R.xstride], (R.wb + koff + (size_t)j * R.bstride)[R.loff], acc, 0, 0, 0);
+  return acc;
+}
+// transposing store of one chain result: lane (lr, lq) holds nodes 4lq .. 4lq+3 of column (slot, w = lr)
+__device__ __forceinline__ void fc_store(float* yw, int slot, const f32x4& v) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) yw[r * FC_YVN + 16 * slot] = v[r];
+}
+
+// Workgroup = 16 virtual nodes x the granules [gsplit[y], gsplit[y+1]), 8 waves: wave w owns virtual nodes 2w, 2w+1 in the
+// edge GEMM and row w (k = 8g + w) of every 8-row k group g in the node contraction.  A lane's two A values of the edge GEMM
+// over a group (k = 8g + 2q + sub) are one 8-B load of the fragment-ordered hidden rows.  The contracted group is
+// double-buffered in LDS; per iteration a wave contracts row w of group g+1 (weights requested one iteration earlier),
+// requests the weights of group g+2 and the hidden fragments of g+1, and multiplies group g into its edge accumulators:
+// one barrier per 8 k.  The bias row of the packed second layer (h = 1) is added outside the MFMA loop.
+template <int MAXD, bool GENERIC>
+__global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
+  DDMI_DYN_SMEM(float, smem);
+  constexpr int GS2 = 4 * MAXD + 3, SHS = 11;
+  float* xbuf = smem;                                  // [16][XS+1]
+  float* ybuf = xbuf + FC_VN * NC_XS;                  // [2][16 x FC_YVN]
+  float* gscr = ybuf + 2 * FC_YB;                      // per wave: [32][GS2] coupling rows + [32][SHS] sh rows
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = DDMI_UNIFORM(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int nvn = *a.nvn;
+  const int v0 = blockIdx.x * FC_VN;
+  if (v0 >= nvn) return;
+  const int nv_live = min(FC_VN, nvn - v0);
+  for (int idx = tid; idx < FC_VN * XS; idx += 64 * FC_WAVES) {
+    const int nl = idx / XS, c = idx - nl * XS;
+    xbuf[nl * NC_XS + c] = nl < nv_live ? a.X[(size_t)(a.gbase + a.vn_node[v0 + nl]) * XS + c] : 0.f;
+  }
+  int ve0[2], vne[2];
+#pragma unroll
+  for (int vi = 0; vi < 2; ++vi) {
+    const int v = v0 + 2 * wave + vi;
+    ve0[vi] = 0; vne[vi] = 0;
+    if (v < nvn) {
+      ve0[vi] = a.vn_e0[v];
+      vne[vi] = min(32, a.goff[a.vn_node[v] + 1] - ve0[vi]);
+    }
+  }
+  float* gw = gscr + wave * 32 * (GS2 + SHS);
+  float* shw = gw + 32 * GS2;
+  __syncthreads();
+  const int H = a.HK - 1;
+  const int NG8 = a.NG8;
+  const float* __restrict__ hfrag = a.Hb + ((size_t)(v0 + 2 * wave) * 2 * NG8) * 128 + 2 * lane;   // + ((vi*2 + rt)*NG8 + g)*128
+  float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
+  const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
+  for (int gi = a.gsplit[blockIdx.y]; gi < a.gsplit[blockIdx.y + 1]; ++gi) {
+    const FGran& Gd = a.gran[gi];
+    f32x4 acc[2][2][4];
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[vi][rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!Gd.empty) {
+      const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq);
+      const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
+      const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
+      const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.w0, lr, lq);
+      FcPre pre;
+      const int shape = Gd.shape;
+      auto fetch = [&](int k) __attribute__((always_inline)) {
+        if (k >= H) return;
+        const size_t koff = (size_t)k * a.KS;
+        if (GENERIC) {
+          fc_fetch<FC_CAP0>(s0, koff, pre.b0); fc_fetch<FC_CAPN>(s1, koff, pre.b1);
+          fc_fetch<FC_CAPN>(s2, koff, pre.b2); fc_fetch<FC_CAPN>(s3, koff, pre.b3);
+        } else if (shape == 1) {
+          fc_fetch_n<12>(s0, koff, pre.b0); fc_fetch_n<3>(s1, koff, pre.b1); fc_fetch_n<3>(s2, koff, pre.b2); fc_fetch_n<3>(s3, koff, pre.b3);
+        } else if (shape == 2) {
+          fc_fetch_n<3>(s0, koff, pre.b0); fc_fetch_n<3>(s1, koff, pre.b1); fc_fetch_n<3>(s2, koff, pre.b2); fc_fetch_n<3>(s3, koff, pre.b3);
+        } else {
+          fc_fetch_n<12>(s0, koff, pre.b0);
+        }
+      };
+      // contraction of row k (this wave's row of a group) into buffer `buf`; rows past the hidden width are zero
+      auto contract = [&](int k, int buf) __attribute__((always_inline)) {
+        float* yw = ywr + buf * FC_YB;
+        f32x4 r0 = f32x4{0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;
+        if (k < H) {
+          const size_t koff = (size_t)k * a.KS;
+          if (GENERIC) {
+            r0 = fc_apply<FC_CAP0>(s0, koff, pre.b0); r1 = fc_apply<FC_CAPN>(s1, koff, pre.b1);
+            r2 = fc_apply<FC_CAPN>(s2, koff, pre.b2); r3 = fc_apply<FC_CAPN>(s3, koff, pre.b3);
+          } else if (shape == 1) {
+            r0 = fc_apply_n<12>(s0, pre.b0); r1 = fc_apply_n<3>(s1, pre.b1); r2 = fc_apply_n<3>(s2, pre.b2); r3 = fc_apply_n<3>(s3, pre.b3);
+          } else if (shape == 2) {
+            r0 = fc_apply_n<3>(s0, pre.b0); r1 = fc_apply_n<3>(s1, pre.b1); r2 = fc_apply_n<3>(s2, pre.b2); r3 = fc_apply_n<3>(s3, pre.b3);
+          } else {
+            r0 = fc_apply_n<12>(s0, pre.b0);
+          }
+        }
+        fc_store(yw, 0, r0); fc_store(yw, 1, r1); fc_store(yw, 2, r2); fc_store(yw, 3, r3);
+      };
+      // edge GEMM of this wave's 2 virtual nodes on the group in buffer `buf` (two k-steps: sub = 0, 1)
+      auto edge_gemm = [&](int buf, const float2 (&hA)[2][2]) __attribute__((always_inline)) {
+        const float* __restrict__ yb0 = yrd + buf * FC_YB;
+#pragma unroll
+        for (int vi = 0; vi < 2; ++vi) {
+          if (vne[vi] == 0) continue;
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            const float* __restrict__ yb = yb0 + vi * FC_YVN + sub * FC_YROW;
+            const float b0 = yb[0], b1 = yb[16], b2 = yb[32], b3 = yb[48];
+            const float a0 = sub == 0 ? hA[vi][0].x : hA[vi][0].y;
+            acc[vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[vi][0][0], 0, 0, 0);
+            acc[vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[vi][0][1], 0, 0, 0);
+            acc[vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b2, acc[vi][0][2], 0, 0, 0);
+            acc[vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b3, acc[vi][0][3], 0, 0, 0);
+            if (vne[vi] > 16) {
+              const float a1 = sub == 0 ? hA[vi][1].x : hA[vi][1].y;
+              acc[vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[vi][1][0], 0, 0, 0);
+              acc[vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[vi][1][1], 0, 0, 0);
+              acc[vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b2, acc[vi][1][2], 0, 0, 0);
+              acc[vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b3, acc[vi][1][3], 0, 0, 0);
+            }
+          }
+        }
+      };
+      auto load_h = [&](int g, float2 (&hA)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            hA[vi][rt] = make_float2(0.f, 0.f);
+            if (g < NG8 && vne[vi] > 16 * rt)
+              hA[vi][rt] = *reinterpret_cast<const float2*>(hfrag + ((size_t)(vi * 2 + rt) * NG8 + g) * 128);
+          }
+      };
+      float2 hC[2][2], hN[2][2];
+      fetch(wave);
+      load_h(0, hC);
+      contract(wave, 0);
+      fetch(8 + wave);
+      __syncthreads();
+      for (int g = 0; g < NG8; ++g) {
+        const int kn = 8 * (g + 1) + wave;
+        if (g + 1 < NG8) contract(kn, (g + 1) & 1);     // weights requested one iteration ago
+        if (g + 2 < NG8) fetch(kn + 8);
+        load_h(g + 1, hN);
+        edge_gemm(g & 1, hC);
+        __syncthreads();
+#pragma unroll
+        for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+      }
+      // ---- bias row (k = H, h = 1): waves 0..3 contract one slot each, every edge row receives the node's bias row
+      if (wave < 4) {
+        const FcSlotRt& sb = wave == 0 ? s0 : wave == 1 ? s1 : wave == 2 ? s2 : s3;
+        const f32x4 rb = fc_direct(sb, (size_t)H * a.KS);
+        fc_store(ybuf + (4 * lq) * FC_YVN + lr, wave, rb);    // row 0 of buffer 0
+      }
+      __syncthreads();
+#pragma unroll
+      for (int vi = 0; vi < 2; ++vi) {
+        const float* __restrict__ yb = ybuf + (2 * wave + vi) * FC_YVN + lr;
+        const float b0 = yb[0], b1 = yb[16], b2 = yb[32], b3 = yb[48];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[vi][rt][0][r] += b0; acc[vi][rt][1][r] += b1; acc[vi][rt][2][r] += b2; acc[vi][rt][3][r] += b3;
+          }
+      }
+    }
+    // ---- coupling with the spherical harmonics and message stores (wave-local: no workgroup barrier)
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi) {
+      const int ne = vne[vi];
+      if (ne == 0) continue;
+      DDMI_WAVE_SYNC();
+      if (lane < 32) {
+        float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float we = 0.f;
+        int ts = -1;
+        if (lane < ne) {
+          const int e = ve0[vi] + lane;
+          const int ar = a.arow ? a.arow[e] : e;
+          edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
+          we = a.ew ? a.ew[ar] : 1.f;
+          ts = a.tslot[e];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) shw[lane * SHS + j] = sh[j];
+        gw[lane * GS2 + 4 * MAXD] = we;
+        reinterpret_cast<int*>(gw)[lane * GS2 + 4 * MAXD + 1] = ts;
+      }
+      DDMI_WAVE_SYNC();
+      {
+        const int el = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const int sl = 2 * half + ss;
+          const int g0 = Gd.g[sl];
+#pragma unroll
+          for (int k = 0; k < MAXD; ++k) {
+            float v = 0.f;
+            if (g0 >= 0 && k < Gd.dout) {
+              const GEntry E = a.gmap[g0 + k];
+              for (int j = 0; j < E.ds; ++j) v = fmaf(a.ctab[E.c_idx + j * E.dout], shw[el * SHS + E.s_off + j], v);
+            }
+            gw[el * GS2 + sl * MAXD + k] = v;
+          }
+        }
+      }
+      DDMI_WAVE_SYNC();
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        if (ne <= 16 * rt) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int el = rt * 16 + 4 * lq + r;
+          const float* __restrict__ G = gw + el * GS2;
+          const float t0 = acc[vi][rt][0][r], t1 = acc[vi][rt][1][r], t2 = acc[vi][rt][2][r], t3 = acc[vi][rt][3][r];
+          const float we = G[4 * MAXD];
+          const int ts = reinterpret_cast<const int*>(G)[4 * MAXD + 1];
+          if (lr < Gd.n_w && el < ne) {
+            float* __restrict__ mp = a.msg + (size_t)ts * XS + Gd.o_off + (Gd.w0 + lr) * Gd.dout;
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k) {
+              if (k < Gd.dout) {
+                float v = G[k] * t0;
+                v = fmaf(G[MAXD + k], t1, v);
+                v = fmaf(G[2 * MAXD + k], t2, v);
+                v = fmaf(G[3 * MAXD + k], t3, v);
+                v *= we;
+                mp[k] = Gd.accumulate ? mp[k] + v : v;
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();   // chunk buffers / coupling scratch are reused by the next granule
+  }
+}
+
+void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
+  if (a_in.vcap <= 0 || a_in.ysplit <= 0) return;
+  FusedConvArgs a = a_in;
+  a.dbg = ablate_mask();
+  const int maxd = a.maxd <= 3 ? 3 : 5;
+  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FC_YB + FC_WAVES * 32 * (4 * maxd + 3 + 11)) * sizeof(float);
+  dim3 grid(cdiv(a.vcap, FC_VN), a.ysplit);
+  static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per process)
+  if (!lds_opt_in) {
+    const int cap = 160 * 1024;
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    lds_opt_in = true;
+  }
+  if (a.generic) {
+    if (maxd == 3) hipLaunchKernelGGL((k_conv_fused<3, true>), grid, dim3(64 * FC_WAVES), smem, s, a);
+    else hipLaunchKernelGGL((k_conv_fused<5, true>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  } else {
+    if (maxd == 3) hipLaunchKernelGGL((k_conv_fused<3, false>), grid, dim3(64 * FC_WAVES), smem, s, a);
+    else hipLaunchKernelGGL((k_conv_fused<5, false>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  }
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 // ---------------------------------------------------------------------- reduce + BN
 __global__ __launch_bounds__(192) void k_reduce_bn(const ReduceGroup* __restrict__ groups, int n_groups, int nbase,
                                                    int D_in, int D_out, const float* __restrict__ bn_mean,

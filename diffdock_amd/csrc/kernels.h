@@ -65,6 +65,42 @@ struct EdgeConvArgs {
 };
 void launch_edge_conv(const EdgeConvArgs& a, hipStream_t s);
 
+// ---- fused form for gather nodes with few edges each (receptor residues): the contracted rows never leave the CU.
+// A VIRTUAL NODE = one gather node with up to 32 of its edges (nodes with more edges appear several times, nodes
+// without edges not at all).  A workgroup owns 16 virtual nodes and walks GRANULES of 64 fused columns
+// (w = w0 + lane%16, slot 4q + s): per 8-row k chunk it contracts the 16 x rows with the packed second-layer weights
+// into LDS (v_mfma_f32_16x16x4_f32, M = nodes) and immediately multiplies the chunk into the edge accumulators
+// (M = edges), then couples with the spherical harmonics and writes the message columns of the granule.
+struct FGran {
+  NcSlot slot[4];        // the 4 (path, input component) columns of this granule; din == 0 -> padding (zero)
+  int w0, n_w;           // lanes lr < n_w carry output channel w0 + lr
+  int o_off, dout;       // message columns o_off + w*dout + k'
+  int g[4];              // slot s couples through gmap[g[s] .. g[s]+dout), -1 = padding
+  int accumulate;        // 0: first granule of its (output block, w tile) unit writes, later ones add
+  int empty;             // no path reaches this granule: the message columns are zero
+  int shape;             // chain-length class of the 4 slots: 1 = (12,3,3,3), 2 = (3,3,3,3), 3 = (12,-,-,-), 0 = generic
+};
+void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s);
+void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
+                        const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
+                        float* Hb, hipStream_t s);
+struct FusedConvArgs {
+  const int* nvn; int vcap;              // live virtual nodes (device) and their capacity (grid size)
+  const int* vn_node; const int* vn_e0;  // [vcap] gather node (local), first edge
+  const int* goff;                       // [gcount+1] gather CSR
+  const int* tslot; const int* arow;     // [E] message row, attr row (nullptr = identity)
+  const float* X; int gbase;             // node table (stride XS), first gather node
+  const float* wpack; int KS, HK;        // packed second layer [HK][KS]
+  const float* Hb; int NG8;              // hidden rows in A-fragment order [vcap][2][NG8][64][2], NG8 = ceil(H / 8)
+  const float* nvec; const float* ew; float sgn; int sh_lmax;
+  const FGran* gran; int ysplit; int gsplit[9];   // blockIdx.y walks granules [gsplit[y], gsplit[y+1])
+  const GEntry* gmap; const float* ctab; int maxd;
+  int generic;                           // some granule has no static chain shape: predicated kernel variant
+  float* msg;                            // [E][XS]
+  int dbg = 0;
+};
+void launch_conv_fused(const FusedConvArgs& a, hipStream_t s);
+
 struct ReduceGroup { const int* toff; const float* msg; int tbase, tcount; };
 // X_out[s] = BN(mean over all groups' incoming messages) + pad(X_in[s]) for s in [nbase, nbase+ncount)
 void launch_reduce_bn(const ReduceGroup* groups_dev, int n_groups, int nbase, int ncount, int D_in, int D_out,

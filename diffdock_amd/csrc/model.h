@@ -45,6 +45,8 @@ struct ConvW {  // one TensorProductConvLayer
   int n_edge = 0, H = 0, HK = 0, HKp = 0, D_in = 0, D_out = 0, NT = 0, NTs = 0, sh_dim = 0, Wn = 0;
   std::vector<float*> W1, b1, W2, b2, wpack;
   NcUnit* nc_units = nullptr; int n_nc = 0, KS = 0;          // node-contraction work list, k-slab size of wpack
+  FGran* fgran = nullptr; int n_fgran = 0, HKq = 0; bool fgran_generic = false;          // fused form: granule list, padded hidden-row length
+  std::vector<int> fgran_unit;                               // unit id of every granule (split points of the grid)
   ObInfo* obs = nullptr; int n_ob = 0; QuadDesc* qdesc = nullptr; GEntry* gmap = nullptr; int GN = 0, maxd = 1;
   DevPath* paths = nullptr; float* ctab = nullptr; CgItem* items = nullptr; int n_items = 0;
   float *bn_mean = nullptr, *bn_scale = nullptr, *bn_bias = nullptr;
@@ -81,6 +83,8 @@ struct Model {
   hipStream_t side_stream = nullptr;   // ligand-gather edge groups run here, concurrently with the receptor-gather ones
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool two_streams = true;
+  bool fused = true;        // receptor-gather edge groups use k_conv_fused (DDMI_FUSED=0: contracted rows through HBM)
+  int fused_ysplit = 1;     // workgroups per 16-virtual-node tile (granule ranges)
   double crop_cutoff = 0.0;  // > 0: receptor cropped to this distance from the ligand in ddmi_forward (crop_beyond)
   DevicePool cpool;
   struct Cx;  // defined in complex.cpp

@@ -269,11 +269,15 @@ static void commit_conv(Model& m, ConvW& L) {
     // work list of the node contraction: (output block, 16-wide w tile) units, heaviest first so the 4 waves balance
     std::vector<NcUnit> nc;
     std::vector<long> cost;
+    std::vector<FGran> fg;
+    L.fgran_unit.clear();
     for (int ob = 0; ob < (int)obs.size(); ++ob) {
       const ObInfo& O = obs[ob];
       for (int w0 = 0; w0 < O.mul; w0 += 16) {
         NcUnit U{};
         U.col_base = O.base; U.itemw = O.itemw; U.w0 = w0; U.n_w = std::min(16, O.mul - w0);
+        int slot_g[16];
+        for (int i = 0; i < 16; ++i) slot_g[i] = -1;
         long c = 0;
         for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
           const TPPath& p = L.table.paths[pi];
@@ -281,13 +285,46 @@ static void commit_conv(Model& m, ConvW& L) {
           for (int i = 0; i < p.din; ++i) {
             U.slot[slot_base[pi] + i] = {p.i_off, p.din, i, p.mul_in, (int)round_up(p.mul_in, 4),
                                          (int)round_up(p.mul_out, 16), wk_off[pi]};
+            slot_g[slot_base[pi] + i] = dp[pi].g_off + i * p.dout;
             c += round_up(p.mul_in, 4) / 4;
           }
+        }
+        // fused form: one granule per quad of item columns
+        for (int q = 0; q < O.itemw / 4; ++q) {
+          FGran G{};
+          G.w0 = w0; G.n_w = U.n_w; G.o_off = O.o_off; G.dout = O.dout; G.accumulate = q > 0; G.empty = 1;
+          for (int sl = 0; sl < 4; ++sl) {
+            G.slot[sl] = U.slot[4 * q + sl];
+            G.g[sl] = slot_g[4 * q + sl];
+            if (G.slot[sl].din != 0) G.empty = 0;
+          }
+          if (G.empty && q > 0) continue;   // padding quad of a wider item: contributes nothing
+          // longest chain first: k_conv_fused prefetches 12 weight fragments for slot 0 and 4 for the others
+          for (int i = 1; i < 4; ++i)
+            for (int j = i; j > 0; --j) {
+              auto steps = [&](int t) { return G.slot[t].din == 0 ? 0 : G.slot[t].u_pad; };
+              if (steps(j) > steps(j - 1)) { std::swap(G.slot[j], G.slot[j - 1]); std::swap(G.g[j], G.g[j - 1]); }
+            }
+          {
+            auto st = [&](int t) { return G.slot[t].din == 0 ? 0 : G.slot[t].u_pad / 4; };
+            auto fits = [&](int t, int n) { return st(t) == n || st(t) == 0; };
+            G.shape = 0;
+            if (st(0) == 12 && st(1) == 0 && st(2) == 0 && st(3) == 0) G.shape = 3;
+            else if (st(0) == 12 && fits(1, 3) && fits(2, 3) && fits(3, 3)) G.shape = 1;
+            else if (st(0) == 3 && fits(1, 3) && fits(2, 3) && fits(3, 3)) G.shape = 2;
+          }
+          fg.push_back(G);
+          L.fgran_unit.push_back((int)nc.size());
         }
         nc.push_back(U);
         cost.push_back(c);
       }
     }
+    L.fgran_generic = false;
+    for (auto& G : fg) if (!G.empty && G.shape == 0) L.fgran_generic = true;
+    L.fgran = m.wpool.upload(fg);
+    L.n_fgran = (int)fg.size();
+    L.HKq = (int)round_up(L.H, 8);   // hidden width padded to the 8-k groups of the fused kernel
     std::vector<int> order(nc.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });

@@ -75,6 +75,9 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
 // ---- launch --------------------------------------------------------------------------
 void hipemu_launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t dyn_smem);
 void* hipemu_dyn_smem();
@@ -83,6 +86,7 @@ void* hipemu_dyn_smem();
 
 // ---- device builtins -----------------------------------------------------------------
 void __syncthreads();
+void hipemu_wave_sync();   // rendezvous of the live lanes of the calling wave
 float hipemu_shfl(float v, int src_lane);
 static inline float __shfl(float v, int lane, int width = 64) { (void)width; return hipemu_shfl(v, lane); }
 float __shfl_xor(float v, int mask, int width = 64);

@@ -96,6 +96,7 @@ inline int lane() { return cur % 64; }
 }  // namespace
 
 void* hipemu_dyn_smem() { return dyn_smem.data(); }
+void hipemu_wave_sync() { wave_sync(); threadIdx = fibers[cur].tid; }
 
 void hipemu_launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t dyn) {
   n_threads = block.x * block.y * block.z;
