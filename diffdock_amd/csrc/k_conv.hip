@@ -498,6 +498,104 @@ __device__ __forceinline__ void fc_store(float* yw, int slot, const f32x4& v) {
   for (int r = 0; r < 4; ++r) yw[r * FC_YVN + 16 * slot] = v[r];
 }
 
+// Steady-state loop of one granule for the static chain shapes (S0, SN, SN, SN), hidden width a multiple of 8:
+// straight-line code per 8-k group -- the k-invariant x fragments stay in registers, the weight fragments arrive one
+// iteration ahead, and the four slot chains are issued interleaved (a dependent f32 MFMA costs 40 cycles, an independent
+// one 32).
+template <int S0, int SN>
+__device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotRt& s0, const FcSlotRt& s1, const FcSlotRt& s2,
+                                            const FcSlotRt& s3, int KS, int NG8, int wave, const float* __restrict__ hfrag,
+                                            const int (&vne)[2], float* ywr, const float* yrd) {
+  constexpr int M0 = S0 > 0 ? S0 : 1, MN = SN > 0 ? SN : 1;
+  float xa0[M0], xa1[MN], xa2[MN], xa3[MN];
+  float b0[M0], b1[MN], b2[MN], b3[MN];
+#pragma unroll
+  for (int j = 0; j < S0; ++j) xa0[j] = s0.xp[j * s0.xstride];
+#pragma unroll
+  for (int j = 0; j < SN; ++j) { xa1[j] = s1.xp[j * s1.xstride]; xa2[j] = s2.xp[j * s2.xstride]; xa3[j] = s3.xp[j * s3.xstride]; }
+  const float* __restrict__ w0 = s0.wb + (size_t)wave * KS;   // row k = 8g + wave: advance by 8*KS per group
+  const float* __restrict__ w1 = s1.wb + (size_t)wave * KS;
+  const float* __restrict__ w2 = s2.wb + (size_t)wave * KS;
+  const float* __restrict__ w3 = s3.wb + (size_t)wave * KS;
+  const size_t gstep = (size_t)8 * KS;
+#define FC_FETCH()                                                                       \
+  do {                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < S0; ++j) b0[j] = (w0 + (size_t)j * s0.bstride)[s0.loff]; \
+    _Pragma("unroll") for (int j = 0; j < SN; ++j) {                                     \
+      b1[j] = (w1 + (size_t)j * s1.bstride)[s1.loff];                                    \
+      b2[j] = (w2 + (size_t)j * s2.bstride)[s2.loff];                                    \
+      b3[j] = (w3 + (size_t)j * s3.bstride)[s3.loff];                                    \
+    }                                                                                    \
+    w0 += gstep; w1 += gstep; w2 += gstep; w3 += gstep;                                  \
+  } while (0)
+#define FC_CONTRACT(buf)                                                                 \
+  do {                                                                                   \
+    f32x4 r0 = f32x4{0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;                     \
+    _Pragma("unroll") for (int j = 0; j < (S0 > 3 * SN ? S0 : 3 * SN); ++j) {            \
+      if (j < S0) r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0[j], b0[j], r0, 0, 0, 0); \
+      if (j < 3 * SN) {                                                                  \
+        if (j % 3 == 0) r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1[j / 3], b1[j / 3], r1, 0, 0, 0);      \
+        else if (j % 3 == 1) r2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa2[j / 3], b2[j / 3], r2, 0, 0, 0); \
+        else r3 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa3[j / 3], b3[j / 3], r3, 0, 0, 0);                 \
+      }                                                                                  \
+    }                                                                                    \
+    float* yw = ywr + (buf) * FC_YB;                                                     \
+    fc_store(yw, 0, r0); fc_store(yw, 1, r1); fc_store(yw, 2, r2); fc_store(yw, 3, r3);  \
+  } while (0)
+  float2 hC[2][2], hN[2][2];
+  const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
+  const float* __restrict__ hp = hfrag;
+#define FC_LOADH(dst)                                                                    \
+  do {                                                                                   \
+    dst[0][0] = *reinterpret_cast<const float2*>(hp);                                    \
+    dst[0][1] = two0 ? *reinterpret_cast<const float2*>(hp + (size_t)NG8 * 128) : make_float2(0.f, 0.f);     \
+    dst[1][0] = *reinterpret_cast<const float2*>(hp + (size_t)2 * NG8 * 128);            \
+    dst[1][1] = two1 ? *reinterpret_cast<const float2*>(hp + (size_t)3 * NG8 * 128) : make_float2(0.f, 0.f); \
+    hp += 128;                                                                           \
+  } while (0)
+  FC_FETCH();
+  FC_LOADH(hC);
+  FC_CONTRACT(0);
+  if (NG8 > 1) FC_FETCH();
+  __syncthreads();
+  for (int g = 0; g < NG8; ++g) {
+    if (g + 1 < NG8) {
+      FC_CONTRACT((g + 1) & 1);
+      if (g + 2 < NG8) FC_FETCH();
+      FC_LOADH(hN);
+    }
+    const float* __restrict__ yb0 = yrd + (g & 1) * FC_YB;
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const float* __restrict__ yb = yb0 + vi * FC_YVN + sub * FC_YROW;
+        const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];
+        const float a0 = sub == 0 ? hC[vi][0].x : hC[vi][0].y;
+        acc[vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[vi][0][0], 0, 0, 0);
+        acc[vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[vi][0][1], 0, 0, 0);
+        acc[vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[vi][0][2], 0, 0, 0);
+        acc[vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[vi][0][3], 0, 0, 0);
+        if (vi == 0 ? two0 : two1) {
+          const float a1 = sub == 0 ? hC[vi][1].x : hC[vi][1].y;
+          acc[vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[vi][1][0], 0, 0, 0);
+          acc[vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[vi][1][1], 0, 0, 0);
+          acc[vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[vi][1][2], 0, 0, 0);
+          acc[vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[vi][1][3], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+  }
+#undef FC_FETCH
+#undef FC_CONTRACT
+#undef FC_LOADH
+}
+
 // Workgroup = 16 virtual nodes x the granules [gsplit[y], gsplit[y+1]), 8 waves: wave w owns virtual nodes 2w, 2w+1 in the
 // edge GEMM and row w (k = 8g + w) of every 8-row k group g in the node contraction.  A lane's two A values of the edge GEMM
 // over a group (k = 8g + 2q + sub) are one 8-B load of the fragment-ordered hidden rows.  The contracted group is
@@ -554,21 +652,19 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.w0, lr, lq);
+      if (!GENERIC) {
+        if (Gd.shape == 1) fc_mainloop<12, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+        else if (Gd.shape == 2) fc_mainloop<3, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+        else fc_mainloop<12, 0>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+      } else {
       FcPre pre;
       const int shape = Gd.shape;
       auto fetch = [&](int k) __attribute__((always_inline)) {
         if (k >= H) return;
         const size_t koff = (size_t)k * a.KS;
-        if (GENERIC) {
-          fc_fetch<FC_CAP0>(s0, koff, pre.b0); fc_fetch<FC_CAPN>(s1, koff, pre.b1);
-          fc_fetch<FC_CAPN>(s2, koff, pre.b2); fc_fetch<FC_CAPN>(s3, koff, pre.b3);
-        } else if (shape == 1) {
-          fc_fetch_n<12>(s0, koff, pre.b0); fc_fetch_n<3>(s1, koff, pre.b1); fc_fetch_n<3>(s2, koff, pre.b2); fc_fetch_n<3>(s3, koff, pre.b3);
-        } else if (shape == 2) {
-          fc_fetch_n<3>(s0, koff, pre.b0); fc_fetch_n<3>(s1, koff, pre.b1); fc_fetch_n<3>(s2, koff, pre.b2); fc_fetch_n<3>(s3, koff, pre.b3);
-        } else {
-          fc_fetch_n<12>(s0, koff, pre.b0);
-        }
+        (void)shape;
+        fc_fetch<FC_CAP0>(s0, koff, pre.b0); fc_fetch<FC_CAPN>(s1, koff, pre.b1);
+        fc_fetch<FC_CAPN>(s2, koff, pre.b2); fc_fetch<FC_CAPN>(s3, koff, pre.b3);
       };
       // contraction of row k (this wave's row of a group) into buffer `buf`; rows past the hidden width are zero
       auto contract = [&](int k, int buf) __attribute__((always_inline)) {
@@ -576,16 +672,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         f32x4 r0 = f32x4{0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;
         if (k < H) {
           const size_t koff = (size_t)k * a.KS;
-          if (GENERIC) {
-            r0 = fc_apply<FC_CAP0>(s0, koff, pre.b0); r1 = fc_apply<FC_CAPN>(s1, koff, pre.b1);
-            r2 = fc_apply<FC_CAPN>(s2, koff, pre.b2); r3 = fc_apply<FC_CAPN>(s3, koff, pre.b3);
-          } else if (shape == 1) {
-            r0 = fc_apply_n<12>(s0, pre.b0); r1 = fc_apply_n<3>(s1, pre.b1); r2 = fc_apply_n<3>(s2, pre.b2); r3 = fc_apply_n<3>(s3, pre.b3);
-          } else if (shape == 2) {
-            r0 = fc_apply_n<3>(s0, pre.b0); r1 = fc_apply_n<3>(s1, pre.b1); r2 = fc_apply_n<3>(s2, pre.b2); r3 = fc_apply_n<3>(s3, pre.b3);
-          } else {
-            r0 = fc_apply_n<12>(s0, pre.b0);
-          }
+          r0 = fc_apply<FC_CAP0>(s0, koff, pre.b0); r1 = fc_apply<FC_CAPN>(s1, koff, pre.b1);
+          r2 = fc_apply<FC_CAPN>(s2, koff, pre.b2); r3 = fc_apply<FC_CAPN>(s3, koff, pre.b3);
         }
         fc_store(yw, 0, r0); fc_store(yw, 1, r1); fc_store(yw, 2, r2); fc_store(yw, 3, r3);
       };
@@ -641,6 +729,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+      }
       }
       // ---- bias row (k = H, h = 1): waves 0..3 contract one slot each, every edge row receives the node's bias row
       if (wave < 4) {
