@@ -12,6 +12,7 @@
 //                     m_e[o,w,k'] = sum_{paths,i,j} C[i][j][k'] sh_e[j] T[e][path,i,w]
 //   k_reduce_bn     : deterministic segmented mean over the target-CSR, BatchNorm, residual
 // Results equal the reference up to fp32 re-association.
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -498,6 +499,33 @@ __device__ __forceinline__ void fc_store(float* yw, int slot, const f32x4& v) {
   for (int r = 0; r < 4; ++r) yw[r * FC_YVN + 16 * slot] = v[r];
 }
 
+// Message columns of 16 edge rows, staged row-major in LDS ([16][RS]), streamed to their message rows with V-float
+// accesses (V = widest vector the column offset and the row length allow).
+template <int V>
+__device__ __forceinline__ void fc_store_rows(const float* __restrict__ stg, int RS, int L, int nrows, const float* __restrict__ erow,
+                                              int ES, int ts_col, float* __restrict__ msg, int c0, int accumulate, int lane) {
+  const int per_row = L / V;
+  for (int idx = lane; idx < nrows * per_row; idx += 64) {
+    const int row = idx / per_row, cv = idx - row * per_row;
+    const int ts = reinterpret_cast<const int*>(erow)[row * ES + ts_col];
+    float* __restrict__ p = msg + (size_t)ts * XS + c0 + V * cv;
+    const float* __restrict__ q = stg + row * RS + V * cv;
+    if (V == 4) {
+      float4 v = *reinterpret_cast<const float4*>(q);
+      if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      *reinterpret_cast<float4*>(p) = v;
+    } else if (V == 2) {
+      float2 v = *reinterpret_cast<const float2*>(q);
+      if (accumulate) { const float2 o = *reinterpret_cast<const float2*>(p); v.x += o.x; v.y += o.y; }
+      *reinterpret_cast<float2*>(p) = v;
+    } else {
+      float v = q[0];
+      if (accumulate) v += p[0];
+      p[0] = v;
+    }
+  }
+}
+
 // Steady-state loop of one granule for the static chain shapes (S0, SN, SN, SN), hidden width a multiple of 8:
 // straight-line code per 8-k group -- the k-invariant x fragments stay in registers, the weight fragments arrive one
 // iteration ahead, and the four slot chains are issued interleaved (a dependent f32 MFMA costs 40 cycles, an independent
@@ -602,13 +630,15 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
 // double-buffered in LDS; per iteration a wave contracts row w of group g+1 (weights requested one iteration earlier),
 // requests the weights of group g+2 and the hidden fragments of g+1, and multiplies group g into its edge accumulators:
 // one barrier per 8 k.  The bias row of the packed second layer (h = 1) is added outside the MFMA loop.
-template <int MAXD, bool GENERIC>
+template <int MAXD, int SHD, bool GENERIC>
 __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
-  constexpr int GS2 = 4 * MAXD + 3, SHS = 11;
+  constexpr int GS2 = 4 * MAXD + 1, ES = SHD + 3, CGN = 4 * MAXD * SHD;
   float* xbuf = smem;                                  // [16][XS+1]
   float* ybuf = xbuf + FC_VN * NC_XS;                  // [2][16 x FC_YVN]
-  float* gscr = ybuf + 2 * FC_YB;                      // per wave: [32][GS2] coupling rows + [32][SHS] sh rows
+  float* gscr = ybuf + 2 * FC_YB;                      // per wave: [32][GS2] coupling rows of the current (granule, virtual node)
+  float* escr = gscr + FC_WAVES * 32 * GS2;            // per wave: [2][32][ES] edge rows: sh (SHD), weight, message row
+  float* cgt = escr + FC_WAVES * 2 * 32 * ES;          // [granules of this workgroup][4 slots][MAXD][SHD] dense coupling rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = DDMI_UNIFORM(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -620,7 +650,22 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     const int nl = idx / XS, c = idx - nl * XS;
     xbuf[nl * NC_XS + c] = nl < nv_live ? a.X[(size_t)(a.gbase + a.vn_node[v0 + nl]) * XS + c] : 0.f;
   }
+  const int g_begin = a.gsplit[blockIdx.y], g_end = a.gsplit[blockIdx.y + 1];
+  // dense coupling rows of this workgroup's granules: cgt[g][s][k'][j] = C_path(s)[comp(s)][j - s_off][k'] (0 outside the path's sh block)
+  for (int idx = tid; idx < (g_end - g_begin) * CGN; idx += 64 * FC_WAVES) {
+    const int gl = idx / CGN, rem = idx - gl * CGN;
+    const int sl = rem / (MAXD * SHD), k = (rem / SHD) % MAXD, j = rem % SHD;
+    const FGran& Gq = a.gran[g_begin + gl];
+    float v = 0.f;
+    if (Gq.g[sl] >= 0 && k < Gq.dout) {
+      const GEntry E = a.gmap[Gq.g[sl] + k];
+      if (j >= E.s_off && j < E.s_off + E.ds) v = a.ctab[E.c_idx + (j - E.s_off) * E.dout];
+    }
+    cgt[idx] = v;
+  }
   int ve0[2], vne[2];
+  float* gw = gscr + wave * 32 * GS2;
+  float* ew_ = escr + wave * 2 * 32 * ES;
 #pragma unroll
   for (int vi = 0; vi < 2; ++vi) {
     const int v = v0 + 2 * wave + vi;
@@ -629,16 +674,31 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       ve0[vi] = a.vn_e0[v];
       vne[vi] = min(32, a.goff[a.vn_node[v] + 1] - ve0[vi]);
     }
+    if (lane < 32) {   // per-edge rows, shared by all granules: spherical harmonics, edge weight, message row
+      float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float we = 0.f;
+      int ts = 0;
+      if (lane < vne[vi]) {
+        const int e = ve0[vi] + lane;
+        const int ar = a.arow ? a.arow[e] : e;
+        edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
+        we = a.ew ? a.ew[ar] : 1.f;
+        ts = a.tslot[e];
+      }
+      float* er = ew_ + (vi * 32 + lane) * ES;
+#pragma unroll
+      for (int j = 0; j < SHD; ++j) er[j] = sh[j];
+      er[SHD] = we;
+      reinterpret_cast<int*>(er)[SHD + 1] = ts;
+    }
   }
-  float* gw = gscr + wave * 32 * (GS2 + SHS);
-  float* shw = gw + 32 * GS2;
   __syncthreads();
   const int H = a.HK - 1;
   const int NG8 = a.NG8;
   const float* __restrict__ hfrag = a.Hb + ((size_t)(v0 + 2 * wave) * 2 * NG8) * 128 + 2 * lane;   // + ((vi*2 + rt)*NG8 + g)*128
   float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
-  for (int gi = a.gsplit[blockIdx.y]; gi < a.gsplit[blockIdx.y + 1]; ++gi) {
+  for (int gi = g_begin; gi < g_end; ++gi) {
     const FGran& Gd = a.gran[gi];
     f32x4 acc[2][2][4];
 #pragma unroll
@@ -647,7 +707,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[vi][rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!Gd.empty) {
+    if (!Gd.empty && !(a.dbg & 128)) {
       const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
@@ -732,7 +792,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       }
       }
       // ---- bias row (k = H, h = 1): waves 0..3 contract one slot each, every edge row receives the node's bias row
-      if (wave < 4) {
+      if (wave < 4 && !(a.dbg & 64)) {
         const FcSlotRt& sb = wave == 0 ? s0 : wave == 1 ? s1 : wave == 2 ? s2 : s3;
         const f32x4 rb = fc_direct(sb, (size_t)H * a.KS);
         fc_store(ybuf + (4 * lq) * FC_YVN + lr, wave, rb);    // row 0 of buffer 0
@@ -750,59 +810,46 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
           }
       }
     }
+    __syncthreads();   // the coupling phase stages message rows in the (now idle) chunk buffers
     // ---- coupling with the spherical harmonics and message stores (wave-local: no workgroup barrier)
+    const float* __restrict__ cg = cgt + (gi - g_begin) * CGN;
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi) {
       const int ne = vne[vi];
-      if (ne == 0) continue;
+      if (ne == 0 || (a.dbg & 32)) continue;
+      const float* __restrict__ erow = ew_ + vi * 32 * ES;
       DDMI_WAVE_SYNC();
-      if (lane < 32) {
-        float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float we = 0.f;
-        int ts = -1;
-        if (lane < ne) {
-          const int e = ve0[vi] + lane;
-          const int ar = a.arow ? a.arow[e] : e;
-          edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
-          we = a.ew ? a.ew[ar] : 1.f;
-          ts = a.tslot[e];
-        }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) shw[lane * SHS + j] = sh[j];
-        gw[lane * GS2 + 4 * MAXD] = we;
-        reinterpret_cast<int*>(gw)[lane * GS2 + 4 * MAXD + 1] = ts;
-      }
-      DDMI_WAVE_SYNC();
-      {
+      {   // G[el][s][k'] = sum_j cg[s][k'][j] * sh_el[j] : lane = (edge row, slot pair)
         const int el = lane & 31, half = lane >> 5;
+        float sh[SHD];
+#pragma unroll
+        for (int j = 0; j < SHD; ++j) sh[j] = erow[el * ES + j];
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
           const int sl = 2 * half + ss;
-          const int g0 = Gd.g[sl];
 #pragma unroll
           for (int k = 0; k < MAXD; ++k) {
             float v = 0.f;
-            if (g0 >= 0 && k < Gd.dout) {
-              const GEntry E = a.gmap[g0 + k];
-              for (int j = 0; j < E.ds; ++j) v = fmaf(a.ctab[E.c_idx + j * E.dout], shw[el * SHS + E.s_off + j], v);
-            }
+#pragma unroll
+            for (int j = 0; j < SHD; ++j) v = fmaf(cg[(sl * MAXD + k) * SHD + j], sh[j], v);
             gw[el * GS2 + sl * MAXD + k] = v;
           }
         }
       }
       DDMI_WAVE_SYNC();
+      {
+        float* stg = ybuf + wave * ((2 * FC_YB) / FC_WAVES);   // the chunk buffers are idle during the coupling phase
+        const int RS = 16 * Gd.dout, L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
+        const int V = ((c0 | L) & 3) == 0 ? 4 : ((c0 | L) & 1) == 0 ? 2 : 1;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        if (ne <= 16 * rt) break;
+        for (int rt = 0; rt < 2; ++rt) {
+          if (ne <= 16 * rt) break;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int el = rt * 16 + 4 * lq + r;
-          const float* __restrict__ G = gw + el * GS2;
-          const float t0 = acc[vi][rt][0][r], t1 = acc[vi][rt][1][r], t2 = acc[vi][rt][2][r], t3 = acc[vi][rt][3][r];
-          const float we = G[4 * MAXD];
-          const int ts = reinterpret_cast<const int*>(G)[4 * MAXD + 1];
-          if (lr < Gd.n_w && el < ne) {
-            float* __restrict__ mp = a.msg + (size_t)ts * XS + Gd.o_off + (Gd.w0 + lr) * Gd.dout;
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * lq + r, el = rt * 16 + row;
+            const float* __restrict__ G = gw + el * GS2;
+            const float t0 = acc[vi][rt][0][r], t1 = acc[vi][rt][1][r], t2 = acc[vi][rt][2][r], t3 = acc[vi][rt][3][r];
+            const float we = erow[el * ES + SHD];
 #pragma unroll
             for (int k = 0; k < MAXD; ++k) {
               if (k < Gd.dout) {
@@ -810,11 +857,19 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
                 v = fmaf(G[MAXD + k], t1, v);
                 v = fmaf(G[2 * MAXD + k], t2, v);
                 v = fmaf(G[3 * MAXD + k], t3, v);
-                v *= we;
-                mp[k] = Gd.accumulate ? mp[k] + v : v;
+                stg[row * RS + lr * Gd.dout + k] = v * we;
               }
             }
           }
+          DDMI_WAVE_SYNC();
+          if (!(a.dbg & 256)) {
+            const int nrows = min(16, ne - 16 * rt);
+            const float* __restrict__ er = erow + rt * 16 * ES;
+            if (V == 4) fc_store_rows<4>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, Gd.accumulate, lane);
+            else if (V == 2) fc_store_rows<2>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, Gd.accumulate, lane);
+            else fc_store_rows<1>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, Gd.accumulate, lane);
+          }
+          DDMI_WAVE_SYNC();
         }
       }
     }
@@ -822,30 +877,33 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   }
 }
 
+template <int MAXD, int SHD>
+static void launch_conv_fused_t(const FusedConvArgs& a, hipStream_t s) {
+  constexpr int GS2 = 4 * MAXD + 1, ES = SHD + 3, CGN = 4 * MAXD * SHD;
+  int max_local = 0;
+  for (int y = 0; y < a.ysplit; ++y) max_local = std::max(max_local, a.gsplit[y + 1] - a.gsplit[y]);
+  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FC_YB + FC_WAVES * 32 * GS2 + FC_WAVES * 2 * 32 * ES + max_local * CGN) * sizeof(float);
+  if (smem > 160 * 1024) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: LDS budget exceeded (raise DDMI_FUSED_YS)");
+  static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per instantiation)
+  if (!lds_opt_in) {
+    const int cap = 160 * 1024;
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    lds_opt_in = true;
+  }
+  dim3 grid(cdiv(a.vcap, FC_VN), a.ysplit);
+  if (a.generic) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, true>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  else hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, false>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
   if (a_in.vcap <= 0 || a_in.ysplit <= 0) return;
   FusedConvArgs a = a_in;
   a.dbg = ablate_mask();
-  const int maxd = a.maxd <= 3 ? 3 : 5;
-  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FC_YB + FC_WAVES * 32 * (4 * maxd + 3 + 11)) * sizeof(float);
-  dim3 grid(cdiv(a.vcap, FC_VN), a.ysplit);
-  static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per process)
-  if (!lds_opt_in) {
-    const int cap = 160 * 1024;
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    lds_opt_in = true;
-  }
-  if (a.generic) {
-    if (maxd == 3) hipLaunchKernelGGL((k_conv_fused<3, true>), grid, dim3(64 * FC_WAVES), smem, s, a);
-    else hipLaunchKernelGGL((k_conv_fused<5, true>), grid, dim3(64 * FC_WAVES), smem, s, a);
-  } else {
-    if (maxd == 3) hipLaunchKernelGGL((k_conv_fused<3, false>), grid, dim3(64 * FC_WAVES), smem, s, a);
-    else hipLaunchKernelGGL((k_conv_fused<5, false>), grid, dim3(64 * FC_WAVES), smem, s, a);
-  }
-  DDMI_CHECK_HIP(hipGetLastError());
+  if (a.maxd <= 3 && a.sh_lmax <= 1) launch_conv_fused_t<3, 4>(a, s);
+  else if (a.maxd <= 3) launch_conv_fused_t<3, 9>(a, s);
+  else launch_conv_fused_t<5, 9>(a, s);
 }
 
 // ---------------------------------------------------------------------- reduce + BN

@@ -151,3 +151,36 @@ def test_crop_with_embedding_layers_matches_oracle(emu_lib):
     keep = m.debug_buffer("crop_keep")
     assert 0 < keep.sum() < keep.size
     assert (pos.reshape(B, -1, 3) - ref).abs().max() < 2e-3
+
+@pytest.mark.parametrize("lmax", [1, 2])
+def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
+    """DDL-synth channel widths (ns=48, nv=10) on a small complex: the statically-shaped main loop of k_conv_fused
+    (chain shapes (12,3,3,3)/(3,3,3,3)/(12,-,-,-)), the generic variant at sh_lmax=2, receptor residues with more than 32
+    ligand neighbours (two virtual nodes per residue, accumulate granules), against the oracle and the unfused kernels."""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = replace(DDL_SYNTH, num_conv_layers=2, sh_lmax=lmax, lm_embedding_type=None, dynamic_max_cross=False,
+                  cross_max_distance=80.0, tr_sigma_max=5.0)
+    sd = init_state_dict(cfg, seed=3)
+    g = make_complex(seed=1, n_res=12, n_lig=40, lm_dim=0)
+    dl = make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.3)
+    b = HeteroBatch.from_data_list(dl)
+    set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+    so3_t, tor_t = tables()
+    ref = CGModelOracle(cfg, sd, so3_t, tor_t)(b)[:3]
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DDMI_FUSED", fused)
+        m = make_model(cfg, sd, emu_lib)
+        m.set_kernel_timing(True)
+        outs[fused] = m(b)[:3]
+        launched = m.kernel_timings()
+        assert ("k_conv_fused" in launched) == (fused == "1")
+        if fused == "1":
+            assert int(m.debug_buffer("vn_off_cross")[-1]) == 2 * b["receptor"].pos.shape[0]   # 40 neighbours -> 2 virtual nodes
+        for o, r in zip(outs[fused], ref):
+            assert rel_err(o, r) < 1e-4
+    for a_, b_ in zip(outs["1"], outs["0"]):
+        assert rel_err(a_, b_) < 1e-5
