@@ -147,7 +147,14 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const int wg = std::min<int>((int)gi, L.G - 1);
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
-    {
+    const bool fuse = m.fused && g.vn >= 0 && !side && L.n_fgran > 0 && c.Hb;
+    const bool fuse_mm = fuse && m.fused_mm && ns % 16 == 0 && ns <= 64;   // first Linear inside the hidden-row kernel
+    if (fuse_mm) {
+      PhaseTimer t(m, "conv_fc1_gemms", gs);
+      if (g.sig) { gemm(g.sig, ns, W1, L.n_edge, nullptr, rowbias, H, c.B, H, ns, 0, gs); rb = rowbias; }
+      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
+      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
+    } else {
       PhaseTimer t(m, "conv_fc1_gemms", gs);
       if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]
         gemm(g.sig, ns, W1, L.n_edge, nullptr, rowbias, H, c.B, H, ns, 0, gs);
@@ -157,7 +164,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
       gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
     }
-    if (m.fused && g.vn >= 0 && !side && L.n_fgran > 0 && c.Hb) {
+    if (fuse) {
       Cx::VnSet& vs = c.vn[g.vn];
       if (vs.built_goff != g.goff || vs.epoch != c.epoch) {
         PhaseTimer t(m, "vn_build", gs);
@@ -165,7 +172,14 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         vs.built_goff = g.goff; vs.epoch = c.epoch;
       }
       const int* nvn = vs.voff + g.gcount;
-      {
+      if (fuse_mm) {
+        PhaseTimer t(m, "k_edge_hidden", gs);
+        EdgeHiddenArgs h{};
+        h.nvn = nvn; h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
+        h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = W1; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
+        h.H = H; h.NG8 = L.HKq / 8; h.Hb = c.Hb;
+        launch_edge_hidden_mm(h, gs);
+      } else {
         PhaseTimer t(m, "k_edge_hidden", gs);
         launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, c.Hb, gs);
       }

@@ -431,6 +431,106 @@ void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int*
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
+__device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// One wave per virtual node (grid-stride), the edge-attribute block of the first Linear in LDS.  The product is taken
+// transposed -- D[hidden k][edge row] = W[k][:] . attr[row][:] with the weights as the A operand -- so that lane
+// (row, q) ends up with 4 consecutive hidden values of ITS row: exactly two (k pair) slots of the fragment order
+// Hb[v][rt][g][16q' + row][sub], k = 8g + 2q' + sub.  The target-node term P[tgt], Q[d] (+ the per-graph term) are
+// added as 16-B row pieces, relu applied, and each lane writes two 8-B pieces (16 lanes = 128 contiguous bytes).
+// k-permuted MFMA steps: lane (row, q) fetches floats [q*ns/4, (q+1)*ns/4) of its attribute row with 16-B loads; step t
+// multiplies attr[row][q*ns/4 + t] with W[k][q*ns/4 + t].
+template <int NSQ>   // ns = 16 * NSQ, H = 3 * ns
+__global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
+  DDMI_DYN_SMEM(float, smem);
+  constexpr int KS = 4 * NSQ;                        // MFMA steps = floats per lane quarter
+  constexpr int H = 48 * NSQ, NB = H / 16, NG8 = H / 8;
+  float* wl = smem;                                  // [KS][4][H]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = DDMI_UNIFORM(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int nvn = *a.nvn;
+  if ((int)blockIdx.x * 4 >= nvn) return;
+  for (int idx = tid; idx < H * 4 * KS; idx += 256) {   // k fastest: coalesced reads of the weight rows
+    const int k = idx % (4 * KS), n = idx / (4 * KS);
+    const int q = k / KS, t = k - q * KS;
+    wl[(t * 4 + q) * H + n] = a.W1[(size_t)n * a.ldw + k];
+  }
+  __syncthreads();
+  for (int v = blockIdx.x * 4 + wave; v < nvn; v += gridDim.x * 4) {
+    const int d = a.vn_node[v], e0 = a.vn_e0[v];
+    const int ne = min(32, a.goff[d + 1] - e0);
+    const int ar0 = a.arow ? a.arow[e0] : e0;
+    const float* __restrict__ qrow = a.Q + (size_t)d * H + 4 * lq;
+    const float* __restrict__ rbrow = a.rowbias ? a.rowbias + (size_t)a.ridx[ar0] * H + 4 * lq : nullptr;
+#pragma unroll 1
+    for (int rt = 0; rt < 2; ++rt) {
+      // lane (row lr, q) owns hidden k = 16nb + 4q + {0..3}: group g = 2nb + (q >> 1), fragment lanes 16(2(q&1) + {0,1}) + row
+      float* __restrict__ hp = a.Hb + (((size_t)v * 2 + rt) * NG8 + (lq >> 1)) * 128 + (32 * (lq & 1) + lr) * 2;
+      const int el = 16 * rt + lr;
+      const bool live = el < ne;
+      if (16 * rt >= ne) {   // empty row tile: zero fragments
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          *reinterpret_cast<float2*>(hp + (size_t)nb * 256) = make_float2(0.f, 0.f);
+          *reinterpret_cast<float2*>(hp + (size_t)nb * 256 + 32) = make_float2(0.f, 0.f);
+        }
+        continue;
+      }
+      float4 ae[NSQ];
+      const float* __restrict__ prow = a.P + 4 * lq;
+      if (live) {
+        const int e = e0 + el;
+        const int ar = a.arow ? a.arow[e] : e;
+        const float* __restrict__ ep = a.ea + (size_t)ar * a.ns + KS * lq;
+        prow += (size_t)(a.tgt[e] - a.tbase) * H;
+#pragma unroll
+        for (int j = 0; j < NSQ; ++j) ae[j] = *reinterpret_cast<const float4*>(ep + 4 * j);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NSQ; ++j) ae[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float4 pq = *reinterpret_cast<const float4*>(qrow + 16 * nb);
+        if (rbrow) { const float4 t = *reinterpret_cast<const float4*>(rbrow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
+        if (live) { const float4 t = *reinterpret_cast<const float4*>(prow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
+        f32x4 acc = f32x4{pq.x, pq.y, pq.z, pq.w}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: a dependent f32 MFMA waits 40 cycles
+        const float* __restrict__ wp = wl + lq * H + 16 * nb + lr;
+#pragma unroll
+        for (int j = 0; j < NSQ; ++j) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 0) * 4 * H], ae[j].x, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 1) * 4 * H], ae[j].y, acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 2) * 4 * H], ae[j].z, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 3) * 4 * H], ae[j].w, acc2, 0, 0, 0);
+        }
+        float2 o0 = make_float2(0.f, 0.f), o1 = o0;
+        if (live) {
+          o0.x = fmaxf(acc[0] + acc2[0], 0.f); o0.y = fmaxf(acc[1] + acc2[1], 0.f);
+          o1.x = fmaxf(acc[2] + acc2[2], 0.f); o1.y = fmaxf(acc[3] + acc2[3], 0.f);
+        }
+        *reinterpret_cast<float2*>(hp + (size_t)nb * 256) = o0;
+        *reinterpret_cast<float2*>(hp + (size_t)nb * 256 + 32) = o1;
+      }
+    }
+  }
+}
+
+void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {
+  if (a.vcap <= 0) return;
+  if (a.ns % 16 != 0 || a.ns > 64 || a.H != 3 * a.ns || a.NG8 * 8 != a.H)
+    throw Error(DDMI_ERR_ARG, "k_edge_hidden_mm: unsupported width");
+  const size_t smem = (size_t)(a.ns * a.H) * sizeof(float);
+  const int grid = std::min(cdiv(a.vcap, 4), 2048);
+  switch (a.ns / 16) {
+    case 1: hipLaunchKernelGGL(k_edge_hidden_mm<1>, dim3(grid), dim3(256), smem, s, a); break;
+    case 2: hipLaunchKernelGGL(k_edge_hidden_mm<2>, dim3(grid), dim3(256), smem, s, a); break;
+    case 3: hipLaunchKernelGGL(k_edge_hidden_mm<3>, dim3(grid), dim3(256), smem, s, a); break;
+    default: hipLaunchKernelGGL(k_edge_hidden_mm<4>, dim3(grid), dim3(256), smem, s, a); break;
+  }
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 constexpr int FC_VN = 16, FC_KC = 8, FC_WAVES = 8, FC_CAP0 = 12, FC_CAPN = 4;
 // chunk buffer in LDS: [16 nodes][8 rows][64 columns], column = 16*slot + w; padded strides keep the transposing stores
 // (lanes = 16 w x 4 node quarters) and the B-fragment loads (lanes = 16 w x rows 2q + sub) on 64 distinct banks

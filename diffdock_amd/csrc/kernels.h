@@ -84,6 +84,23 @@ void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* 
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                         const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
                         float* Hb, hipStream_t s);
+// Hidden rows of the edge MLP from the edge attributes in one pass (ns % 16 == 0): first Linear split over its inputs,
+//   h_e = relu(W1e * edge_attr[arow[e]] + P[tgt[e]] + Q[d] (+ rowbias[ridx])),  P = W1s * x_s[:ns], Q = W1d * x_d[:ns] + b1,
+// edge-attribute block on the matrix cores, written straight in the A-fragment order of k_conv_fused (replaces the
+// per-edge GEMM + k_edge_hidden).
+struct EdgeHiddenArgs {
+  const int* nvn; int vcap; const int* vn_node; const int* vn_e0; const int* goff;
+  const int* arow; const int* tgt; int tbase;
+  const float* ea; int ns;            // [rows][ns] edge attribute rows
+  const float* W1; int ldw;           // [H][ldw]: columns [0,ns) multiply the edge attributes
+  const float* P;                     // [tcount][H], row tgt[e] - tbase
+  const float* Q;                     // [gcount][H]
+  const float* rowbias; const int* ridx;   // optional per-graph term [B][H], graph of attr row
+  int H, NG8;
+  float* Hb;
+};
+void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s);
+
 struct FusedConvArgs {
   const int* nvn; int vcap;              // live virtual nodes (device) and their capacity (grid size)
   const int* vn_node; const int* vn_e0;  // [vcap] gather node (local), first edge
