@@ -55,9 +55,11 @@ def t_schedule(steps):
     return np.linspace(1, 0, steps + 1)[:-1]      # get_t_schedule('expbeta', alpha=beta=1), diffusion_utils.py:138-142
 
 
-def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr):
-    """Algorithmic flops / HBM bytes of every (layer, edge group) launch of the two convolution kernels for one
-    forward pass.  NT = columns of a contracted node row (sum over paths of din*mul_out)."""
+def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr, fused=True):
+    """Algorithmic flops / bytes of every (layer, edge group) launch of the convolution kernels of one forward pass
+    (DESIGN.md section 4).  NT = columns of a contracted node row (sum over paths of din*mul_out), K = 3ns + 1.
+    Receptor-gather groups run k_conv_fused (contracted rows stay in LDS: its HBM bytes are the x rows, the hidden rows
+    and the messages); ligand-gather groups run k_node_contract + k_edge_conv with the rows Y in HBM."""
     from diffdock_amd.irreps import parse_irreps, sh_irreps
     from diffdock_amd.o3 import faster_path_table, fctp_path_table
     out = []
@@ -69,13 +71,18 @@ def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr):
         NT = sum(p.di * p.mul_out for p in table)
         mac_node = sum(p.mul_in * p.mul_out * p.di for p in table)
         d_in, d_out = sum(x.dim for x in parse_irreps(a)), sum(x.dim for x in parse_irreps(b))
-        groups = [(nL, nL, e_ll), (nR, nL, e_lr), (nR, nR, e_rr), (nL, nR, e_lr)]      # (gather nodes, target nodes, edges)
-        for gcount, tcount, E in (groups if l < L - 1 else groups[:2]):
+        # (gather nodes, target nodes, edges, gather side is receptor)
+        groups = [(nL, nL, e_ll, False), (nR, nL, e_lr, True), (nR, nR, e_rr, True), (nL, nR, e_lr, False)]
+        for gcount, tcount, E, rec_gather in (groups if l < L - 1 else groups[:2]):
             H = 3 * cfg.ns
-            out.append({"k_edge_conv": {"flops": 2.0 * E * HK * NT,
-                                        "bytes": gcount * HK * NT * 4.0 + E * (H * 4.0 + d_out * 4.0) + (gcount + tcount) * H * 4.0},
-                        "k_node_contract": {"flops": 2.0 * gcount * HK * mac_node,
-                                            "bytes": gcount * (HK * NT * 4.0 + d_in * 4.0)}})
+            node_flops, edge_flops = 2.0 * gcount * HK * mac_node, 2.0 * E * HK * NT
+            if fused and rec_gather:
+                out.append({"k_conv_fused": {"flops": node_flops + edge_flops,
+                                             "bytes": gcount * d_in * 4.0 + E * (H * 4.0 + d_out * 4.0)}})
+            else:
+                out.append({"k_edge_conv": {"flops": edge_flops,
+                                            "bytes": gcount * HK * NT * 4.0 + E * (H * 4.0 + d_out * 4.0) + (gcount + tcount) * H * 4.0},
+                            "k_node_contract": {"flops": node_flops, "bytes": gcount * (HK * NT * 4.0 + d_in * 4.0)}})
     return out
 
 
@@ -175,13 +182,14 @@ def main():
         kern = {k: v for k, v in timings.items() if k.startswith("k_") or k == "conv_fc1_gemms"}
         dom = max(kern, key=lambda k: kern[k][0]) if kern else None
         roof = None
-        if dom in ("k_edge_conv", "k_node_contract"):
+        if dom in ("k_edge_conv", "k_node_contract", "k_conv_fused"):
             ms, n = kern[dom]
             avg_s = ms / max(n, 1) * 1e-3
-            work = conv_work(cfg, B * N_LIG, B * N_RES, e_ll, e_lr, e_rr)
+            work = [w[dom] for w in conv_work(cfg, B * N_LIG, B * N_RES, e_ll, e_lr, e_rr, fused="k_conv_fused" in kern)
+                    if dom in w]
             launches_per_forward = len(work)
-            flops = sum(w[dom]["flops"] for w in work) / launches_per_forward
-            bytes_ = sum(w[dom]["bytes"] for w in work) / launches_per_forward
+            flops = sum(w["flops"] for w in work) / launches_per_forward
+            bytes_ = sum(w["bytes"] for w in work) / launches_per_forward
             ridge = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
             if flops / bytes_ > ridge:
                 ach = flops / avg_s / 1e12
@@ -193,9 +201,13 @@ def main():
                         "frac": ach / HBM_PEAK_GBS, "traffic": None}
             roof.update({"avg_launch_ms": avg_s * 1e3, "launches": n, "launches_per_forward": launches_per_forward,
                          "alg_flops_per_launch": flops, "alg_bytes_per_launch": bytes_,
-                         "alg_definition": "mean over the launches of one forward; edge_conv: 2*145*NT flop/edge, bytes = contracted "
-                                           "rows Y (145*NT*4 B per gather node) + 576 B first-layer row + 624 B message per edge; "
-                                           "node_contract: 2*145*sum(mul_in*mul_out*din) flop and 145*NT*4 B written per gather node"})
+                         "concurrent_streams": 1 if os.environ.get("DDMI_STREAMS") == "1" else 2,
+                         "alg_definition": "mean over the launches of this kernel in one forward (exact f32 on v_mfma_f32_16x16x4_f32, "
+                                           "peak = dense f32 MFMA); k_conv_fused: 2*145*sum(mul_in*mul_out*din) flop per gather node "
+                                           "+ 2*145*NT flop per edge, bytes = x rows + 576 B hidden row + 624 B message per edge; "
+                                           "k_edge_conv: 2*145*NT flop/edge, bytes = contracted rows Y (145*NT*4 B per gather node) + "
+                                           "hidden + message rows; k_node_contract: node flops, Y written once.  With 2 streams the "
+                                           "ligand-gather kernels run concurrently, so launch durations include their share of the chip"})
         cpu = None if args.no_cpu_baseline else cpu_baseline(cfg, sd, so3_t, tor_t, g)
         out = {
             "metric": "poses/sec (20 steps x 40 samples, DiffDock-L score model)", "value": world * B * args.steps / dt,

@@ -42,9 +42,9 @@ struct Model::Cx {
   // rebuilt when the edge list they were built for changes (once per forward), and the hidden-row scratch
   struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr;
                  const int* built_goff = nullptr; long epoch = -1; };
-  VnSet vn[2];
+  VnSet vn[4];           // + 2 = ligand-ligand, 3 = rec<-lig (ligand gather nodes: load mode)
   long epoch = 0;
-  float* Hb = nullptr;
+  float *Hb = nullptr, *Hb_b = nullptr;   // hidden rows of the main-stream / side-stream group in flight
   ReduceGroup *rg_all, *rg_lig, *rg_ll, *rg_rr;
   // read-outs
   float *c_dist, *c_nvec, *c_ea, *c_attr, *c_hid, *c_W, *c_sh, *c_out, *gp;
@@ -147,7 +147,9 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const int wg = std::min<int>((int)gi, L.G - 1);
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
-    const bool fuse = m.fused && g.vn >= 0 && !side && L.n_fgran > 0 && c.Hb;
+    const bool load_mode = g.vn >= 2;   // ligand gather nodes: contracted rows from k_node_contract, shared by the node's virtual nodes
+    const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb && (!load_mode || (m.fused_lig && c.y_chunk <= 0));
+    float* Hb = side ? c.Hb_b : c.Hb;
     const bool fuse_mm = fuse && m.fused_mm && ns % 16 == 0 && ns <= 64;   // first Linear inside the hidden-row kernel
     if (fuse_mm) {
       PhaseTimer t(m, "conv_fc1_gemms", gs);
@@ -177,15 +179,15 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         EdgeHiddenArgs h{};
         h.nvn = nvn; h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
         h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = W1; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
-        h.H = H; h.NG8 = L.HKq / 8; h.Hb = c.Hb;
+        h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb;
         launch_edge_hidden_mm(h, gs);
       } else {
         PhaseTimer t(m, "k_edge_hidden", gs);
-        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, c.Hb, gs);
+        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs);
       }
       FusedConvArgs f{};
       f.nvn = nvn; f.vcap = vs.vcap; f.vn_node = vs.node; f.vn_e0 = vs.e0; f.goff = g.goff; f.tslot = g.tslot; f.arow = g.arow;
-      f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = c.Hb; f.NG8 = L.HKq / 8;
+      f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
       f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.gmap = L.gmap;
       f.ctab = L.ctab; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
       const int ys = std::max(1, std::min(std::min(m.fused_ysplit, 8), L.n_fgran));
@@ -197,7 +199,14 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         f.gsplit[y] = std::max(b, f.gsplit[y - 1]);
       }
       f.gsplit[ys] = L.n_fgran;
-      PhaseTimer t(m, "k_conv_fused", gs);
+      if (load_mode) {
+        {
+          PhaseTimer t(m, "k_node_contract", gs);
+          launch_node_contract(Xin, g.gbase, g.gcount, L.wpack[wg], L.nc_units, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, Y, gs, L.n_fgran);
+        }
+        f.Yg = Y; f.HKp = L.HKp; f.n_gran = L.n_fgran;
+      }
+      PhaseTimer t(m, load_mode ? "k_conv_fused_load" : "k_conv_fused", gs);
       launch_conv_fused(f, gs);
       continue;
     }
@@ -404,22 +413,30 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   if (const char* e = getenv("DDMI_Y_CHUNK")) c.y_chunk = atoi(e);
   if (const char* e = getenv("DDMI_ESPLIT")) c.esplit_lig = std::max(0, atoi(e));
   const int y_nodes = c.y_chunk > 0 ? std::min(c.y_chunk, std::max(nL, nR)) : std::max(nL, nR);
-  c.Y = dalloc<float>(m, nullptr, {y_nodes, HKp, NTs}, true);
-  c.Y_b = dalloc<float>(m, nullptr, {c.y_chunk > 0 ? std::min(c.y_chunk, nL) : nL, HKp, NTs}, true);
+  int ycols = NTs;   // granule-major rows (load mode of k_conv_fused) are 64 columns per granule
+  for (auto& L : m.conv_layers) ycols = std::max(ycols, 64 * L.n_fgran);
+  for (auto& L : m.lig_emb_layers) ycols = std::max(ycols, 64 * L.n_fgran);
+  c.Y = dalloc<float>(m, nullptr, {y_nodes, HKp, ycols}, true);
+  c.Y_b = dalloc<float>(m, nullptr, {c.y_chunk > 0 ? std::min(c.y_chunk, nL) : nL, HKp, ycols}, true);
   if (m.fused) {
     int HKq = 0;
     for (auto& L : m.conv_layers) HKq = std::max(HKq, L.HKq);
     for (auto& L : m.rec_emb_layers) HKq = std::max(HKq, L.HKq);
-    const int ecap_v[2] = {c.Elr_cap, c.Err};
-    int vmax = 0;
-    for (int i = 0; i < 2; ++i) {
+    for (auto& L : m.lig_emb_layers) HKq = std::max(HKq, L.HKq);
+    const int ecap_v[4] = {c.Elr_cap, c.Err, c.Ell_cap, c.Elr_cap};
+    const int gn_v[4] = {nR, nR, nL, nL};
+    const char* names[4] = {"vn_off_cross", "vn_off_rr", "vn_off_ll", "vn_off_rl"};
+    int vmax = 0, vmax_b = 0;
+    for (int i = 0; i < 4; ++i) {
       Cx::VnSet& vs = c.vn[i];
-      vs.vcap = nR + ecap_v[i] / 32 + 1;
-      vs.cnt = dalloc<int>(m, nullptr, {nR + 1}); vs.voff = dalloc<int>(m, i == 0 ? "vn_off_cross" : "vn_off_rr", {nR + 1});
+      vs.vcap = gn_v[i] + ecap_v[i] / 32 + 1;
+      vs.cnt = dalloc<int>(m, nullptr, {gn_v[i] + 1}); vs.voff = dalloc<int>(m, names[i], {gn_v[i] + 1});
       vs.node = dalloc<int>(m, nullptr, {vs.vcap}); vs.e0 = dalloc<int>(m, nullptr, {vs.vcap});
       vmax = std::max(vmax, vs.vcap);
+      if (i >= 2) vmax_b = std::max(vmax_b, vs.vcap);
     }
     c.Hb = HKq > 0 ? dalloc<float>(m, nullptr, {vmax, 32, HKq}) : nullptr;
+    c.Hb_b = HKq > 0 ? dalloc<float>(m, nullptr, {vmax_b, 32, HKq}) : nullptr;
   }
   const int ecap[4] = {c.Ell_cap, c.Elr_cap, c.Err, c.Elr_cap};
   for (int g = 0; g < 4; ++g) c.msg[g] = dalloc<float>(m, nullptr, {ecap[g], XS});
@@ -546,8 +563,9 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     a.feat = c.bond_attr; a.featidx = c.ll_featidx; a.nfeat = m.nf; a.W0f = m.lig_edge.W0; a.ldw0f = m.lig_edge.in;
     launch_edge_mlp(a, s);
   }
-  const RunGroup g_ll{0, nL, 0, nL, c.goff_ll, c.ll_tgt, c.ll_tslot, nullptr, c.ll_ea, c.Ell_cap, c.goff_ll + nL, nullptr,
-                      nullptr, c.ll_nvec, c.ll_ew, 1.f, c.msg[0]};
+  RunGroup g_ll{0, nL, 0, nL, c.goff_ll, c.ll_tgt, c.ll_tslot, nullptr, c.ll_ea, c.Ell_cap, c.goff_ll + nL, nullptr,
+                nullptr, c.ll_nvec, c.ll_ew, 1.f, c.msg[0]};
+  g_ll.vn = 2;
   int xi = 0;
   for (size_t i = 0; i < m.lig_emb_layers.size(); ++i, ++xi)
     run_conv(m, m.lig_emb_layers[i], {g_ll}, c.rg_ll, 1, c.X[xi], c.X[xi + 1], 0, nL, s);
@@ -598,7 +616,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
                       1.f, c.msg[2]};
   RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                 nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
-  g_lr.vn = 0; g_rr.vn = 1;
+  g_lr.vn = 0; g_rr.vn = 1; g_rl.vn = 3;
   // ligand gather nodes carry up to Nr edges each: their 32-edge passes are dealt over several workgroups
   g_rl.esplit = c.esplit_lig > 0 ? c.esplit_lig : std::max(1, std::min(8, (c.Elr_cap / std::max(nL, 1) + 63) / 64));
   const int Lc = (int)m.conv_layers.size();

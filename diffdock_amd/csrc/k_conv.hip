@@ -99,7 +99,7 @@ __device__ __forceinline__ void nc_slot(const NcSlotRt& R, size_t koff, f32x4& a
 __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
                                                        const float* __restrict__ wpack,
                                                        const NcUnit* __restrict__ units, int n_units, int KS, int HK,
-                                                       int HKp, int NTs, float* __restrict__ Y, int dbg) {
+                                                       int HKp, int NTs, float* __restrict__ Y, int dbg, int n_gran) {
   DDMI_DYN_SMEM(float, smem);
   float* xbuf = smem;                                   // [32][XS+1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,12 +113,13 @@ __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restric
   __syncthreads();
   const int lr = lane & 15, lq = lane >> 4;
   const int n_live = min(NC_NODES, gcount - node0);
-  const size_t node_stride = (size_t)n_super * HKp * 64;
+  const size_t node_stride = n_gran > 0 ? (size_t)n_gran * HKp * 64 : (size_t)n_super * HKp * 64;
   for (int it = wave; it < n_units; it += 4) {
     const NcUnit& U = units[it];
     if (U.n_w == 0) continue;
     const int col = U.col_base + (U.w0 + lr) * U.itemw;
     for (int q = 0; q < (U.itemw >> 2); ++q) {
+      if (n_gran > 0 && U.gran[q] < 0) continue;
       const NcSlotRt s0 = nc_slot_setup(U.slot[4 * q + 0], wpack, xbuf, U.w0, lr, lq);
       const NcSlotRt s1 = nc_slot_setup(U.slot[4 * q + 1], wpack, xbuf, U.w0, lr, lq);
       const NcSlotRt s2 = nc_slot_setup(U.slot[4 * q + 2], wpack, xbuf, U.w0, lr, lq);
@@ -132,7 +133,16 @@ __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restric
         nc_slot(s1, koff, a10, a11, dbg);
         nc_slot(s2, koff, a20, a21, dbg);
         nc_slot(s3, koff, a30, a31, dbg);
-        if (lr < U.n_w && !(dbg & 2048)) {
+        if (n_gran > 0) {   // granule-major rows: column 16 * (slot position) + w, all 16 lanes (padding w are zero-weight columns)
+          float* __restrict__ yg = Y + (size_t)node0 * node_stride + ((size_t)U.gran[q] * HKp + k) * 64 + lr;
+          const int p0 = 16 * U.perm[4 * q], p1 = 16 * U.perm[4 * q + 1], p2 = 16 * U.perm[4 * q + 2], p3 = 16 * U.perm[4 * q + 3];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n0 = 4 * lq + r;
+            if (n0 < n_live) { float* y = yg + (size_t)n0 * node_stride; y[p0] = a00[r]; y[p1] = a10[r]; y[p2] = a20[r]; y[p3] = a30[r]; }
+            if (n0 + 16 < n_live) { float* y = yg + (size_t)(n0 + 16) * node_stride; y[p0] = a01[r]; y[p1] = a11[r]; y[p2] = a21[r]; y[p3] = a31[r]; }
+          }
+        } else if (lr < U.n_w && !(dbg & 2048)) {
           float* __restrict__ yk = yp + (size_t)k * 64;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -147,12 +157,12 @@ __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restric
 }
 
 void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcUnit* units, int n_units,
-                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s) {
+                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s, int n_gran) {
   if (gcount <= 0 || n_units <= 0) return;
   const size_t smem = (size_t)(NC_NODES * NC_XS) * sizeof(float);
   dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, NC_KC));
   hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, units, n_units, KS, HK, HKp, NTs, Y,
-                     ablate_mask());
+                     ablate_mask(), n_gran);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -724,13 +734,95 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
 #undef FC_LOADH
 }
 
+// Load mode (gather nodes with many edges each, e.g. ligand atoms towards all residues): the contracted rows come
+// precomputed from k_node_contract (granule-major), one copy per DISTINCT gather node of the tile (slot table stab:
+// [0,16) node of slot, [16,32) slot of virtual node, [32] slot count) -- a tile of 16 virtual nodes usually shares one or
+// two rows.  Same pipeline as the compute modes: rows of group g+2 are requested while group g is multiplied.
+__device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][4], const float* __restrict__ yg, size_t node_stride,
+                                                 const int* stab, int NG8, const float* __restrict__ hfrag, const int (&vne)[2],
+                                                 const int (&vslot)[2], float* ybuf, int tid, int lr, int lq) {
+  const int nslots = stab[32];
+  const int ls = tid >> 7, row = (tid >> 4) & 7, c4 = tid & 15;
+  const float* src[4];
+  bool on[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    on[p] = 4 * p + ls < nslots;
+    src[p] = yg + (on[p] ? (size_t)stab[4 * p + ls] * node_stride : 0) + row * 64 + 4 * c4;
+  }
+  float* dst = ybuf + ls * FC_YVN + row * FC_YROW + 4 * c4;
+  float4 yq[4];
+#define FC_FETCHY(g)                                                                      \
+  do {                                                                                    \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) if (on[p]) yq[p] = nt_load4(src[p] + (size_t)(g) * 512); \
+  } while (0)
+#define FC_STOREY(buf)                                                                    \
+  do {                                                                                    \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p)                                         \
+      if (on[p]) *reinterpret_cast<float4*>(dst + (buf) * FC_YB + 4 * p * FC_YVN) = yq[p]; \
+  } while (0)
+  float2 hC[2][2], hN[2][2];
+  const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
+  const float* __restrict__ hp = hfrag;
+#define FC_LOADH(dst_)                                                                   \
+  do {                                                                                   \
+    dst_[0][0] = *reinterpret_cast<const float2*>(hp);                                   \
+    dst_[0][1] = two0 ? *reinterpret_cast<const float2*>(hp + (size_t)NG8 * 128) : make_float2(0.f, 0.f);     \
+    dst_[1][0] = *reinterpret_cast<const float2*>(hp + (size_t)2 * NG8 * 128);           \
+    dst_[1][1] = two1 ? *reinterpret_cast<const float2*>(hp + (size_t)3 * NG8 * 128) : make_float2(0.f, 0.f); \
+    hp += 128;                                                                           \
+  } while (0)
+  FC_FETCHY(0);
+  FC_LOADH(hC);
+  FC_STOREY(0);
+  if (NG8 > 1) FC_FETCHY(1);
+  __syncthreads();
+  for (int g = 0; g < NG8; ++g) {
+    if (g + 1 < NG8) {
+      FC_STOREY((g + 1) & 1);
+      if (g + 2 < NG8) FC_FETCHY(g + 2);
+      FC_LOADH(hN);
+    }
+    const float* __restrict__ yb0 = ybuf + (g & 1) * FC_YB + (2 * lq) * FC_YROW + lr;
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const float* __restrict__ yb = yb0 + vslot[vi] * FC_YVN + sub * FC_YROW;
+        const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];
+        const float a0 = sub == 0 ? hC[vi][0].x : hC[vi][0].y;
+        acc[vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[vi][0][0], 0, 0, 0);
+        acc[vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[vi][0][1], 0, 0, 0);
+        acc[vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[vi][0][2], 0, 0, 0);
+        acc[vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[vi][0][3], 0, 0, 0);
+        if (vi == 0 ? two0 : two1) {
+          const float a1 = sub == 0 ? hC[vi][1].x : hC[vi][1].y;
+          acc[vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[vi][1][0], 0, 0, 0);
+          acc[vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[vi][1][1], 0, 0, 0);
+          acc[vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[vi][1][2], 0, 0, 0);
+          acc[vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[vi][1][3], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+  }
+#undef FC_FETCHY
+#undef FC_STOREY
+#undef FC_LOADH
+}
+
 // Workgroup = 16 virtual nodes x the granules [gsplit[y], gsplit[y+1]), 8 waves: wave w owns virtual nodes 2w, 2w+1 in the
 // edge GEMM and row w (k = 8g + w) of every 8-row k group g in the node contraction.  A lane's two A values of the edge GEMM
 // over a group (k = 8g + 2q + sub) are one 8-B load of the fragment-ordered hidden rows.  The contracted group is
 // double-buffered in LDS; per iteration a wave contracts row w of group g+1 (weights requested one iteration earlier),
 // requests the weights of group g+2 and the hidden fragments of g+1, and multiplies group g into its edge accumulators:
 // one barrier per 8 k.  The bias row of the packed second layer (h = 1) is added outside the MFMA loop.
-template <int MAXD, int SHD, bool GENERIC>
+// MODE 0: static chain shapes, 1: generic (predicated) contraction, 2: load mode (rows from k_node_contract)
+template <int MAXD, int SHD, int MODE>
 __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
   constexpr int GS2 = 4 * MAXD + 1, ES = SHD + 3, CGN = 4 * MAXD * SHD;
@@ -746,9 +838,24 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   const int v0 = blockIdx.x * FC_VN;
   if (v0 >= nvn) return;
   const int nv_live = min(FC_VN, nvn - v0);
-  for (int idx = tid; idx < FC_VN * XS; idx += 64 * FC_WAVES) {
-    const int nl = idx / XS, c = idx - nl * XS;
-    xbuf[nl * NC_XS + c] = nl < nv_live ? a.X[(size_t)(a.gbase + a.vn_node[v0 + nl]) * XS + c] : 0.f;
+  int* stab = reinterpret_cast<int*>(xbuf);
+  if (MODE == 2) {
+    if (tid == 0) {   // distinct gather nodes of the tile (virtual nodes are sorted by node)
+      int ns_ = 0, prev = -1;
+      for (int i = 0; i < FC_VN; ++i) {
+        if (i < nv_live) {
+          const int node = a.vn_node[v0 + i];
+          if (node != prev) { stab[ns_++] = node; prev = node; }
+        }
+        stab[16 + i] = ns_ > 0 ? ns_ - 1 : 0;
+      }
+      stab[32] = ns_;
+    }
+  } else {
+    for (int idx = tid; idx < FC_VN * XS; idx += 64 * FC_WAVES) {
+      const int nl = idx / XS, c = idx - nl * XS;
+      xbuf[nl * NC_XS + c] = nl < nv_live ? a.X[(size_t)(a.gbase + a.vn_node[v0 + nl]) * XS + c] : 0.f;
+    }
   }
   const int g_begin = a.gsplit[blockIdx.y], g_end = a.gsplit[blockIdx.y + 1];
   // dense coupling rows of this workgroup's granules: cgt[g][s][k'][j] = C_path(s)[comp(s)][j - s_off][k'] (0 outside the path's sh block)
@@ -793,6 +900,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     }
   }
   __syncthreads();
+  int vslot[2] = {2 * wave, 2 * wave + 1};   // chunk-buffer row block of each virtual node
+  if (MODE == 2) { vslot[0] = stab[16 + 2 * wave]; vslot[1] = stab[17 + 2 * wave]; }
   const int H = a.HK - 1;
   const int NG8 = a.NG8;
   const float* __restrict__ hfrag = a.Hb + ((size_t)(v0 + 2 * wave) * 2 * NG8) * 128 + 2 * lane;   // + ((vi*2 + rt)*NG8 + g)*128
@@ -807,12 +916,34 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[vi][rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!Gd.empty && !(a.dbg & 128)) {
+    if (MODE == 2) {
+      if (!Gd.empty) {
+        const size_t nstride = (size_t)a.n_gran * a.HKp * 64;
+        const float* __restrict__ yg = a.Yg + (size_t)gi * a.HKp * 64;
+        fc_mainloop_load(acc, yg, nstride, stab, NG8, hfrag, vne, vslot, ybuf, tid, lr, lq);
+        // bias row (k = H, h = 1) of every slot -> row 0 of buffer 0
+        if (tid < 256 && (tid >> 4) < stab[32])
+          *reinterpret_cast<float4*>(ybuf + (tid >> 4) * FC_YVN + 4 * (tid & 15)) =
+              nt_load4(yg + (size_t)stab[tid >> 4] * nstride + (size_t)H * 64 + 4 * (tid & 15));
+        __syncthreads();
+#pragma unroll
+        for (int vi = 0; vi < 2; ++vi) {
+          const float* __restrict__ yb = ybuf + vslot[vi] * FC_YVN + lr;
+          const float b0 = yb[0], b1 = yb[16], b2 = yb[32], b3 = yb[48];
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[vi][rt][0][r] += b0; acc[vi][rt][1][r] += b1; acc[vi][rt][2][r] += b2; acc[vi][rt][3][r] += b3;
+            }
+        }
+      }
+    } else if (!Gd.empty && !(a.dbg & 128)) {
       const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.w0, lr, lq);
-      if (!GENERIC) {
+      if (MODE == 0) {
         if (Gd.shape == 1) fc_mainloop<12, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
         else if (Gd.shape == 2) fc_mainloop<3, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
         else fc_mainloop<12, 0>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
@@ -987,13 +1118,15 @@ static void launch_conv_fused_t(const FusedConvArgs& a, hipStream_t s) {
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per instantiation)
   if (!lds_opt_in) {
     const int cap = 160 * 1024;
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     lds_opt_in = true;
   }
   dim3 grid(cdiv(a.vcap, FC_VN), a.ysplit);
-  if (a.generic) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, true>), grid, dim3(64 * FC_WAVES), smem, s, a);
-  else hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, false>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  if (a.Yg) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 2>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  else if (a.generic) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 1>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  else hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 0>), grid, dim3(64 * FC_WAVES), smem, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

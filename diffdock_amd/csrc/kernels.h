@@ -37,11 +37,14 @@ struct NcSlot { int x_off, din, comp, mul_in, u_pad, w_pad, wk_off; };   // one 
 struct NcUnit {     // one (output block, 16-wide w tile) unit of the node contraction: n_w items x itemw columns
   int col_base, itemw, w0, n_w;
   NcSlot slot[16];  // slot[s].din == 0 -> padding column (written as 0)
+  int gran[4];      // granule-major output (k_conv_fused load mode): granule of quad q, -1 = padding quad (not stored)
+  int perm[16];     // ... and the position of unit slot 4q + c inside that granule (column 16*perm + w)
 };
 
 // Y[node][st][k][64] (st = 64-column super-tile) = sum_u x[node][x_off + u*din + i] * W2pack[k][path][u][w]
+// n_gran > 0: granule-major output Y[node][granule][k][64] (column 16*slot + w) for the load mode of k_conv_fused
 void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcUnit* units, int n_units,
-                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s);
+                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s, int n_gran = 0);
 
 struct EdgeConvArgs {
   int gcount;            // gather nodes
@@ -109,6 +112,7 @@ struct FusedConvArgs {
   const float* X; int gbase;             // node table (stride XS), first gather node
   const float* wpack; int KS, HK;        // packed second layer [HK][KS]
   const float* Hb; int NG8;              // hidden rows in A-fragment order [vcap][2][NG8][64][2], NG8 = ceil(H / 8)
+  const float* Yg; int HKp, n_gran;      // load mode (gather nodes with many edges): contracted rows [node][granule][HKp][64]
   const float* nvec; const float* ew; float sgn; int sh_lmax;
   const FGran* gran; int ysplit; int gsplit[9];   // blockIdx.y walks granules [gsplit[y], gsplit[y+1])
   const GEntry* gmap; const float* ctab; int maxd;

@@ -298,13 +298,19 @@ static void commit_conv(Model& m, ConvW& L) {
             G.g[sl] = slot_g[4 * q + sl];
             if (G.slot[sl].din != 0) G.empty = 0;
           }
+          U.gran[q] = -1;
           if (G.empty && q > 0) continue;   // padding quad of a wider item: contributes nothing
           // longest chain first: k_conv_fused prefetches 12 weight fragments for slot 0 and 4 for the others
+          int orig[4] = {0, 1, 2, 3};
           for (int i = 1; i < 4; ++i)
             for (int j = i; j > 0; --j) {
               auto steps = [&](int t) { return G.slot[t].din == 0 ? 0 : G.slot[t].u_pad; };
-              if (steps(j) > steps(j - 1)) { std::swap(G.slot[j], G.slot[j - 1]); std::swap(G.g[j], G.g[j - 1]); }
+              if (steps(j) > steps(j - 1)) {
+                std::swap(G.slot[j], G.slot[j - 1]); std::swap(G.g[j], G.g[j - 1]); std::swap(orig[j], orig[j - 1]);
+              }
             }
+          U.gran[q] = (int)fg.size();
+          for (int j = 0; j < 4; ++j) U.perm[4 * q + orig[j]] = j;
           {
             auto st = [&](int t) { return G.slot[t].din == 0 ? 0 : G.slot[t].u_pad / 4; };
             auto fits = [&](int t, int n) { return st(t) == n || st(t) == 0; };

@@ -173,11 +173,13 @@ def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
     outs = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("DDMI_FUSED", fused)
+        monkeypatch.setenv("DDMI_FUSED_LIG", "1" if lmax == 1 else "0")   # lmax 1 also routes the ligand-gather groups (load mode)
         m = make_model(cfg, sd, emu_lib)
         m.set_kernel_timing(True)
         outs[fused] = m(b)[:3]
         launched = m.kernel_timings()
         assert ("k_conv_fused" in launched) == (fused == "1")
+        assert ("k_conv_fused_load" in launched) == (fused == "1" and lmax == 1)
         if fused == "1":
             assert int(m.debug_buffer("vn_off_cross")[-1]) == 2 * b["receptor"].pos.shape[0]   # 40 neighbours -> 2 virtual nodes
         for o, r in zip(outs[fused], ref):
