@@ -99,13 +99,13 @@ __device__ __forceinline__ void nc_slot(const NcSlotRt& R, size_t koff, f32x4& a
 __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
                                                        const float* __restrict__ wpack,
                                                        const NcUnit* __restrict__ units, int n_units, int KS, int HK,
-                                                       int HKp, int NTs, float* __restrict__ Y, int dbg, int n_gran) {
+                                                       int HKp, int NTs, float* __restrict__ Y, int dbg, int n_gran, int kc) {
   DDMI_DYN_SMEM(float, smem);
   float* xbuf = smem;                                   // [32][XS+1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int node0 = blockIdx.x * NC_NODES;
   const int n_super = NTs >> 6;
-  const int k_begin = blockIdx.y * NC_KC, k_end = min(k_begin + NC_KC, HK);
+  const int k_begin = blockIdx.y * kc, k_end = min(k_begin + kc, HK);
   for (int idx = tid; idx < NC_NODES * XS; idx += 256) {
     const int nl = idx / XS, c = idx - nl * XS;
     xbuf[nl * NC_XS + c] = (node0 + nl) < gcount ? X[(size_t)(gbase + node0 + nl) * XS + c] : 0.f;
@@ -160,9 +160,13 @@ void launch_node_contract(const float* X, int gbase, int gcount, const float* wp
                           int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s, int n_gran) {
   if (gcount <= 0 || n_units <= 0) return;
   const size_t smem = (size_t)(NC_NODES * NC_XS) * sizeof(float);
-  dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, NC_KC));
+  // k rows per workgroup: 15 for large node sets (each x tile is read HK/15 times); fewer for small ones (ligand atoms), so
+  // that the launch still spreads over >= ~1500 workgroups
+  int kc = NC_KC;
+  while (kc > 3 && (long)cdiv(gcount, NC_NODES) * cdiv(HK, kc) < 1500) kc -= 2;
+  dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, kc));
   hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, units, n_units, KS, HK, HKp, NTs, Y,
-                     ablate_mask(), n_gran);
+                     ablate_mask(), n_gran, kc);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -204,7 +208,15 @@ __global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
   float* mbuf = gbuf + EC_E * GS;                    // [32][MS]
   float* shbuf = mbuf + EC_E * MS;                   // [32][10]: sh(9), edge weight
   int* ibuf = reinterpret_cast<int*>(shbuf + EC_E * 10);   // [32][3]: arow, tgt - tbase, tslot
-  const int d = blockIdx.x;
+  // (gather node, split) from the linear workgroup id: consecutive ids are dealt round-robin over the 8 XCDs, so the
+  // splits of one node take ids 8 apart -- same XCD, dispatched together -- and share the node's rows Y_d in that L2
+  int d = blockIdx.x, split = 0;
+  if (a.esplit > 1) {
+    const int id = blockIdx.x, blk = 8 * a.esplit;
+    const int base = (id / blk) * 8;
+    if (base + 8 <= a.gcount) { d = base + id % 8; split = (id / 8) % a.esplit; }
+    else { const int rem = a.gcount - base, r = id - (id / blk) * blk; d = base + r % rem; split = r / rem; }   // ragged tail
+  }
   const int e_begin = a.goff[d], e_end = a.goff[d + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
   const int n_super = a.NTs >> 6;
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
   const int H4 = a.H >> 2;                           // H = 3*ns is a multiple of 4 for every supported ns
   int pass = 0;
   for (int e0 = e_begin; e0 < e_end; e0 += EC_E, ++pass) {
-    if (pass % a.esplit != (int)blockIdx.y) continue;
+    if (pass % a.esplit != split) continue;
     const int ne = min(EC_E, e_end - e0);
     // ---- phase 1a: per-edge indices, spherical harmonics, weight
     if (tid < EC_E) {
@@ -375,8 +387,8 @@ void launch_edge_conv(const EdgeConvArgs& a_in, hipStream_t s) {
   const int n_super = a.NTs >> 6;
   const int waves = n_super < 4 ? n_super : 4;   // 3 workgroups of 4 waves per CU: their phases interleave
   if (a.H % 4 != 0) throw Error(DDMI_ERR_ARG, "3*ns must be a multiple of 4");
-  if (a.maxd <= 3) hipLaunchKernelGGL(k_edge_conv<3>, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
-  else hipLaunchKernelGGL(k_edge_conv<5>, dim3(a.gcount, a.esplit), dim3(64 * waves), smem, s, a);
+  if (a.maxd <= 3) hipLaunchKernelGGL(k_edge_conv<3>, dim3(a.gcount * a.esplit), dim3(64 * waves), smem, s, a);
+  else hipLaunchKernelGGL(k_edge_conv<5>, dim3(a.gcount * a.esplit), dim3(64 * waves), smem, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
