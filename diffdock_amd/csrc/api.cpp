@@ -30,7 +30,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     try { build_weight_spec(h->m); } catch (...) { delete h; throw; }
     if (const char* e = getenv("DDMI_STREAMS")) h->m.two_streams = atoi(e) != 1;
     if (const char* e = getenv("DDMI_FUSED")) h->m.fused = atoi(e) != 0;
-    if (const char* e = getenv("DDMI_FUSED_LIG")) h->m.fused_lig = atoi(e) != 0;
+    if (const char* e = getenv("DDMI_FUSED_LIG")) h->m.fused_lig = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_YS")) h->m.fused_ysplit = std::max(1, atoi(e));
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));

@@ -148,7 +148,9 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
     const bool load_mode = g.vn >= 2;   // ligand gather nodes: contracted rows from k_node_contract, shared by the node's virtual nodes
-    const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb && (!load_mode || (m.fused_lig && c.y_chunk <= 0));
+    // load mode pays when a gather node carries many edges (its rows are shared by >= 2 virtual nodes)
+    const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb &&
+                      (!load_mode || (m.fused_lig && c.y_chunk <= 0 && (m.fused_lig > 1 || g.ea_rows >= 64 * (long)g.gcount)));
     float* Hb = side ? c.Hb_b : c.Hb;
     const bool fuse_mm = fuse && m.fused_mm && ns % 16 == 0 && ns <= 64;   // first Linear inside the hidden-row kernel
     if (fuse_mm) {
@@ -170,7 +172,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       Cx::VnSet& vs = c.vn[g.vn];
       if (vs.built_goff != g.goff || vs.epoch != c.epoch) {
         PhaseTimer t(m, "vn_build", gs);
-        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, gs);
+        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, gs, load_mode ? 1 : 0);
         vs.built_goff = g.goff; vs.epoch = c.epoch;
       }
       const int* nvn = vs.voff + g.gcount;
@@ -429,7 +431,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     int vmax = 0, vmax_b = 0;
     for (int i = 0; i < 4; ++i) {
       Cx::VnSet& vs = c.vn[i];
-      vs.vcap = gn_v[i] + ecap_v[i] / 32 + 1;
+      vs.vcap = (i >= 2 ? 2 : 1) * gn_v[i] + ecap_v[i] / 32 + 2;   // load-mode lists pad every node to an even count
       vs.cnt = dalloc<int>(m, nullptr, {gn_v[i] + 1}); vs.voff = dalloc<int>(m, names[i], {gn_v[i] + 1});
       vs.node = dalloc<int>(m, nullptr, {vs.vcap}); vs.e0 = dalloc<int>(m, nullptr, {vs.vcap});
       vmax = std::max(vmax, vs.vcap);

@@ -394,20 +394,23 @@ void launch_edge_conv(const EdgeConvArgs& a_in, hipStream_t s) {
 
 // ------------------------------------------------------------------ fused contraction + edge kernel
 // Virtual nodes: gather node d with edges [goff[d], goff[d+1]) becomes ceil(deg/32) entries (d, first edge).
-__global__ void k_vn_count(const int* __restrict__ goff, int gcount, int* __restrict__ cnt) {
+__global__ void k_vn_count(const int* __restrict__ goff, int gcount, int pad_even, int* __restrict__ cnt) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d < gcount) cnt[d] = (goff[d + 1] - goff[d] + 31) >> 5;
+  if (d >= gcount) return;
+  int n = (goff[d + 1] - goff[d] + 31) >> 5;
+  if (pad_even) n = (n + 1) & ~1;   // load mode: a node starts on an even slot, so a 16-entry tile spans <= 8 nodes
+  cnt[d] = n;
 }
 __global__ void k_vn_fill(const int* __restrict__ goff, const int* __restrict__ voff, int gcount, int* __restrict__ vn_node,
                           int* __restrict__ vn_e0) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= gcount) return;
-  const int v0 = voff[d], n = voff[d + 1] - v0, e0 = goff[d];
-  for (int b = 0; b < n; ++b) { vn_node[v0 + b] = d; vn_e0[v0 + b] = e0 + 32 * b; }
+  const int v0 = voff[d], n = voff[d + 1] - v0, e0 = goff[d], e1 = goff[d + 1];
+  for (int b = 0; b < n; ++b) { vn_node[v0 + b] = d; vn_e0[v0 + b] = min(e0 + 32 * b, e1); }   // padding entry: no edges
 }
-void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s) {
+void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s, int pad_even) {
   if (gcount <= 0) return;
-  hipLaunchKernelGGL(k_vn_count, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, gcount, cnt_tmp);
+  hipLaunchKernelGGL(k_vn_count, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, gcount, pad_even, cnt_tmp);
   launch_exclusive_scan(cnt_tmp, voff, gcount, s);
   hipLaunchKernelGGL(k_vn_fill, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, voff, gcount, vn_node, vn_e0);
   DDMI_CHECK_HIP(hipGetLastError());
@@ -482,9 +485,9 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
   for (int v = blockIdx.x * 4 + wave; v < nvn; v += gridDim.x * 4) {
     const int d = a.vn_node[v], e0 = a.vn_e0[v];
     const int ne = min(32, a.goff[d + 1] - e0);
-    const int ar0 = a.arow ? a.arow[e0] : e0;
     const float* __restrict__ qrow = a.Q + (size_t)d * H + 4 * lq;
-    const float* __restrict__ rbrow = a.rowbias ? a.rowbias + (size_t)a.ridx[ar0] * H + 4 * lq : nullptr;
+    const float* __restrict__ rbrow = nullptr;
+    if (a.rowbias && ne > 0) rbrow = a.rowbias + (size_t)a.ridx[a.arow ? a.arow[e0] : e0] * H + 4 * lq;
 #pragma unroll 1
     for (int rt = 0; rt < 2; ++rt) {
       // lane (row lr, q) owns hidden k = 16nb + 4q + {0..3}: group g = 2nb + (q >> 1), fragment lanes 16(2(q&1) + {0,1}) + row
@@ -748,21 +751,24 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
 
 // Load mode (gather nodes with many edges each, e.g. ligand atoms towards all residues): the contracted rows come
 // precomputed from k_node_contract (granule-major), one copy per DISTINCT gather node of the tile (slot table stab:
-// [0,16) node of slot, [16,32) slot of virtual node, [32] slot count) -- a tile of 16 virtual nodes usually shares one or
-// two rows.  Same pipeline as the compute modes: rows of group g+2 are requested while group g is multiplied.
-__device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][4], const float* __restrict__ yg, size_t node_stride,
-                                                 const int* stab, int NG8, const float* __restrict__ hfrag, const int (&vne)[2],
-                                                 const int (&vslot)[2], float* ybuf, int tid, int lr, int lq) {
+// [0,8) node of slot, [16,32) slot of virtual node, [32] slot count; the virtual-node list pads every node to an even
+// count, so a tile holds <= 8 nodes).  No contraction registers are needed here, so TWO granules (128 columns) are
+// multiplied per pass and the hidden rows -- the dominant HBM stream of this mode -- are read half as often.
+// Chunk buffer: [granule 2][slot 8] row blocks.  Same pipeline: rows of group g+2 are requested while group g is multiplied.
+__device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const float* __restrict__ yg, size_t gran_stride,
+                                                 size_t node_stride, int ng, const int* stab, int NG8,
+                                                 const float* __restrict__ hfrag, const int (&vne)[2], const int (&vslot)[2],
+                                                 float* ybuf, int tid, int lr, int lq) {
   const int nslots = stab[32];
-  const int ls = tid >> 7, row = (tid >> 4) & 7, c4 = tid & 15;
+  const int lu = tid >> 8, ls = (tid >> 7) & 1, row = (tid >> 4) & 7, c4 = tid & 15;
   const float* src[4];
   bool on[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    on[p] = 4 * p + ls < nslots;
-    src[p] = yg + (on[p] ? (size_t)stab[4 * p + ls] * node_stride : 0) + row * 64 + 4 * c4;
+    on[p] = 2 * p + ls < nslots && lu < ng;
+    src[p] = yg + (on[p] ? (size_t)lu * gran_stride + (size_t)stab[2 * p + ls] * node_stride : 0) + row * 64 + 4 * c4;
   }
-  float* dst = ybuf + ls * FC_YVN + row * FC_YROW + 4 * c4;
+  float* dst = ybuf + (lu * 8 + ls) * FC_YVN + row * FC_YROW + 4 * c4;
   float4 yq[4];
 #define FC_FETCHY(g)                                                                      \
   do {                                                                                    \
@@ -771,7 +777,7 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][4], const fl
 #define FC_STOREY(buf)                                                                    \
   do {                                                                                    \
     _Pragma("unroll") for (int p = 0; p < 4; ++p)                                         \
-      if (on[p]) *reinterpret_cast<float4*>(dst + (buf) * FC_YB + 4 * p * FC_YVN) = yq[p]; \
+      if (on[p]) *reinterpret_cast<float4*>(dst + (buf) * FC_YB + 2 * p * FC_YVN) = yq[p]; \
   } while (0)
   float2 hC[2][2], hN[2][2];
   const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
@@ -797,22 +803,26 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][4], const fl
     }
     const float* __restrict__ yb0 = ybuf + (g & 1) * FC_YB + (2 * lq) * FC_YROW + lr;
 #pragma unroll
-    for (int vi = 0; vi < 2; ++vi) {
+    for (int u = 0; u < 2; ++u) {
+      if (u >= ng) break;
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const float* __restrict__ yb = yb0 + vslot[vi] * FC_YVN + sub * FC_YROW;
-        const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];
-        const float a0 = sub == 0 ? hC[vi][0].x : hC[vi][0].y;
-        acc[vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[vi][0][0], 0, 0, 0);
-        acc[vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[vi][0][1], 0, 0, 0);
-        acc[vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[vi][0][2], 0, 0, 0);
-        acc[vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[vi][0][3], 0, 0, 0);
-        if (vi == 0 ? two0 : two1) {
-          const float a1 = sub == 0 ? hC[vi][1].x : hC[vi][1].y;
-          acc[vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[vi][1][0], 0, 0, 0);
-          acc[vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[vi][1][1], 0, 0, 0);
-          acc[vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[vi][1][2], 0, 0, 0);
-          acc[vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[vi][1][3], 0, 0, 0);
+      for (int vi = 0; vi < 2; ++vi) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const float* __restrict__ yb = yb0 + (u * 8 + vslot[vi]) * FC_YVN + sub * FC_YROW;
+          const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];
+          const float a0 = sub == 0 ? hC[vi][0].x : hC[vi][0].y;
+          acc[u][vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[u][vi][0][0], 0, 0, 0);
+          acc[u][vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[u][vi][0][1], 0, 0, 0);
+          acc[u][vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[u][vi][0][2], 0, 0, 0);
+          acc[u][vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[u][vi][0][3], 0, 0, 0);
+          if (vi == 0 ? two0 : two1) {
+            const float a1 = sub == 0 ? hC[vi][1].x : hC[vi][1].y;
+            acc[u][vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[u][vi][1][0], 0, 0, 0);
+            acc[u][vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[u][vi][1][1], 0, 0, 0);
+            acc[u][vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[u][vi][1][2], 0, 0, 0);
+            acc[u][vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[u][vi][1][3], 0, 0, 0);
+          }
         }
       }
     }
@@ -857,7 +867,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       for (int i = 0; i < FC_VN; ++i) {
         if (i < nv_live) {
           const int node = a.vn_node[v0 + i];
-          if (node != prev) { stab[ns_++] = node; prev = node; }
+          if (node != prev && ns_ < 8) { stab[ns_++] = node; prev = node; }
         }
         stab[16 + i] = ns_ > 0 ? ns_ - 1 : 0;
       }
@@ -919,37 +929,46 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   const float* __restrict__ hfrag = a.Hb + ((size_t)(v0 + 2 * wave) * 2 * NG8) * 128 + 2 * lane;   // + ((vi*2 + rt)*NG8 + g)*128
   float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
-  for (int gi = g_begin; gi < g_end; ++gi) {
+  constexpr int NGR = MODE == 2 ? 2 : 1;   // granules per pass
+  for (int gi = g_begin; gi < g_end; gi += NGR) {
     const FGran& Gd = a.gran[gi];
-    f32x4 acc[2][2][4];
+    f32x4 acc_all[2][2][2][4];
 #pragma unroll
-    for (int vi = 0; vi < 2; ++vi)
+    for (int u = 0; u < NGR; ++u)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[vi][rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc_all[u][vi][rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 (&acc)[2][2][4] = acc_all[0];
     if (MODE == 2) {
-      if (!Gd.empty) {
-        const size_t nstride = (size_t)a.n_gran * a.HKp * 64;
-        const float* __restrict__ yg = a.Yg + (size_t)gi * a.HKp * 64;
-        fc_mainloop_load(acc, yg, nstride, stab, NG8, hfrag, vne, vslot, ybuf, tid, lr, lq);
-        // bias row (k = H, h = 1) of every slot -> row 0 of buffer 0
-        if (tid < 256 && (tid >> 4) < stab[32])
-          *reinterpret_cast<float4*>(ybuf + (tid >> 4) * FC_YVN + 4 * (tid & 15)) =
-              nt_load4(yg + (size_t)stab[tid >> 4] * nstride + (size_t)H * 64 + 4 * (tid & 15));
-        __syncthreads();
+      const int ng = min(NGR, g_end - gi);
+      const size_t gstride = (size_t)a.HKp * 64, nstride = (size_t)a.n_gran * gstride;
+      const float* __restrict__ yg = a.Yg + (size_t)gi * gstride;
+      fc_mainloop_load(acc_all, yg, gstride, nstride, ng, stab, NG8, hfrag, vne, vslot, ybuf, tid, lr, lq);
+      // bias row (k = H, h = 1) of every (granule, slot) -> row 0 of buffer 0
+      {
+        const int bu = tid >> 7, bs = (tid >> 4) & 7;
+        if (tid < 256 && bu < ng && bs < stab[32])
+          *reinterpret_cast<float4*>(ybuf + (bu * 8 + bs) * FC_YVN + 4 * (tid & 15)) =
+              nt_load4(yg + (size_t)bu * gstride + (size_t)stab[bs] * nstride + (size_t)H * 64 + 4 * (tid & 15));
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NGR; ++u)
 #pragma unroll
         for (int vi = 0; vi < 2; ++vi) {
-          const float* __restrict__ yb = ybuf + vslot[vi] * FC_YVN + lr;
+          const float* __restrict__ yb = ybuf + (u * 8 + vslot[vi]) * FC_YVN + lr;
           const float b0 = yb[0], b1 = yb[16], b2 = yb[32], b3 = yb[48];
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              acc[vi][rt][0][r] += b0; acc[vi][rt][1][r] += b1; acc[vi][rt][2][r] += b2; acc[vi][rt][3][r] += b3;
+              acc_all[u][vi][rt][0][r] += b0; acc_all[u][vi][rt][1][r] += b1;
+              acc_all[u][vi][rt][2][r] += b2; acc_all[u][vi][rt][3][r] += b3;
             }
         }
-      }
     } else if (!Gd.empty && !(a.dbg & 128)) {
       const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
@@ -1055,7 +1074,12 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     }
     __syncthreads();   // the coupling phase stages message rows in the (now idle) chunk buffers
     // ---- coupling with the spherical harmonics and message stores (wave-local: no workgroup barrier)
-    const float* __restrict__ cg = cgt + (gi - g_begin) * CGN;
+#pragma unroll
+    for (int u = 0; u < NGR; ++u) {
+    if (gi + u >= g_end) break;
+    const FGran& Gd = a.gran[gi + u];
+    f32x4 (&acc)[2][2][4] = acc_all[u];
+    const float* __restrict__ cg = cgt + (gi + u - g_begin) * CGN;
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi) {
       const int ne = vne[vi];
@@ -1115,6 +1139,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
           DDMI_WAVE_SYNC();
         }
       }
+    }
     }
     __syncthreads();   // chunk buffers / coupling scratch are reused by the next granule
   }

@@ -210,16 +210,20 @@ void launch_score_heads(const ScoreHeadArgs& a, hipStream_t s) {
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
-__global__ void k_tor_head(TorHeadArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per torsion bond: lane c owns hidden unit c (c, c + 64, ..), tanh, weighted wave sum
+__global__ __launch_bounds__(64) void k_tor_head(TorHeadArgs a) {
+  const int t = blockIdx.x, lane = threadIdx.x;
   if (t >= a.nT) return;
-  const float* f = a.feat + (size_t)t * a.in_dim;
-  float out = 0.f;
-  for (int c = 0; c < a.ns; ++c) {
+  const float* __restrict__ f = a.feat + (size_t)t * a.in_dim;
+  float part = 0.f;
+  for (int c = lane; c < a.ns; c += 64) {
+    const float* __restrict__ w = a.W0 + (size_t)c * a.in_dim;
     float h = 0.f;
-    for (int j = 0; j < a.in_dim; ++j) h = fmaf(a.W0[(size_t)c * a.in_dim + j], f[j], h);
-    out = fmaf(a.W3[c], tanhf(h), out);
+    for (int j = 0; j < a.in_dim; ++j) h = fmaf(w[j], f[j], h);
+    part = fmaf(a.W3[c], tanhf(h), part);
   }
+  float out = wave_sum(part);
+  if (lane != 0) return;
   if (a.scale_by_sigma) {
     const float sig = sigma_of_t(a.smin, a.smax, a.t_tor[a.tor_batch[t]]);
     const double PI = 3.14159265358979323846;
@@ -232,7 +236,7 @@ __global__ void k_tor_head(TorHeadArgs a) {
 }
 void launch_tor_head(const TorHeadArgs& a, hipStream_t s) {
   if (a.nT <= 0) return;
-  hipLaunchKernelGGL(k_tor_head, dim3(cdiv(a.nT, 64)), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_tor_head, dim3(a.nT), dim3(64), 0, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

@@ -83,7 +83,8 @@ struct FGran {
   int empty;             // no path reaches this granule: the message columns are zero
   int shape;             // chain-length class of the 4 slots: 1 = (12,3,3,3), 2 = (3,3,3,3), 3 = (12,-,-,-), 0 = generic
 };
-void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s);
+void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s,
+                     int pad_even = 0);
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                         const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
                         float* Hb, hipStream_t s);

@@ -84,8 +84,8 @@ struct Model {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool two_streams = true;
   bool fused = true;        // receptor-gather edge groups use k_conv_fused (DDMI_FUSED=0: contracted rows through HBM)
-  bool fused_lig = false;   // DDMI_FUSED_LIG=1: ligand-gather groups through k_conv_fused in load mode (measured slower than k_edge_conv:
-                            // both stream ~2 GB per launch, hidden rows vs contracted rows; kept for a 2-granule variant)
+  int fused_lig = 1;        // ligand-gather groups through k_conv_fused in load mode: 1 = when a node carries >= 64 edges,
+                            // 2 = always, 0 = never (k_edge_conv) -- DDMI_FUSED_LIG
   bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden
   int fused_ysplit = 1;     // workgroups per 16-virtual-node tile (granule ranges)
   double crop_cutoff = 0.0;  // > 0: receptor cropped to this distance from the ligand in ddmi_forward (crop_beyond)

@@ -173,7 +173,7 @@ def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
     outs = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("DDMI_FUSED", fused)
-        monkeypatch.setenv("DDMI_FUSED_LIG", "1" if lmax == 1 else "0")   # lmax 1 also routes the ligand-gather groups (load mode)
+        monkeypatch.setenv("DDMI_FUSED_LIG", "2" if lmax == 1 else "0")   # lmax 1 also forces both ligand-gather groups into load mode
         m = make_model(cfg, sd, emu_lib)
         m.set_kernel_timing(True)
         outs[fused] = m(b)[:3]
