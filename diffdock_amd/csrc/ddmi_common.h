@@ -34,10 +34,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // wave-uniform value -> scalar register
 #define DDMI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // LDS hand-off between lanes of ONE wave (lock-step on the hardware: order the ds ops, keep the compiler from moving them)
-#define DDMI_WAVE_SYNC()                                   \
-  do {                                                     \
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
-    __builtin_amdgcn_wave_barrier();                       \
+#define DDMI_WAVE_SYNC()                                                                     \
+  do {                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* LDS only: global stores stay in flight */ \
+    __builtin_amdgcn_wave_barrier();                                                         \
   } while (0)
 #define DDMI_NT_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
 #define DDMI_NT_LOAD(ptr) __builtin_nontemporal_load((ptr))

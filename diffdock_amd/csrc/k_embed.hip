@@ -110,8 +110,99 @@ __global__ __launch_bounds__(256) void k_edge_mlp(EdgeMlpArgs a) {
     __syncthreads();
   }
 }
+// Matrix-core form of the same two-layer MLP for ns % 16 == 0, D % 4 == 0, nfeat <= 4: one wave per 16 edges, both
+// products taken transposed (weights = A operand from LDS, edges = the N dimension), so that lane (edge, q) owns hidden
+// units 16cb + 4q + {0..3} of ITS edge after the first layer -- which is exactly the B fragment (k = 16cb + 4q + r,
+// n = edge) the second layer needs: no transpose, no LDS round trip for the activations.  The Gaussians are the first
+// layer's B fragments, computed in registers.  Output: 16 B per lane (64 B per edge per column block).
+template <int NSB>   // ns = 16 * NSB
+__global__ __launch_bounds__(256) void k_edge_mlp_mm(EdgeMlpArgs a) {
+  DDMI_DYN_SMEM(float, smem);
+  constexpr int ns = 16 * NSB, WS = ns + (16 - ns % 64 + 64) % 64;   // LDS row stride = 16 mod 64: the 4 lane quarters hit distinct banks
+  const int D = a.D, nf = a.nfeat, T0 = D >> 2;
+  float* w0 = smem;                  // [D + 4][WS]: w0[k][c] = W0g[c][k], rows D.. = W0f (zero padded to 4 features)
+  float* w1 = w0 + (D + 4) * WS;     // [ns][WS]:    w1[j][c] = W1[c][j]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = DDMI_UNIFORM(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int i = tid; i < (D + 4) * ns; i += 256) {
+    const int c = i / (D + 4), k = i - c * (D + 4);
+    float v = 0.f;
+    if (k < D) v = a.W0g[(size_t)c * a.ldw0g + k];
+    else if (k - D < nf) v = a.W0f[(size_t)c * a.ldw0f + (k - D)];
+    w0[k * WS + c] = v;
+  }
+  for (int i = tid; i < ns * ns; i += 256) { const int c = i / ns, j = i - c * ns; w1[j * WS + c] = a.W1[i]; }
+  int E = a.E;
+  if (a.e_dev) { const int ev = *a.e_dev; E = ev < E ? ev : E; }
+  __syncthreads();
+  f32x4 b1v[NSB];
+#pragma unroll
+  for (int nb = 0; nb < NSB; ++nb)
+    b1v[nb] = f32x4{a.b1[16 * nb + 4 * lq], a.b1[16 * nb + 4 * lq + 1], a.b1[16 * nb + 4 * lq + 2], a.b1[16 * nb + 4 * lq + 3]};
+  for (int base = (blockIdx.x * 4 + wave) * 16; base < E; base += gridDim.x * 64) {
+    const int e = base + lr;
+    const bool live = e < E;
+    const float dist = live ? a.dist[e] : 0.f;
+    const float* __restrict__ gv = a.gvec + (size_t)((live && a.gidx) ? a.gidx[e] : 0) * ns + 4 * lq;
+    float fv = 0.f;   // this lane's bond feature (feature index = lq)
+    if (live && nf > 0 && lq < nf) {
+      const int fr = a.featidx ? a.featidx[e] : e;
+      if (fr >= 0) fv = a.feat[(size_t)fr * nf + lq];
+    }
+    f32x4 h[NSB];
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gv + 16 * cb);
+      h[cb] = f32x4{g4.x, g4.y, g4.z, g4.w};
+    }
+    for (int t = 0; t < T0; ++t) {   // Gaussian k = 4t + lq of this lane's edge
+      const float dd = dist - a.offsets[4 * t + lq];
+      const float g = expf(a.coeff * (dd * dd));
+      const float* __restrict__ wp = w0 + (4 * t + lq) * WS + lr;
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb) h[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[16 * cb], g, h[cb], 0, 0, 0);
+    }
+    if (nf > 0) {
+      const float* __restrict__ wp = w0 + (D + lq) * WS + lr;
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb) h[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[16 * cb], fv, h[cb], 0, 0, 0);
+    }
+    f32x4 o[NSB];
+#pragma unroll
+    for (int nb = 0; nb < NSB; ++nb) o[nb] = b1v[nb];
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = fmaxf(h[cb][r], 0.f);                       // hidden unit j = 16cb + 4lq + r of this lane's edge
+        const float* __restrict__ wp = w1 + (16 * cb + 4 * lq + r) * WS + lr;
+#pragma unroll
+        for (int nb = 0; nb < NSB; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[16 * nb], hv, o[nb], 0, 0, 0);
+      }
+    if (live) {
+      float* __restrict__ op = a.out + (size_t)e * a.ldo + 4 * lq;
+#pragma unroll
+      for (int nb = 0; nb < NSB; ++nb) *reinterpret_cast<float4*>(op + 16 * nb) = make_float4(o[nb][0], o[nb][1], o[nb][2], o[nb][3]);
+    }
+  }
+}
+
 void launch_edge_mlp(const EdgeMlpArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
+  if (a.ns % 16 == 0 && a.ns <= 64 && a.D % 4 == 0 && a.nfeat <= 4 && a.ldo % 4 == 0) {
+    const int ns = a.ns, WS = ns + (16 - ns % 64 + 64) % 64;
+    const size_t smem = (size_t)((a.D + 4) * WS + ns * WS) * sizeof(float);
+    const int grid = min(cdiv(a.E, 64), 2048);
+    switch (ns / 16) {
+      case 1: hipLaunchKernelGGL(k_edge_mlp_mm<1>, dim3(grid), dim3(256), smem, s, a); break;
+      case 2: hipLaunchKernelGGL(k_edge_mlp_mm<2>, dim3(grid), dim3(256), smem, s, a); break;
+      case 3: hipLaunchKernelGGL(k_edge_mlp_mm<3>, dim3(grid), dim3(256), smem, s, a); break;
+      default: hipLaunchKernelGGL(k_edge_mlp_mm<4>, dim3(grid), dim3(256), smem, s, a); break;
+    }
+    DDMI_CHECK_HIP(hipGetLastError());
+    return;
+  }
   const size_t smem = (size_t)(a.D * a.ns + a.nfeat * a.ns + a.ns * a.ns + 4 * (a.D + a.ns)) * sizeof(float);
   const int grid = min(cdiv(a.E, 4), 2048);
   hipLaunchKernelGGL(k_edge_mlp, dim3(grid), dim3(256), smem, s, a);
