@@ -612,10 +612,22 @@ __device__ __forceinline__ f32x4 fc_apply(const FcSlotRt& R, size_t koff, const 
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], (R.wb + koff + (size_t)j * R.bstride)[R.loff], acc, 0, 0, 0);
   return acc;
 }
+template <int N>
+__device__ __forceinline__ void fc_direct_n(const FcSlotRt& R, size_t koff, int j0, f32x4& acc) {
+  float bv[N], av[N];   // all fragments requested before the first MFMA: one L2 round trip per chain piece
+#pragma unroll
+  for (int j = 0; j < N; ++j) { bv[j] = (R.wb + koff + (size_t)(j0 + j) * R.bstride)[R.loff]; av[j] = R.xp[(j0 + j) * R.xstride]; }
+#pragma unroll
+  for (int j = 0; j < N; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+}
 __device__ __forceinline__ f32x4 fc_direct(const FcSlotRt& R, size_t koff) {   // un-prefetched chain (bias row)
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int j = 0; j < R.steps; ++j)
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(R.xp[j * R.xstride], (R.wb + koff + (size_t)j * R.bstride)[R.loff], acc, 0, 0, 0);
+  int j = 0;
+  for (; j + 12 <= R.steps; j += 12) fc_direct_n<12>(R, koff, j, acc);
+  for (; j + 4 <= R.steps; j += 4) fc_direct_n<4>(R, koff, j, acc);
+  if (R.steps - j == 3) fc_direct_n<3>(R, koff, j, acc);
+  else if (R.steps - j == 2) fc_direct_n<2>(R, koff, j, acc);
+  else if (R.steps - j == 1) fc_direct_n<1>(R, koff, j, acc);
   return acc;
 }
 // transposing store of one chain result: lane (lr, lq) holds nodes 4lq .. 4lq+3 of column (slot, w = lr)
