@@ -17,6 +17,7 @@ import argparse
 # vocabulary sizes (reference datasets/process_mols.py:59-87)
 LIG_FEATURE_DIMS = (119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2)
 REC_RESIDUE_FEATURE_DIMS = (38,)
+REC_ATOM_FEATURE_DIMS = (38, 119, 23, 38)   # amino acid, atomic number, atom_type_2, atom_type_3 (process_mols.py:78-83)
 LM_EMBEDDING_DIM = 1280  # 'precomputed' ESM2 embeddings (models/cg_model.py:73-74)
 
 
@@ -58,6 +59,7 @@ class ModelConfig:
     tor_sigma_min: float = 0.0314
     tor_sigma_max: float = 3.14
     crop_beyond: float | None = None
+    all_atoms: bool = False             # AAModel (models/aa_model.py): receptor heavy atoms as a third node type
 
     # ------------------------------------------------------------------ derived
     @property
@@ -90,9 +92,11 @@ class ModelConfig:
         return seq[min(i, len(seq) - 1)], seq[min(i + 1, len(seq) - 1)]
 
     def conv_groups(self, l) -> int:
-        """edge groups of conv layer l (models/cg_model.py:167)."""
+        """edge groups of conv layer l (models/cg_model.py:167, models/aa_model.py:157)."""
         if not self.differentiate_convolutions:
             return 1
+        if self.all_atoms:
+            return 3 if l == self.num_conv_layers - 1 else 9
         return 2 if l == self.num_conv_layers - 1 else 4
 
     def to_namespace(self) -> argparse.Namespace:
@@ -100,7 +104,7 @@ class ModelConfig:
         d = asdict(self)
         d.update(max_radius=self.lig_max_radius, no_batch_norm=not self.batch_norm,
                  no_differentiate_convolutions=not self.differentiate_convolutions,
-                 embedding_type="sinusoidal", all_atoms=False, dropout=0.0,
+                 embedding_type="sinusoidal", dropout=0.0,
                  esm_embeddings_path="precomputed" if self.lm_embedding_type else None)
         for k in ('fixed_center_conv', 'lm_embedding_type', 'batch_norm', 'differentiate_convolutions',
                   'lig_max_radius', 'rec_max_radius', 'center_max_distance', 'in_lig_edge_features'):
@@ -125,9 +129,8 @@ def config_from_args(args) -> ModelConfig:
               "pdbsidechain_esm_embeddings_path", "esm_embeddings_path"):
         if get(k, None) is not None:
             lm = "precomputed"
-    if get("all_atoms", False):
-        raise NotImplementedError("all_atoms (AAModel) is not on the built path yet")
     return ModelConfig(
+        all_atoms=bool(get("all_atoms", False)),
         ns=args.ns, nv=args.nv, num_conv_layers=args.num_conv_layers,
         num_prot_emb_layers=get("num_prot_emb_layers", 0), sh_lmax=get("sh_lmax", 2),
         sigma_embed_dim=args.sigma_embed_dim, distance_embed_dim=args.distance_embed_dim,

@@ -5,6 +5,7 @@ hot path touches on a PyG `HeteroData` / `Batch`:
     data['ligand', 'ligand'].edge_index / .edge_attr / .num_edges     (-> lig_bond relation)
     data['receptor'].pos / .x / .batch / .side_chain_vecs
     data['receptor', 'receptor'].edge_index                            (-> rec_contact relation)
+    data['atom'].pos / .x / .batch, data['atom', 'atom'].edge_index, data['atom', 'receptor'].edge_index   (all_atoms)
     data.num_graphs, data.complex_t, data['name'], data.to(device), data.to_data_list()
 
 torch_geometric is not installed in this image; real PyG batches expose the same
@@ -48,7 +49,9 @@ class Store:
 
 
 _REL = {("ligand", "ligand"): ("ligand", "lig_bond", "ligand"),
-        ("receptor", "receptor"): ("receptor", "rec_contact", "receptor")}
+        ("receptor", "receptor"): ("receptor", "rec_contact", "receptor"),
+        ("atom", "atom"): ("atom", "atom_contact", "atom"),                   # all-atom graphs (datasets/process_mols.py:238-239)
+        ("atom", "receptor"): ("atom", "atom_rec_contact", "receptor")}
 
 
 class HeteroData:
@@ -219,9 +222,9 @@ class DataLoader:
 
 
 def set_time(batch, t_tr, t_rot, t_tor, batchsize, device=None):
-    """utils/diffusion_utils.py:146-168 for the CG model (no 'atom' nodes)."""
+    """utils/diffusion_utils.py:146-168 ('atom' nodes receive node_t when the graph has them = all_atoms)."""
     device = device or batch["ligand"].pos.device
-    for nt in ("ligand", "receptor"):
+    for nt in ("ligand", "receptor") + (("atom",) if "atom" in batch.node_types else ()):
         n = batch[nt].num_nodes
         batch[nt].node_t = {"tr": t_tr * torch.ones(n, device=device),
                             "rot": t_rot * torch.ones(n, device=device),

@@ -149,8 +149,39 @@ def transformation_mask(nl, bonds):
     return mask_edges, mask_rotate
 
 
+def receptor_atoms(rng, rc, restype, atoms_per_res=(4, 11), atom_radius=5.0, atom_max_neighbors=8):
+    """Heavy atoms of the all-atom graphs (datasets/process_mols.py:204-239 semantics): a few atoms around every
+    C-alpha, categorical features (amino acid, atomic number, atom_type_2, atom_type_3), atom-atom edges = neighbours
+    within atom_radius capped at the atom_max_neighbors nearest (nearest one if none), edge_index = [neighbour; atom],
+    and one atom -> own residue edge per atom."""
+    from .config import REC_ATOM_FEATURE_DIMS
+    n_res = len(rc)
+    counts = rng.integers(atoms_per_res[0], atoms_per_res[1] + 1, size=n_res)
+    res_of = np.repeat(np.arange(n_res), counts)
+    na = len(res_of)
+    pos = rc[res_of] + rng.normal(size=(na, 3)) * 1.3
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    pos[first] = rc                                   # the C-alpha itself
+    feats = np.stack([restype[res_of, 0].astype(np.int64)] +
+                     [rng.integers(0, d, size=na) for d in REC_ATOM_FEATURE_DIMS[1:]], 1)
+    feats[:, 1] = rng.choice([5, 6, 7, 15], size=na, p=[0.62, 0.17, 0.2, 0.01])
+    d = np.linalg.norm(pos[:, None, :] - pos[None, :, :], axis=-1)
+    src, dst = [], []
+    for i in range(na):
+        nb = [j for j in np.where(d[i] < atom_radius)[0] if j != i]
+        if len(nb) > atom_max_neighbors:
+            nb = list(np.argsort(d[i])[1:atom_max_neighbors + 1])
+        if len(nb) == 0:
+            nb = list(np.argsort(d[i])[1:2])
+        src += [i] * len(nb)
+        dst += [int(j) for j in nb]
+    aa = np.asarray([dst, src], dtype=np.int64)
+    ar = np.stack([np.arange(na), res_of]).astype(np.int64)
+    return pos.astype(np.float32), feats.astype(np.float32), aa, ar
+
+
 def make_complex(seed=0, n_res=300, n_lig=30, receptor_radius=15.0, c_alpha_max_neighbors=24,
-                 lm_dim=LM_EMBEDDING_DIM, name=None) -> HeteroData:
+                 lm_dim=LM_EMBEDDING_DIM, name=None, all_atoms=False, atoms_per_res=(4, 11)) -> HeteroData:
     rng = np.random.default_rng(seed)
     g = HeteroData()
     # receptor ------------------------------------------------------------
@@ -162,6 +193,12 @@ def make_complex(seed=0, n_res=300, n_lig=30, receptor_radius=15.0, c_alpha_max_
     g["receptor"].side_chain_vecs = torch.zeros(n_res, 10)
     g["receptor", "rec_contact", "receptor"].edge_index = torch.from_numpy(
         receptor_contact_graph(rc, receptor_radius, c_alpha_max_neighbors))
+    if all_atoms:
+        ap, af, aa, ar = receptor_atoms(np.random.default_rng(seed + 7919), rc, restype, atoms_per_res)
+        g["atom"].x = torch.from_numpy(af)
+        g["atom"].pos = torch.from_numpy(ap)
+        g["atom", "atom_contact", "atom"].edge_index = torch.from_numpy(aa)
+        g["atom", "atom_rec_contact", "receptor"].edge_index = torch.from_numpy(ar)
     # ligand --------------------------------------------------------------
     bonds = _ligand_topology(rng, n_lig)
     lc = _ligand_coords(rng, n_lig, bonds)

@@ -12,7 +12,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from .config import ModelConfig, LIG_FEATURE_DIMS, REC_RESIDUE_FEATURE_DIMS
+from .config import ModelConfig, LIG_FEATURE_DIMS, REC_RESIDUE_FEATURE_DIMS, REC_ATOM_FEATURE_DIMS
 from .irreps import parse_irreps, irreps_num, sh_irreps, full_tp_irreps, tp_weight_numel
 
 
@@ -71,17 +71,28 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
     sh = sh_irreps(cfg.sh_lmax)
     encoder("lig_node_embedding", LIG_FEATURE_DIMS, sd)
     mlp("lig_edge_embedding", cfg.in_lig_edge_features + sd + cfg.distance_embed_dim, ns, ns)
-    encoder("rec_node_embedding", REC_RESIDUE_FEATURE_DIMS, cfg.lm_embedding_dim)
-    mlp("rec_edge_embedding", cfg.distance_embed_dim, ns, ns)
-    mlp("rec_sigma_embedding", sd, ns, ns)
-    mlp("cross_edge_embedding", sd + cfg.cross_distance_embed_dim, ns, ns)
+    if cfg.all_atoms:   # models/aa_model.py:90-103
+        mlp("rec_sigma_embedding", sd, ns, ns)
+        encoder("rec_node_embedding", REC_RESIDUE_FEATURE_DIMS, cfg.lm_embedding_dim)
+        mlp("rec_edge_embedding", cfg.distance_embed_dim, ns, ns)
+        encoder("atom_node_embedding", REC_ATOM_FEATURE_DIMS, 0)
+        mlp("atom_edge_embedding", cfg.distance_embed_dim, ns, ns)
+        mlp("lr_edge_embedding", sd + cfg.cross_distance_embed_dim, ns, ns)
+        mlp("ar_edge_embedding", cfg.distance_embed_dim, ns, ns)
+        mlp("la_edge_embedding", sd + cfg.cross_distance_embed_dim, ns, ns)
+    else:
+        encoder("rec_node_embedding", REC_RESIDUE_FEATURE_DIMS, cfg.lm_embedding_dim)
+        mlp("rec_edge_embedding", cfg.distance_embed_dim, ns, ns)
+        mlp("rec_sigma_embedding", sd, ns, ns)
+        mlp("cross_edge_embedding", sd + cfg.cross_distance_embed_dim, ns, ns)
     spec["lig_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:lig")
     spec["rec_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:rec")
     spec["cross_distance_expansion.offset"] = ((cfg.cross_distance_embed_dim,), "offset:cross")
     K, L = cfg.num_prot_emb_layers, cfg.num_conv_layers
     for i in range(K):
         a, b = cfg.layer_irreps(i)
-        conv(f"rec_emb_layers.{i}", a, sh, b, 3 * ns, 3 * ns, 1, cfg.faster)
+        conv(f"rec_emb_layers.{i}", a, sh, b, 3 * ns, 3 * ns,
+             (4 if cfg.differentiate_convolutions else 1) if cfg.all_atoms else 1, cfg.faster)
     if cfg.embed_also_ligand:
         for i in range(K):
             a, b = cfg.layer_irreps(i)

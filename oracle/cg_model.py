@@ -213,7 +213,12 @@ class CGModelOracle:
             if inter is not None:
                 inter[f"node_attr{l + 1}"] = node_attr.clone()
         lig_node_attr = node_attr[:n_lig]
+        return self._readouts(data, lig_node_attr, tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates)
 
+    def _readouts(self, data, lig_node_attr, tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates):
+        """Centre convolution, score heads, torsion convolution (cg_model.py:368-424 == aa_model.py:438-484)."""
+        c, sd, ns = self.cfg, self.sd, self.cfg.ns
+        lig = data["ligand"]
         cei, cea, csh = self.build_center_conv_graph(data)
         cea = mlp2(sd, "center_edge_embedding", cea)
         cea = torch.cat([cea, lig_node_attr[cei[1 if c.fixed_center_conv else 0], :ns]], -1)

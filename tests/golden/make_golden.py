@@ -84,14 +84,21 @@ def install_stubs():
 def build_case(cfg, n_res, n_lig, n_samples, seed, t):
     from diffdock_amd.synth import make_complex, make_pose_list
     from diffdock_amd.weights import init_state_dict
-    g = make_complex(seed=seed, n_res=n_res, n_lig=n_lig)
-    data_list = make_pose_list(g, n_samples, tr_sigma_max=cfg.tr_sigma_max, seed=seed + 100)
+    g = make_complex(seed=seed, n_res=n_res, n_lig=n_lig, all_atoms=cfg.all_atoms, atoms_per_res=(3, 7))
+    # all-atom cases start inside the pocket: the ligand<-atom group (5 A radius) must not be empty, FasterTensorProduct
+    # cannot reshape an empty edge group (reference defect, see header)
+    data_list = make_pose_list(g, n_samples, tr_sigma_max=cfg.tr_sigma_max, seed=seed + 100,
+                               **(dict(initial_noise_std_proportion=0.05) if cfg.all_atoms else {}))
     sd = init_state_dict(cfg, seed=1234 + seed)
     return g, data_list, sd
 
 
 def graph_to_dict(g):
-    return {"rec_x": g["receptor"].x, "rec_pos": g["receptor"].pos,
+    extra = {}
+    if "atom" in g.node_types:   # all-atom graphs
+        extra = {"atom_x": g["atom"].x, "atom_pos": g["atom"].pos, "atom_edge_index": g["atom", "atom"].edge_index,
+                 "atom_rec_edge_index": g["atom", "receptor"].edge_index}
+    return {**extra, "rec_x": g["receptor"].x, "rec_pos": g["receptor"].pos,
             "rec_edge_index": g["receptor", "receptor"].edge_index,
             "lig_x": g["ligand"].x, "lig_pos": g["ligand"].pos, "edge_mask": g["ligand"].edge_mask,
             "mask_rotate": torch.from_numpy(np.asarray(g["ligand"].mask_rotate[0])),
@@ -130,7 +137,14 @@ def main():
                                     n_res=32, n_lig=11, n_samples=2, seed=3, t=0.5),
         # per-step receptor cropping (utils/sampling.py:104-109): cutoff 3*sigma_tr + 6 A shrinks from 21 A to 7 A
         "tiny_l2_crop": dict(cfg=TINY.replace(sh_lmax=2, crop_beyond=6.0), n_res=44, n_lig=12, n_samples=3, seed=4, t=0.3),
+        # all-atom score model (models/aa_model.py): receptor heavy atoms as a third node type, 9 edge groups per layer
+        "tiny_aa_l1": dict(cfg=TINY.replace(all_atoms=True, num_conv_layers=3, lig_max_radius=10.0, tr_sigma_max=2.0),
+                           n_res=24, n_lig=10, n_samples=2, seed=5, t=0.6),
+        "tiny_aa_l2": dict(cfg=TINY.replace(all_atoms=True, num_conv_layers=4, sh_lmax=2, fixed_center_conv=True),
+                           n_res=20, n_lig=9, n_samples=2, seed=6, t=0.4),
     }
+    if len(sys.argv) > 1:
+        cases = {k: v for k, v in cases.items() if k in sys.argv[1:]}
     for name, c in cases.items():
         print("case", name, flush=True)
         cfg = c["cfg"]
@@ -148,7 +162,7 @@ def main():
         # ---- single forward at time t, with per-layer node tables via hooks
         batch = HeteroBatch.from_data_list(copy.deepcopy(data_list))
         B = batch.num_graphs
-        set_time(batch, None, c["t"], c["t"], c["t"], B, False, torch.device("cpu"))
+        set_time(batch, None, c["t"], c["t"], c["t"], B, cfg.all_atoms, torch.device("cpu"))
         layer_out = []
         hooks = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone())) for l in model.conv_layers]
         with torch.no_grad():
@@ -185,6 +199,8 @@ def main():
         torch.save(fixture, os.path.join(HERE, f"{name}.pt"))
         print(name, "tr", tr[0].tolist(), "tor", tor[:3].tolist(), "n_draws", len(draws))
 
+    if len(sys.argv) > 1:
+        return
     # ---- crop_beyond (utils/utils.py:388-413) on one complex
     from diffdock_amd.synth import make_complex, make_pose_list
     g = make_complex(seed=5, n_res=60, n_lig=10)

@@ -1,7 +1,7 @@
 """The oracle against fixtures produced by EXECUTING the reference's python
 (tests/golden/make_golden.py).  These pin the restated wiring of CGModel.forward,
 TensorProductConvLayer / tp_scatter_*, FasterTensorProduct, the pose update and the
-reverse-diffusion loop."""
+reverse-diffusion loop; the tiny_aa_* cases pin AAModel.forward (models/aa_model.py) the same way."""
 import numpy as np
 import pytest
 import torch
@@ -11,16 +11,16 @@ from oracle import conformer as oc
 from oracle.cg_model import CGModelOracle
 from oracle.layers import faster_tensor_product, gaussian_smearing
 from oracle.sampling import sampling
-from util import fixture_case, load_fixture, rel_err, split_draws, tables, graph_from_dict
+from util import fixture_case, load_fixture, oracle_model, rel_err, split_draws, tables, graph_from_dict
 
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop"]
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2"]
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_forward_matches_reference(name):
     fx, cfg, data_list = fixture_case(name)
     so3_t, tor_t = tables()
-    model = CGModelOracle(cfg, fx["state_dict"], so3_t, tor_t)
+    model = oracle_model(cfg, fx["state_dict"], so3_t, tor_t)
     batch = HeteroBatch.from_data_list(data_list)
     set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
     tr, rot, tor, _, inter = model(batch, return_intermediates=True)
@@ -37,7 +37,7 @@ def test_forward_matches_reference(name):
 def test_sampling_matches_reference(name):
     fx, cfg, data_list = fixture_case(name)
     so3_t, tor_t = tables()
-    model = CGModelOracle(cfg, fx["state_dict"], so3_t, tor_t)
+    model = oracle_model(cfg, fx["state_dict"], so3_t, tor_t)
     s = fx["sampling"]
     B = len(data_list)
     R = int(data_list[0]["ligand"].edge_mask.sum())

@@ -25,6 +25,11 @@ def graph_from_dict(d, pos=None):
     g["receptor"].pos = d["rec_pos"]
     g["receptor"].side_chain_vecs = torch.zeros(d["rec_pos"].shape[0], 10)
     g["receptor", "rec_contact", "receptor"].edge_index = d["rec_edge_index"]
+    if "atom_x" in d:   # all-atom fixture
+        g["atom"].x = d["atom_x"]
+        g["atom"].pos = d["atom_pos"]
+        g["atom", "atom_contact", "atom"].edge_index = d["atom_edge_index"]
+        g["atom", "atom_rec_contact", "receptor"].edge_index = d["atom_rec_edge_index"]
     g["ligand"].x = d["lig_x"]
     g["ligand"].pos = d["lig_pos"] if pos is None else pos
     g["ligand"].edge_mask = d["edge_mask"]
@@ -40,6 +45,15 @@ def fixture_case(name):
     cfg = ModelConfig(**fx["cfg"])
     data_list = [graph_from_dict(fx["graph"], pos=p.clone()) for p in fx["poses"]]
     return fx, cfg, data_list
+
+
+def oracle_model(cfg, state_dict, so3_t=None, tor_t=None, dtype=torch.float32):
+    """The oracle class the configuration selects (get_model's all_atoms switch, utils/utils.py:221-224)."""
+    from oracle.aa_model import AAModelOracle
+    from oracle.cg_model import CGModelOracle
+    if so3_t is None:
+        so3_t, tor_t = tables()
+    return (AAModelOracle if cfg.all_atoms else CGModelOracle)(cfg, state_dict, so3_t, tor_t, dtype)
 
 
 def rel_err(a, b):
