@@ -42,7 +42,21 @@ struct Model::Cx {
   // rebuilt when the edge list they were built for changes (once per forward), and the hidden-row scratch
   struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr;
                  const int* built_goff = nullptr; long epoch = -1; };
-  VnSet vn[4];           // + 2 = ligand-ligand, 3 = rec<-lig (ligand gather nodes: load mode)
+  VnSet vn[9];           // + 2 = ligand-ligand, 3 = rec<-lig (ligand gather nodes: load mode); all_atoms: 4 la, 5 ra, 6 aa, 7 al, 8 ar
+  // ---- all_atoms (models/aa_model.py): receptor heavy atoms = third node type, node rows [nL + nR, N)
+  int nA = 0, maxNa = 0, Eaa = 0, Ear = 0, Ela_cap = 0;
+  int *atom_batch = nullptr, *atom_ptr = nullptr, *atom_x = nullptr;
+  float* atom_pos = nullptr;
+  struct StaticEdges { int E = 0; int *goff = nullptr, *toff = nullptr, *arow = nullptr, *tgt = nullptr, *tslot = nullptr; };
+  StaticEdges se_aa, se_ar, se_ra;   // atom<-atom; atom<-rec (group "ar"); rec<-atom (the flipped group)
+  int *aa_batch = nullptr, *ar_batch = nullptr;
+  float *aa_dist = nullptr, *aa_nvec = nullptr, *aa_ew = nullptr, *atom_edge_base = nullptr;
+  float *ar_dist = nullptr, *ar_nvec = nullptr, *ar_edge_base = nullptr, *atom_node_base = nullptr;
+  int *la_pairrank = nullptr, *la_cnt_l = nullptr, *la_cnt_a = nullptr, *la_offs_l = nullptr, *la_offs_a = nullptr;
+  int *la1_tgt = nullptr, *la1_tslot = nullptr, *la3_tgt = nullptr, *la3_tslot = nullptr, *la_pbatch = nullptr;
+  float *la_dist = nullptr, *la_nvec = nullptr, *la_ew = nullptr, *la_ea = nullptr, *la_gvec = nullptr;
+  float* msg_aa[9] = {};
+  ReduceGroup *rg_aa_all = nullptr, *rg_aa_lig = nullptr;
   long epoch = 0;
   float *Hb = nullptr, *Hb_b = nullptr;   // hidden rows of the main-stream / side-stream group in flight
   ReduceGroup *rg_all, *rg_lig, *rg_ll, *rg_rr;
@@ -117,7 +131,8 @@ struct RunGroup {
   const float *nvec, *ew; float sgn;
   float* msg;
   int esplit = 1;
-  int vn = -1;     // >= 0: receptor-gather topology id -> eligible for the fused kernel
+  int vn = -1;     // >= 0: virtual-node list id -> eligible for the fused kernel
+  bool load = false;   // gather nodes are ligand atoms (few nodes, possibly many edges each): load mode of the fused kernel
 };
 
 // One TensorProductConvLayer in the node-contracted form (k_conv.hip).
@@ -147,7 +162,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const int wg = std::min<int>((int)gi, L.G - 1);
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
-    const bool load_mode = g.vn >= 2;   // ligand gather nodes: contracted rows from k_node_contract, shared by the node's virtual nodes
+    const bool load_mode = g.load;   // ligand gather nodes: contracted rows from k_node_contract, shared by the node's virtual nodes
     // load mode pays when a gather node carries many edges (its rows are shared by >= 2 virtual nodes)
     const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb &&
                       (!load_mode || (m.fused_lig && c.y_chunk <= 0 && (m.fused_lig > 1 || g.ea_rows >= 64 * (long)g.gcount)));
@@ -279,6 +294,13 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   const ddmi_config& cfg = m.cfg;
   const int ns = m.ns, sd = m.sd, H = m.H;
   c.B = cc.num_graphs; c.nL = cc.n_lig; c.nR = cc.n_rec; c.N = c.nL + c.nR; c.Eb = cc.n_bond_edges; c.Err = cc.n_rec_edges;
+  if (cfg.all_atoms) {
+    DDMI_REQUIRE(cc.n_atom > 0 && cc.atom_ptr && cc.atom_x && cc.atom_pos && cc.atom_edge_index && cc.atom_rec_edge_index,
+                 DDMI_ERR_ARG, "all_atoms model: atom arrays missing in ddmi_complex");
+    DDMI_REQUIRE(m.crop_cutoff <= 0.0, DDMI_ERR_ARG, "crop_beyond is not implemented for the all-atom model (aa_model.py:365-367)");
+    c.nA = cc.n_atom; c.Eaa = cc.n_atom_edges; c.Ear = cc.n_atom_rec_edges;
+    c.N = c.nL + c.nR + c.nA;
+  }
   c.nT = cfg.no_torsion ? 0 : cc.n_tor;
   c.lig_ptr_h.assign(cc.lig_ptr, cc.lig_ptr + c.B + 1);
   c.rec_ptr_h.assign(cc.rec_ptr, cc.rec_ptr + c.B + 1);
@@ -306,6 +328,48 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     for (int i = c.rec_ptr_h[b]; i < c.rec_ptr_h[b + 1]; ++i) rec_batch[i] = b;
   }
   c.Ell_cap = c.Eb + c.lig_cap * c.nL;
+  // ---- all_atoms: atom batches and the three static atom relations (gather-ordered CSR + target slots)
+  std::vector<int> atom_ptr_h, atom_batch, aa_tl, aa_gl, ar_atom, ar_rec, aa_batch_h, ar_batch_h;
+  struct HostEdges { std::vector<int> goff, toff, arow, tgt, tslot; };
+  auto build_static = [&](const std::vector<int>& tl, const std::vector<int>& gl, int n_t, int n_g, int tgt_base) {
+    HostEdges h;
+    const int E = (int)tl.size();
+    h.goff.assign(n_g + 1, 0); h.toff.assign(n_t + 1, 0);
+    for (int k = 0; k < E; ++k) {
+      DDMI_REQUIRE(tl[k] >= 0 && tl[k] < n_t && gl[k] >= 0 && gl[k] < n_g, DDMI_ERR_ARG, "atom edge index out of range");
+      h.goff[gl[k] + 1]++; h.toff[tl[k] + 1]++;
+    }
+    for (int i = 0; i < n_g; ++i) h.goff[i + 1] += h.goff[i];
+    for (int i = 0; i < n_t; ++i) h.toff[i + 1] += h.toff[i];
+    h.arow.resize(E); h.tgt.resize(E); h.tslot.resize(E);
+    std::vector<int> cur(h.goff.begin(), h.goff.end() - 1), tcur(h.toff.begin(), h.toff.end() - 1);
+    for (int k = 0; k < E; ++k) h.arow[cur[gl[k]]++] = k;
+    for (int e = 0; e < E; ++e) { const int k = h.arow[e]; h.tgt[e] = tgt_base + tl[k]; h.tslot[e] = tcur[tl[k]]++; }
+    return h;
+  };
+  HostEdges h_aa, h_ar, h_ra;
+  if (cfg.all_atoms) {
+    atom_ptr_h.assign(cc.atom_ptr, cc.atom_ptr + c.B + 1);
+    DDMI_REQUIRE(atom_ptr_h[0] == 0 && atom_ptr_h[c.B] == c.nA, DDMI_ERR_ARG, "atom_ptr does not span the atom array");
+    atom_batch.resize(c.nA);
+    for (int b = 0; b < c.B; ++b) {
+      const int na = atom_ptr_h[b + 1] - atom_ptr_h[b], nl = c.lig_ptr_h[b + 1] - c.lig_ptr_h[b];
+      c.maxNa = std::max(c.maxNa, na);
+      c.Ela_cap += nl * na;
+      for (int i = atom_ptr_h[b]; i < atom_ptr_h[b + 1]; ++i) atom_batch[i] = b;
+    }
+    std::vector<int> aa_index(2 * (size_t)c.Eaa), ar_index(2 * (size_t)c.Ear);
+    DDMI_CHECK_HIP(hipMemcpy(aa_index.data(), cc.atom_edge_index, aa_index.size() * 4, hipMemcpyDeviceToHost));
+    DDMI_CHECK_HIP(hipMemcpy(ar_index.data(), cc.atom_rec_edge_index, ar_index.size() * 4, hipMemcpyDeviceToHost));
+    aa_tl.assign(aa_index.begin(), aa_index.begin() + c.Eaa); aa_gl.assign(aa_index.begin() + c.Eaa, aa_index.end());
+    ar_atom.assign(ar_index.begin(), ar_index.begin() + c.Ear); ar_rec.assign(ar_index.begin() + c.Ear, ar_index.end());
+    h_aa = build_static(aa_tl, aa_gl, c.nA, c.nA, c.nL + c.nR);    // atom <- atom
+    h_ar = build_static(ar_atom, ar_rec, c.nA, c.nR, c.nL + c.nR);  // atom <- residue  (group "ar", aa_model.py:401-403)
+    h_ra = build_static(ar_rec, ar_atom, c.nR, c.nA, c.nL);         // residue <- atom  (flip(ar))
+    aa_batch_h.resize(c.Eaa); ar_batch_h.resize(c.Ear);
+    for (int k = 0; k < c.Eaa; ++k) aa_batch_h[k] = atom_batch[aa_tl[k]];     // atom.batch[edge_index[0]] (aa_model.py:332)
+    for (int k = 0; k < c.Ear; ++k) ar_batch_h[k] = atom_batch[ar_atom[k]];   // (aa_model.py:335)
+  }
   // bonds: ranks inside the gather (edge_index[1]) and target (edge_index[0]) lists
   std::vector<int> bsrc(c.Eb), bdst(c.Eb), bgr(c.Eb), btr(c.Eb), bg(c.nL, 0), bt(c.nL, 0);
   for (int k = 0; k < c.Eb; ++k) {
@@ -342,6 +406,35 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     rr_gnode[e] = rr_dst[k];
   }
   // ---- uploads
+  if (cfg.all_atoms) {
+    c.atom_batch = dup(m, "atom_batch", atom_batch); c.atom_ptr = dup(m, nullptr, atom_ptr_h);
+    c.atom_x = dalloc<int>(m, nullptr, {c.nA * 4});
+    DDMI_CHECK_HIP(hipMemcpy(c.atom_x, cc.atom_x, (size_t)c.nA * 4 * 4, hipMemcpyDeviceToDevice));
+    c.atom_pos = dalloc<float>(m, nullptr, {c.nA * 3});
+    DDMI_CHECK_HIP(hipMemcpy(c.atom_pos, cc.atom_pos, (size_t)c.nA * 12, hipMemcpyDeviceToDevice));
+    auto up_edges = [&](const HostEdges& h, const char* name) {
+      Cx::StaticEdges e;
+      e.E = (int)h.arow.size();
+      e.goff = dup(m, name, h.goff); e.toff = dup(m, nullptr, h.toff); e.arow = dup(m, nullptr, h.arow);
+      e.tgt = dup(m, nullptr, h.tgt); e.tslot = dup(m, nullptr, h.tslot);
+      return e;
+    };
+    c.se_aa = up_edges(h_aa, "aa_goff"); c.se_ar = up_edges(h_ar, "ar_goff"); c.se_ra = up_edges(h_ra, "ra_goff");
+    c.aa_batch = dup(m, nullptr, aa_batch_h); c.ar_batch = dup(m, nullptr, ar_batch_h);
+    int* aa_src = dup(m, nullptr, aa_tl); int* aa_dst = dup(m, nullptr, aa_gl);
+    int* ar_src = dup(m, nullptr, ar_atom); int* ar_dst = dup(m, nullptr, ar_rec);
+    c.aa_dist = dalloc<float>(m, nullptr, {c.Eaa}); c.aa_nvec = dalloc<float>(m, nullptr, {c.Eaa, 3});
+    c.aa_ew = cfg.smooth_edges ? dalloc<float>(m, nullptr, {c.Eaa}) : nullptr;
+    c.ar_dist = dalloc<float>(m, nullptr, {c.Ear}); c.ar_nvec = dalloc<float>(m, nullptr, {c.Ear, 3});
+    c.atom_edge_base = dalloc<float>(m, nullptr, {c.Eaa, ns}); c.ar_edge_base = dalloc<float>(m, nullptr, {c.Ear, ns});
+    c.atom_node_base = dalloc<float>(m, "atom_node_base", {c.nA, XS}, true);
+    // static geometry: vec = pos[edge_index[1]] - pos[edge_index[0]] (aa_model.py:573-576, 627-629)
+    launch_rec_edge_geom(c.atom_pos, aa_src, aa_dst, c.Eaa, cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.aa_dist, c.aa_nvec,
+                         c.aa_ew, s);
+    float* rp = dalloc<float>(m, nullptr, {c.nR * 3});
+    DDMI_CHECK_HIP(hipMemcpy(rp, cc.rec_pos, (size_t)c.nR * 12, hipMemcpyDeviceToDevice));
+    launch_rec_edge_geom(c.atom_pos, ar_src, ar_dst, c.Ear, 0.f, c.ar_dist, c.ar_nvec, nullptr, s, rp);
+  }
   c.lig_batch = dup(m, "lig_batch", lig_batch); c.rec_batch = dup(m, "rec_batch", rec_batch);
   c.lig_ptr = dup(m, nullptr, c.lig_ptr_h); c.rec_ptr = dup(m, nullptr, c.rec_ptr_h);
   c.lig_x = dalloc<int>(m, nullptr, {c.nL * 16});
@@ -403,9 +496,9 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.pbatch = dalloc<int>(m, nullptr, {c.Elr_cap}); c.pdist = dalloc<float>(m, "cross_dist", {c.Elr_cap});
   c.pnvec = dalloc<float>(m, nullptr, {c.Elr_cap, 3}); c.pew = cfg.smooth_edges ? dalloc<float>(m, nullptr, {c.Elr_cap}) : nullptr;
   c.cross_ea = dalloc<float>(m, "cross_ea", {c.Elr_cap, ns});
-  const int max_rows = std::max(std::max(c.Ell_cap, c.Elr_cap), c.Err);
+  const int max_rows = std::max(std::max(std::max(c.Ell_cap, c.Elr_cap), std::max(c.Err, c.Eaa)), std::max(c.Ear, c.Ela_cap));
   c.HE = dalloc<float>(m, nullptr, {max_rows, H}); c.P = dalloc<float>(m, nullptr, {N, H}); c.Q = dalloc<float>(m, nullptr, {N, H});
-  c.HE_b = dalloc<float>(m, nullptr, {std::max(c.Ell_cap, c.Elr_cap), H}); c.P_b = dalloc<float>(m, nullptr, {N, H});
+  c.HE_b = dalloc<float>(m, nullptr, {std::max(std::max(c.Ell_cap, c.Elr_cap), c.Ela_cap), H}); c.P_b = dalloc<float>(m, nullptr, {N, H});
   c.Q_b = dalloc<float>(m, nullptr, {N, H}); c.rowbias_b = dalloc<float>(m, nullptr, {B, H});
   int HKp = 0, NTs = 0;
   auto upd = [&](const ConvW& L) { HKp = std::max(HKp, L.HKp); NTs = std::max(NTs, L.NTs); };
@@ -414,7 +507,9 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   for (auto& L : m.rec_emb_layers) upd(L);
   if (const char* e = getenv("DDMI_Y_CHUNK")) c.y_chunk = atoi(e);
   if (const char* e = getenv("DDMI_ESPLIT")) c.esplit_lig = std::max(0, atoi(e));
-  const int y_nodes = c.y_chunk > 0 ? std::min(c.y_chunk, std::max(nL, nR)) : std::max(nL, nR);
+  // rows of the HBM-resident contracted table: receptor / atom gather groups only need them when the fused kernel is off
+  const int y_big = std::max(std::max(nL, nR), m.fused ? 0 : c.nA);
+  const int y_nodes = c.y_chunk > 0 ? std::min(c.y_chunk, y_big) : y_big;
   int ycols = NTs;   // granule-major rows (load mode of k_conv_fused) are 64 columns per granule
   for (auto& L : m.conv_layers) ycols = std::max(ycols, 64 * L.n_fgran);
   for (auto& L : m.lig_emb_layers) ycols = std::max(ycols, 64 * L.n_fgran);
@@ -425,17 +520,21 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     for (auto& L : m.conv_layers) HKq = std::max(HKq, L.HKq);
     for (auto& L : m.rec_emb_layers) HKq = std::max(HKq, L.HKq);
     for (auto& L : m.lig_emb_layers) HKq = std::max(HKq, L.HKq);
-    const int ecap_v[4] = {c.Elr_cap, c.Err, c.Ell_cap, c.Elr_cap};
-    const int gn_v[4] = {nR, nR, nL, nL};
-    const char* names[4] = {"vn_off_cross", "vn_off_rr", "vn_off_ll", "vn_off_rl"};
+    // virtual-node lists: 0 lig<-rec, 1 rec-rec, 2 lig-lig, 3 rec<-lig; all_atoms: 4 lig<-atom, 5 rec<-atom, 6 atom-atom,
+    // 7 atom<-lig, 8 atom<-rec.  Ligand-gather lists (2, 3, 7) are load-mode lists (every node padded to an even count).
+    const int ecap_v[9] = {c.Elr_cap, c.Err, c.Ell_cap, c.Elr_cap, c.Ela_cap, c.Ear, c.Eaa, c.Ela_cap, c.Ear};
+    const int gn_v[9] = {nR, nR, nL, nL, c.nA, c.nA, c.nA, nL, nR};
+    const bool lig_v[9] = {false, false, true, true, false, false, false, true, false};
+    const char* names[9] = {"vn_off_cross", "vn_off_rr", "vn_off_ll", "vn_off_rl", "vn_off_la", "vn_off_ra", "vn_off_aa",
+                            "vn_off_al", "vn_off_ar"};
     int vmax = 0, vmax_b = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (cfg.all_atoms ? 9 : 4); ++i) {
       Cx::VnSet& vs = c.vn[i];
-      vs.vcap = (i >= 2 ? 2 : 1) * gn_v[i] + ecap_v[i] / 32 + 2;   // load-mode lists pad every node to an even count
+      vs.vcap = (lig_v[i] ? 2 : 1) * gn_v[i] + ecap_v[i] / 32 + 2;
       vs.cnt = dalloc<int>(m, nullptr, {gn_v[i] + 1}); vs.voff = dalloc<int>(m, names[i], {gn_v[i] + 1});
       vs.node = dalloc<int>(m, nullptr, {vs.vcap}); vs.e0 = dalloc<int>(m, nullptr, {vs.vcap});
       vmax = std::max(vmax, vs.vcap);
-      if (i >= 2) vmax_b = std::max(vmax_b, vs.vcap);
+      if (lig_v[i]) vmax_b = std::max(vmax_b, vs.vcap);
     }
     c.Hb = HKq > 0 ? dalloc<float>(m, nullptr, {vmax, 32, HKq}) : nullptr;
     c.Hb_b = HKq > 0 ? dalloc<float>(m, nullptr, {vmax_b, 32, HKq}) : nullptr;
@@ -457,6 +556,30 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     c.rg_all_crop = m.cpool.upload(rc);
     std::vector<ReduceGroup> r2c = {{c.toff2, c.msg[2], nL, nR}};  // cropped embedding layers run in the full node table
     c.rg_rr_crop = m.cpool.upload(r2c);
+    if (cfg.all_atoms) {
+      // dynamic ligand <-> atom relation (radius lig_max_radius, aa_model.py:606-614): same pair machinery as the cross graph
+      const int nA = c.nA;
+      c.la_pairrank = dalloc<int>(m, nullptr, {nL, c.maxNa}); c.la_cnt_l = dalloc<int>(m, nullptr, {nL});
+      c.la_cnt_a = dalloc<int>(m, nullptr, {nA}); c.la_offs_l = dalloc<int>(m, "offs_la_l", {nL + 1});
+      c.la_offs_a = dalloc<int>(m, "offs_la_a", {nA + 1});
+      c.la1_tgt = dalloc<int>(m, nullptr, {c.Ela_cap}); c.la1_tslot = dalloc<int>(m, nullptr, {c.Ela_cap});
+      c.la3_tgt = dalloc<int>(m, nullptr, {c.Ela_cap}); c.la3_tslot = dalloc<int>(m, nullptr, {c.Ela_cap});
+      c.la_pbatch = dalloc<int>(m, nullptr, {c.Ela_cap}); c.la_dist = dalloc<float>(m, nullptr, {c.Ela_cap});
+      c.la_nvec = dalloc<float>(m, nullptr, {c.Ela_cap, 3});
+      c.la_ew = cfg.smooth_edges ? dalloc<float>(m, nullptr, {c.Ela_cap}) : nullptr;
+      c.la_ea = dalloc<float>(m, nullptr, {c.Ela_cap, ns}); c.la_gvec = dalloc<float>(m, nullptr, {B, ns});
+      // message buffers of the nine groups [ll, lr, la, rr, rl, ra, aa, al, ar] (aa_model.py:399-403), reduced per target type
+      const int ecap9[9] = {c.Ell_cap, c.Elr_cap, c.Ela_cap, c.Err, c.Elr_cap, c.Ear, c.Eaa, c.Ela_cap, c.Ear};
+      for (int g = 0; g < 9; ++g) c.msg_aa[g] = (g == 0 || g == 1 || g == 3 || g == 4) ? c.msg[g == 0 ? 0 : g == 1 ? 1 : g == 3 ? 2 : 3]
+                                                                                          : dalloc<float>(m, nullptr, {ecap9[g], XS});
+      std::vector<ReduceGroup> r9 = {{c.toff_ll, c.msg_aa[0], 0, nL}, {c.offs_l, c.msg_aa[1], 0, nL}, {c.la_offs_l, c.msg_aa[2], 0, nL},
+                                     {c.rr_toff, c.msg_aa[3], nL, nR}, {c.offs_r, c.msg_aa[4], nL, nR}, {c.se_ra.toff, c.msg_aa[5], nL, nR},
+                                     {c.se_aa.toff, c.msg_aa[6], nL + nR, nA}, {c.la_offs_a, c.msg_aa[7], nL + nR, nA},
+                                     {c.se_ar.toff, c.msg_aa[8], nL + nR, nA}};
+      c.rg_aa_all = m.cpool.upload(r9);
+      std::vector<ReduceGroup> r3(r9.begin(), r9.begin() + 3);
+      c.rg_aa_lig = m.cpool.upload(r3);
+    }
   }
   const ConvW& F = m.final_conv;
   c.c_dist = dalloc<float>(m, nullptr, {nL}); c.c_nvec = dalloc<float>(m, nullptr, {nL, 3});
@@ -498,6 +621,15 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     launch_add_rowvec(c.rec_node_base, XS, cat, ns, nullptr, 0, nullptr, nR, ns, 0, s);
   }
   c.rec_base_dim = ns;
+  if (cfg.all_atoms) {   // aa_model.py:288-294: atom encoder (sum of 4 embeddings, no extra features), static edge embeddings
+    float* emb = dalloc<float>(m, nullptr, {c.nA, ns});
+    launch_lig_node_embed(c.atom_x, c.nA, m.atom_emb, m.atom_emb_off, 4, ns, emb, s);
+    launch_add_rowvec(c.atom_node_base, XS, emb, ns, nullptr, 0, nullptr, c.nA, ns, 0, s);
+    launch_edge_mlp(mlp_args(m.atom_edge, ns, c.Eaa, nullptr, c.aa_dist, m.off_lig, m.D, m.coeff_lig, 0, m.atom_edge.b0, nullptr,
+                             c.atom_edge_base), s);
+    launch_edge_mlp(mlp_args(m.ar_edge, ns, c.Ear, nullptr, c.ar_dist, m.off_rec, m.D, m.coeff_rec, 0, m.ar_edge.b0, nullptr,
+                             c.ar_edge_base), s);
+  }
   c.rec_node_enc = nullptr;
   if (!m.rec_emb_layers.empty()) {
     c.rec_node_enc = dalloc<float>(m, nullptr, {nR, XS}, true);
@@ -567,12 +699,13 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   }
   RunGroup g_ll{0, nL, 0, nL, c.goff_ll, c.ll_tgt, c.ll_tslot, nullptr, c.ll_ea, c.Ell_cap, c.goff_ll + nL, nullptr,
                 nullptr, c.ll_nvec, c.ll_ew, 1.f, c.msg[0]};
-  g_ll.vn = 2;
+  g_ll.vn = 2; g_ll.load = true;
   int xi = 0;
   for (size_t i = 0; i < m.lig_emb_layers.size(); ++i, ++xi)
     run_conv(m, m.lig_emb_layers[i], {g_ll}, c.rg_ll, 1, c.X[xi], c.X[xi + 1], 0, nL, s);
   // ---- per-step receptor crop (utils/sampling.py:104-109): residue mask + re-compacted contact graph
   const bool crop = m.crop_cutoff > 0.0;
+  DDMI_REQUIRE(!(crop && cfg.all_atoms), DDMI_ERR_ARG, "crop_beyond is not implemented for the all-atom model (aa_model.py:365-367)");
   const int* keep = nullptr;
   if (crop) {
     const double cd = m.crop_cutoff;
@@ -618,15 +751,55 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
                       1.f, c.msg[2]};
   RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                 nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
-  g_lr.vn = 0; g_rr.vn = 1; g_rl.vn = 3;
+  g_lr.vn = 0; g_rr.vn = 1; g_rl.vn = 3; g_rl.load = true;
   // ligand gather nodes carry up to Nr edges each: their 32-edge passes are dealt over several workgroups
   g_rl.esplit = c.esplit_lig > 0 ? c.esplit_lig : std::max(1, std::min(8, (c.Elr_cap / std::max(nL, 1) + 63) / 64));
   const int Lc = (int)m.conv_layers.size();
-  t_phase.reset();
-  for (int l = 0; l < Lc; ++l, ++xi) {
-    if (l < Lc - 1)
-      run_conv(m, m.conv_layers[l], {g_ll, g_lr, g_rr, g_rl}, crop ? c.rg_all_crop : c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s);
-    else run_conv(m, m.conv_layers[l], {g_ll, g_lr}, c.rg_lig, 2, c.X[xi], c.X[xi + 1], 0, nL, s);
+  if (cfg.all_atoms) {
+    // ---- all-atom model (aa_model.py:364-436): atom rows, ligand<->atom radius graph, nine edge groups
+    const int nA = c.nA, aB = nL + nR;
+    launch_add_rowvec(c.X[xi] + (size_t)aB * XS, XS, c.atom_node_base, XS, c.rec_sig, ns, c.atom_batch, nA, ns, ns, s);
+    launch_cross_count(lig_pos, c.atom_pos, c.lig_batch, c.atom_batch, c.lig_ptr, c.atom_ptr, nL, nA, c.maxNa, nullptr,
+                       cfg.lig_max_radius, nullptr, c.la_pairrank, c.la_cnt_l, c.la_cnt_a, s);
+    launch_exclusive_scan(c.la_cnt_l, c.la_offs_l, nL, s);
+    launch_exclusive_scan(c.la_cnt_a, c.la_offs_a, nA, s);
+    launch_cross_fill(lig_pos, c.atom_pos, c.atom_batch, c.lig_ptr, c.atom_ptr, nL, nA, c.maxNa, c.la_pairrank, c.la_offs_l,
+                      c.la_offs_a, nullptr, cfg.lig_max_radius, cfg.smooth_edges, c.la1_tgt, c.la1_tslot, c.la3_tgt, c.la3_tslot,
+                      c.la_pbatch, c.la_dist, c.la_nvec, c.la_ew, s, aB);
+    gemm(c.temb, sd, m.la_edge.W0, m.la_edge.in, m.la_edge.b0, c.la_gvec, ns, B, ns, sd, 0, s);
+    launch_edge_mlp(mlp_args(m.la_edge, ns, c.Ela_cap, c.la_offs_l + nL, c.la_dist, m.off_lig, m.D, m.coeff_lig, sd, c.la_gvec,
+                             c.la_pbatch, c.la_ea), s);
+    // groups in the reference's order [ll, lr, la, rr, rl, ra, aa, al, ar]; the flipped groups reuse the forward
+    // spherical harmonics (aa_model.py:411-412), so every group has sgn = +1
+    RunGroup a_ll = g_ll, a_lr = g_lr, a_rr = g_rr, a_rl = g_rl;
+    a_rl.sgn = 1.f;
+    a_ll.msg = c.msg_aa[0]; a_lr.msg = c.msg_aa[1]; a_rr.msg = c.msg_aa[3]; a_rl.msg = c.msg_aa[4];
+    RunGroup a_la{aB, nA, 0, nL, c.la_offs_a, c.la1_tgt, c.la1_tslot, c.la1_tslot, c.la_ea, c.Ela_cap, c.la_offs_l + nL, nullptr,
+                  nullptr, c.la_nvec, c.la_ew, 1.f, c.msg_aa[2]};
+    RunGroup a_ra{aB, nA, nL, nR, c.se_ra.goff, c.se_ra.tgt, c.se_ra.tslot, c.se_ra.arow, c.ar_edge_base, c.Ear, nullptr, c.rec_sig,
+                  c.ar_batch, c.ar_nvec, nullptr, 1.f, c.msg_aa[5]};
+    RunGroup a_aa{aB, nA, aB, nA, c.se_aa.goff, c.se_aa.tgt, c.se_aa.tslot, c.se_aa.arow, c.atom_edge_base, c.Eaa, nullptr, c.rec_sig,
+                  c.aa_batch, c.aa_nvec, c.aa_ew, 1.f, c.msg_aa[6]};
+    RunGroup a_al{0, nL, aB, nA, c.la_offs_l, c.la3_tgt, c.la3_tslot, nullptr, c.la_ea, c.Ela_cap, c.la_offs_l + nL, nullptr,
+                  nullptr, c.la_nvec, c.la_ew, 1.f, c.msg_aa[7]};
+    RunGroup a_ar{nL, nR, aB, nA, c.se_ar.goff, c.se_ar.tgt, c.se_ar.tslot, c.se_ar.arow, c.ar_edge_base, c.Ear, nullptr, c.rec_sig,
+                  c.ar_batch, c.ar_nvec, nullptr, 1.f, c.msg_aa[8]};
+    a_la.vn = 4; a_ra.vn = 5; a_aa.vn = 6; a_al.vn = 7; a_al.load = true; a_ar.vn = 8;
+    a_al.esplit = c.esplit_lig > 0 ? c.esplit_lig : 1;
+    t_phase.reset();
+    for (int l = 0; l < Lc; ++l, ++xi) {
+      if (l < Lc - 1)
+        run_conv(m, m.conv_layers[l], {a_ll, a_lr, a_la, a_rr, a_rl, a_ra, a_aa, a_al, a_ar}, c.rg_aa_all, 9, c.X[xi], c.X[xi + 1], 0,
+                 c.N, s);
+      else run_conv(m, m.conv_layers[l], {a_ll, a_lr, a_la}, c.rg_aa_lig, 3, c.X[xi], c.X[xi + 1], 0, nL, s);
+    }
+  } else {
+    t_phase.reset();
+    for (int l = 0; l < Lc; ++l, ++xi) {
+      if (l < Lc - 1)
+        run_conv(m, m.conv_layers[l], {g_ll, g_lr, g_rr, g_rl}, crop ? c.rg_all_crop : c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s);
+      else run_conv(m, m.conv_layers[l], {g_ll, g_lr}, c.rg_lig, 2, c.X[xi], c.X[xi + 1], 0, nL, s);
+    }
   }
   const float* XL = c.X[xi];
   PhaseTimer t_read(m, "readouts", s);

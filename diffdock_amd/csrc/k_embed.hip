@@ -209,13 +209,13 @@ void launch_edge_mlp(const EdgeMlpArgs& a, hipStream_t s) {
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
-__global__ void k_rec_edge_geom(const float* __restrict__ pos, const int* __restrict__ src, const int* __restrict__ dst,
-                                int E, float smooth_max, float* __restrict__ dist, float* __restrict__ nvec,
-                                float* __restrict__ ew) {
+__global__ void k_rec_edge_geom(const float* __restrict__ pos, const float* __restrict__ pos_d, const int* __restrict__ src,
+                                const int* __restrict__ dst, int E, float smooth_max, float* __restrict__ dist,
+                                float* __restrict__ nvec, float* __restrict__ ew) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int s = src[e], d = dst[e];
-  const float vx = pos[3 * d] - pos[3 * s], vy = pos[3 * d + 1] - pos[3 * s + 1], vz = pos[3 * d + 2] - pos[3 * s + 2];
+  const float vx = pos_d[3 * d] - pos[3 * s], vy = pos_d[3 * d + 1] - pos[3 * s + 1], vz = pos_d[3 * d + 2] - pos[3 * s + 2];
   const float dd = sqrtf(vx * vx + vy * vy + vz * vz);
   const float inv = 1.f / fmaxf(dd, 1e-12f);
   dist[e] = dd;
@@ -226,9 +226,10 @@ __global__ void k_rec_edge_geom(const float* __restrict__ pos, const int* __rest
   }
 }
 void launch_rec_edge_geom(const float* pos, const int* src, const int* dst, int E, float smooth_max, float* dist,
-                          float* nvec, float* ew, hipStream_t s) {
+                          float* nvec, float* ew, hipStream_t s, const float* pos_dst) {
   if (E <= 0) return;
-  hipLaunchKernelGGL(k_rec_edge_geom, dim3(cdiv(E, 256)), dim3(256), 0, s, pos, src, dst, E, smooth_max, dist, nvec, ew);
+  hipLaunchKernelGGL(k_rec_edge_geom, dim3(cdiv(E, 256)), dim3(256), 0, s, pos, pos_dst ? pos_dst : pos, src, dst, E,
+                     smooth_max, dist, nvec, ew);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

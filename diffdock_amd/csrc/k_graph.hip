@@ -206,7 +206,7 @@ __global__ void k_cross_fill(const float* __restrict__ lpos, const float* __rest
                              const int* __restrict__ offs_r, const float* __restrict__ cutoff, float const_cutoff,
                              int smooth, int* __restrict__ g1_tgt, int* __restrict__ g1_tslot, int* __restrict__ g3_tgt,
                              int* __restrict__ g3_tslot, int* __restrict__ pbatch, float* __restrict__ pdist,
-                             float* __restrict__ pnvec, float* __restrict__ pew) {
+                             float* __restrict__ pnvec, float* __restrict__ pew, int rbase) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nR) return;
   const int b = rbatch[j], lo = lptr[b], hi = lptr[b + 1], jl = j - rptr[b];
@@ -218,7 +218,7 @@ __global__ void k_cross_fill(const float* __restrict__ lpos, const float* __rest
     const int e_l = offs_l[i] + rl, e_r = offs_r[j] + rr++;
     g1_tgt[e_r] = i;
     g1_tslot[e_r] = e_l;
-    g3_tgt[e_l] = nL + j;
+    g3_tgt[e_l] = rbase + j;   // global id of the second node type (residues: nL, atoms: nL + nR)
     g3_tslot[e_l] = e_r;
     pbatch[e_l] = b;
     write_geom(rpos[3 * j] - lpos[3 * i], rpos[3 * j + 1] - lpos[3 * i + 1], rpos[3 * j + 2] - lpos[3 * i + 2],
@@ -228,11 +228,11 @@ __global__ void k_cross_fill(const float* __restrict__ lpos, const float* __rest
 void launch_cross_fill(const float* lpos, const float* rpos, const int* rbatch, const int* lptr, const int* rptr, int nL,
                        int nR, int maxNr, const int* pairrank, const int* offs_l, const int* offs_r, const float* cutoff,
                        float const_cutoff, int smooth, int* g1_tgt, int* g1_tslot, int* g3_tgt, int* g3_tslot,
-                       int* pbatch, float* pdist, float* pnvec, float* pew, hipStream_t s) {
+                       int* pbatch, float* pdist, float* pnvec, float* pew, hipStream_t s, int rbase) {
   if (nR <= 0) return;
   hipLaunchKernelGGL(k_cross_fill, dim3(cdiv(nR, 64)), dim3(64), 0, s, lpos, rpos, rbatch, lptr, rptr, nL, nR, maxNr,
                      pairrank, offs_l, offs_r, cutoff, const_cutoff, smooth, g1_tgt, g1_tslot, g3_tgt, g3_tslot, pbatch,
-                     pdist, pnvec, pew);
+                     pdist, pnvec, pew, rbase < 0 ? nL : rbase);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

@@ -150,7 +150,8 @@ void launch_rr_filter(const int* keep, const int* goff, const int* tgt, const in
 void launch_cross_fill(const float* lpos, const float* rpos, const int* rbatch, const int* lptr, const int* rptr, int nL,
                        int nR, int maxNr, const int* pairrank, const int* offs_l, const int* offs_r, const float* cutoff,
                        float const_cutoff, int smooth, int* g1_tgt, int* g1_tslot, int* g3_tgt, int* g3_tslot,
-                       int* pbatch, float* pdist, float* pnvec, float* pew, hipStream_t s);
+                       int* pbatch, float* pdist, float* pnvec, float* pew, hipStream_t s,
+                       int rbase = -1 /* first global id of the second node type; default nL */);
 void launch_cross_cutoff(const float* t_tr, int B, float smin, float smax, float* out, hipStream_t s);
 void launch_tor_radius(const float* pos, const int* ptr, const int* tor_u, const int* tor_v, const int* tor_batch, int nT,
                        float r, int cap, float smooth_max, int* cnt, int* atom, float* dist, float* nvec, float* ew,
@@ -175,8 +176,9 @@ struct EdgeMlpArgs {
   float* out = nullptr; int ldo = 0;
 };
 void launch_edge_mlp(const EdgeMlpArgs& a, hipStream_t s);
+// vec = pos_dst[dst] - pos[src] (pos_dst = nullptr: same array): static receptor / atom relations
 void launch_rec_edge_geom(const float* pos, const int* src, const int* dst, int E, float smooth_max, float* dist,
-                          float* nvec, float* ew, hipStream_t s);
+                          float* nvec, float* ew, hipStream_t s, const float* pos_dst = nullptr);
 void launch_concat_rec_input(const float* rec_x, int ldx, const float* emb, int ns, int lm, int nR, float* out,
                              hipStream_t s);
 

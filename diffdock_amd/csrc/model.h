@@ -68,6 +68,8 @@ struct Model {
   float* lig_emb = nullptr; int* lig_emb_off = nullptr;
   Mlp2W lig_enc;     // additional_features_embedder as (W0 = [ns][ns+sd], b0)
   Mlp2W lig_edge, rec_edge, rec_sigma, cross_edge, center_edge, final_edge, tr_final, rot_final;
+  Mlp2W atom_edge, ar_edge, la_edge;            // all_atoms (cross_edge then holds lr_edge_embedding)
+  float* atom_emb = nullptr; int* atom_emb_off = nullptr;
   float* rec_emb = nullptr; float *rec_enc_W = nullptr, *rec_enc_b = nullptr;
   float *off_lig = nullptr, *off_rec = nullptr, *off_cross = nullptr, *off_center = nullptr;
   float coeff_lig = 0, coeff_rec = 0, coeff_cross = 0, coeff_center = 0;

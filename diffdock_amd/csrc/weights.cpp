@@ -9,10 +9,11 @@ namespace ddmi {
 
 static const int LIG_DIMS[16] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2};  // datasets/process_mols.py:59-76
 static const int REC_DIMS[1] = {38};                                                   // process_mols.py:85-87
+static const int ATOM_DIMS[4] = {38, 119, 23, 38};                                     // process_mols.py:78-83 (rec_atom_feature_dims)
 
 DevicePool::~DevicePool() { release(); }
 void DevicePool::release() {
-  for (void* p : blocks_) hipFree(p);
+  for (void* p : blocks_) (void)hipFree(p);
   blocks_.clear();
   total_ = 0;
 }
@@ -46,6 +47,7 @@ static Irreps layer_irreps(const ddmi_config& c, int i) {
 
 static int conv_groups(const ddmi_config& c, int l) {
   if (!c.differentiate_convolutions) return 1;
+  if (c.all_atoms) return l == c.num_conv_layers - 1 ? 3 : 9;   // models/aa_model.py:157
   return l == c.num_conv_layers - 1 ? 2 : 4;
 }
 
@@ -115,10 +117,23 @@ void build_weight_spec(Model& m) {
   const int K = c.num_prot_emb_layers, Lc = c.num_conv_layers;
   encoder("lig_node_embedding", LIG_DIMS, 16, sd);
   mlp("lig_edge_embedding", m.nf + sd + m.D, ns, ns);
-  encoder("rec_node_embedding", REC_DIMS, 1, m.lm);
-  mlp("rec_edge_embedding", m.D, ns, ns);
-  mlp("rec_sigma_embedding", sd, ns, ns);
-  mlp("cross_edge_embedding", sd + m.Dc, ns, ns);
+  if (c.all_atoms) {   // models/aa_model.py:90-103
+    DDMI_REQUIRE(K == 0, DDMI_ERR_ARG, "all_atoms with receptor embedding layers is not built");
+    DDMI_REQUIRE(m.D == m.Dc, DDMI_ERR_ARG, "AAModel feeds lig_distance_expansion into la_edge_embedding: distance_embed_dim must equal cross_distance_embed_dim");
+    mlp("rec_sigma_embedding", sd, ns, ns);
+    encoder("rec_node_embedding", REC_DIMS, 1, m.lm);
+    mlp("rec_edge_embedding", m.D, ns, ns);
+    encoder("atom_node_embedding", ATOM_DIMS, 4, 0);
+    mlp("atom_edge_embedding", m.D, ns, ns);
+    mlp("lr_edge_embedding", sd + m.Dc, ns, ns);
+    mlp("ar_edge_embedding", m.D, ns, ns);
+    mlp("la_edge_embedding", sd + m.Dc, ns, ns);
+  } else {
+    encoder("rec_node_embedding", REC_DIMS, 1, m.lm);
+    mlp("rec_edge_embedding", m.D, ns, ns);
+    mlp("rec_sigma_embedding", sd, ns, ns);
+    mlp("cross_edge_embedding", sd + m.Dc, ns, ns);
+  }
   S.push_back({"lig_distance_expansion.offset", {m.D}});
   S.push_back({"rec_distance_expansion.offset", {m.D}});
   S.push_back({"cross_distance_expansion.offset", {m.Dc}});
@@ -407,7 +422,23 @@ void commit_weights(Model& m) {
   m.lig_edge = up_mlp(m, "lig_edge_embedding");
   m.rec_edge = up_mlp(m, "rec_edge_embedding");
   m.rec_sigma = up_mlp(m, "rec_sigma_embedding");
-  m.cross_edge = up_mlp(m, "cross_edge_embedding");
+  m.cross_edge = up_mlp(m, c.all_atoms ? "lr_edge_embedding" : "cross_edge_embedding");
+  if (c.all_atoms) {
+    std::vector<float> emb;
+    std::vector<int> off;
+    int rows = 0;
+    for (int i = 0; i < 4; ++i) {
+      off.push_back(rows);
+      const HostTensor& t = W(m, "atom_node_embedding.atom_embedding_list." + std::to_string(i) + ".weight");
+      emb.insert(emb.end(), t.data.begin(), t.data.end());
+      rows += ATOM_DIMS[i];
+    }
+    m.atom_emb = m.wpool.upload(emb);
+    m.atom_emb_off = m.wpool.upload(off);
+    m.atom_edge = up_mlp(m, "atom_edge_embedding");
+    m.ar_edge = up_mlp(m, "ar_edge_embedding");
+    m.la_edge = up_mlp(m, "la_edge_embedding");
+  }
   m.center_edge = up_mlp(m, "center_edge_embedding");
   m.tr_final = up_mlp(m, "tr_final_layer");
   m.rot_final = up_mlp(m, "rot_final_layer");

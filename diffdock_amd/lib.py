@@ -30,13 +30,16 @@ class Config(C.Structure):
                                          "differentiate_convolutions", "embed_also_ligand", "batch_norm", "smooth_edges",
                                          "odd_parity", "no_torsion", "scale_by_sigma", "fixed_center_conv")] + \
                [(n, C.c_float) for n in ("embedding_scale", "tr_sigma_min", "tr_sigma_max", "rot_sigma_min",
-                                         "rot_sigma_max", "tor_sigma_min", "tor_sigma_max")]
+                                         "rot_sigma_max", "tor_sigma_min", "tor_sigma_max")] + \
+               [("all_atoms", C.c_int32)]
 
 
 class Complex(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_graphs", "n_lig", "n_rec", "n_bond_edges", "n_rec_edges", "n_tor")] + \
                [(n, C.c_void_p) for n in ("lig_ptr", "rec_ptr", "lig_x", "bond_index", "bond_attr", "edge_mask", "rec_x",
-                                          "rec_pos", "rec_edge_index", "mask_rotate")]
+                                          "rec_pos", "rec_edge_index", "mask_rotate")] + \
+               [(n, C.c_int32) for n in ("n_atom", "n_atom_edges", "n_atom_rec_edges")] + \
+               [(n, C.c_void_p) for n in ("atom_ptr", "atom_x", "atom_pos", "atom_edge_index", "atom_rec_edge_index")]
 
 
 class SampleCfg(C.Structure):

@@ -149,8 +149,15 @@ class MIScoreModel:
         c = _lib.Complex()
         c.num_graphs, c.n_lig, c.n_rec = B, lig.pos.shape[0], rec.pos.shape[0]
         c.n_bond_edges, c.n_rec_edges, c.n_tor = bond.edge_index.shape[1], rr.edge_index.shape[1], n_tor
-        for name in ("lig_ptr", "rec_ptr", "lig_x", "bond_index", "bond_attr", "edge_mask", "rec_x", "rec_pos",
-                     "rec_edge_index", "mask_rotate"):
+        names = ["lig_ptr", "rec_ptr", "lig_x", "bond_index", "bond_attr", "edge_mask", "rec_x", "rec_pos",
+                 "rec_edge_index", "mask_rotate"]
+        if self.cfg.all_atoms:   # receptor heavy atoms and their static relations (models/aa_model.py:291-303)
+            atom, aa, ar = data["atom"], data["atom", "atom"], data["atom", "receptor"]
+            keep.update(atom_ptr=ptr_of(atom.batch, atom.pos.shape[0]), atom_x=i32(atom.x[:, :4]), atom_pos=f32(atom.pos),
+                        atom_edge_index=i32(aa.edge_index), atom_rec_edge_index=i32(ar.edge_index))
+            c.n_atom, c.n_atom_edges, c.n_atom_rec_edges = atom.pos.shape[0], aa.edge_index.shape[1], ar.edge_index.shape[1]
+            names += ["atom_ptr", "atom_x", "atom_pos", "atom_edge_index", "atom_rec_edge_index"]
+        for name in names:
             setattr(c, name, keep[name].data_ptr() if keep[name] is not None else None)
         _lib.check(self.lib, self.lib.ddmi_set_complex(self._h, C.byref(c), self._stream()))
         self._keep, self._complex_key = keep, key

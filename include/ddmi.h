@@ -52,6 +52,7 @@ typedef struct ddmi_config {
   int32_t fixed_center_conv;
   float embedding_scale;
   float tr_sigma_min, tr_sigma_max, rot_sigma_min, rot_sigma_max, tor_sigma_min, tor_sigma_max;
+  int32_t all_atoms; /* get_model's model_class switch (utils/utils.py:221-224): 1 = AAModel (models/aa_model.py) */
 } ddmi_config;
 
 /* Static description of one collated batch of complexes = the fields of the PyG Batch the
@@ -72,6 +73,13 @@ typedef struct ddmi_complex {
   const float* rec_pos;          /* [n_rec,3]                                       */
   const int32_t* rec_edge_index; /* [2,n_rec_edges] ('receptor','rec_contact','receptor') */
   const uint8_t* mask_rotate;    /* [n_tor/B, n_lig/B] or NULL                      */
+  /* all_atoms only (models/aa_model.py:275-362): receptor heavy atoms and their two static relations */
+  int32_t n_atom, n_atom_edges, n_atom_rec_edges;
+  const int32_t* atom_ptr;            /* host [B+1] */
+  const int32_t* atom_x;              /* [n_atom,4] categorical atom features                  */
+  const float* atom_pos;              /* [n_atom,3]                                            */
+  const int32_t* atom_edge_index;     /* [2,n_atom_edges] ('atom','atom_contact','atom')       */
+  const int32_t* atom_rec_edge_index; /* [2,n_atom_rec_edges] ('atom','atom_rec_contact','receptor'): row 0 atoms, row 1 residues */
 } ddmi_complex;
 
 /* Reverse-diffusion loop parameters = the arguments of sampling() (utils/sampling.py:69-72).

@@ -13,11 +13,11 @@ from diffdock_amd.hetero import HeteroBatch, set_time
 from diffdock_amd.model import MIScoreModel
 from oracle.cg_model import CGModelOracle
 from oracle.conformer import get_t_schedule
-from util import fixture_case, graph_from_dict, load_fixture, rel_err, split_draws, tables
+from util import fixture_case, graph_from_dict, load_fixture, oracle_model, rel_err, split_draws, tables
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "hipemu", "libddmi_emu.so")
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter"]
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_aa_l1", "tiny_aa_l2"]   # tiny_aa_*: AAModel
 
 
 @pytest.fixture(scope="session")
@@ -51,12 +51,14 @@ def test_forward_matches_reference_fixture(name, emu_lib):
             assert rel_err(mine[:n, :ref_nodes.shape[1]], ref_nodes[:n]) < 1e-4, l
     # edge counts of the graphs built on the device against the oracle's graph builders
     so3_t, tor_t = tables()
-    inter = CGModelOracle(cfg, fx["state_dict"], so3_t, tor_t)(batch, return_intermediates=True)[4]
+    inter = oracle_model(cfg, fx["state_dict"], so3_t, tor_t)(batch, return_intermediates=True)[4]
     assert int(m.debug_buffer("goff_ll")[-1]) == inter["edge_counts"][0]
     assert int(m.debug_buffer("offs_l")[-1]) == inter["edge_counts"][1] == int(m.debug_buffer("offs_r")[-1])
+    if cfg.all_atoms:   # ligand <-> atom radius graph built on the device, and really populated in the fixture
+        assert int(m.debug_buffer("offs_la_l")[-1]) == inter["edge_counts"][2] == int(m.debug_buffer("offs_la_a")[-1]) > 0
 
 
-@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop"])
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2"])
 def test_device_loop_matches_reference_trajectory(name, emu_lib):
     fx, cfg, data_list = fixture_case(name)
     m = make_model(cfg, fx["state_dict"], emu_lib)

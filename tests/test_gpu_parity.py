@@ -14,11 +14,11 @@ from diffdock_amd.synth import make_complex, make_pose_list
 from diffdock_amd.weights import init_state_dict
 from oracle.cg_model import CGModelOracle
 from oracle.conformer import get_t_schedule
-from util import fixture_case, graph_from_dict, load_fixture, rel_err, split_draws, tables
+from util import fixture_case, graph_from_dict, load_fixture, oracle_model, rel_err, split_draws, tables
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop"]
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2"]
 
 
 def gpu_model(cfg, sd):
@@ -50,7 +50,7 @@ def test_forward_matches_reference_fixture(name):
             assert rel_err(mine[:n, :ref_nodes.shape[1]], ref_nodes[:n]) < REL, l
 
 
-@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop"])
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2"])
 def test_device_loop_matches_reference_trajectory(name):
     fx, cfg, data_list = fixture_case(name)
     m = gpu_model(cfg, fx["state_dict"])
@@ -96,6 +96,27 @@ def test_ddl_synth_forward_matches_oracle(lmax, t):
     m = gpu_model(cfg, sd)
     tr2, rot2, tor2, _ = m(to_gpu(batch))
     assert rel_err(tr2.cpu(), tr) < REL and rel_err(rot2.cpu(), rot) < REL and rel_err(tor2.cpu(), tor) < REL
+
+
+def test_all_atom_ddl_width_matches_oracle():
+    """AAModel (models/aa_model.py) at the DDL-synth channel widths: 120 residues / ~900 receptor atoms / 24 ligand atoms,
+    2 poses started inside the pocket (so that the ligand<->atom radius graph is populated), nine edge groups per layer,
+    against the oracle (which materialises the per-edge weights, hence the small complex)."""
+    cfg = DDL_SYNTH.replace(all_atoms=True, num_conv_layers=4, lm_embedding_type=None)
+    sd = init_state_dict(cfg, seed=77)
+    g = make_complex(seed=12, n_res=120, n_lig=24, lm_dim=0, all_atoms=True)
+    dl = make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=13, initial_noise_std_proportion=0.05)
+    batch = HeteroBatch.from_data_list(dl)
+    set_time(batch, 0.4, 0.4, 0.4, 2)
+    tr, rot, tor, _, inter = oracle_model(cfg, sd)(batch, return_intermediates=True)
+    m = gpu_model(cfg, sd)
+    tr2, rot2, tor2, _ = m(to_gpu(batch))
+    assert inter["edge_counts"][2] > 100 and int(m.debug_buffer("offs_la_l")[-1]) == inter["edge_counts"][2]
+    assert rel_err(tr2.cpu(), tr) < REL and rel_err(rot2.cpu(), rot) < REL and rel_err(tor2.cpu(), tor) < REL
+    for l in range(cfg.num_conv_layers - 1):   # all node rows: ligand, residues, atoms
+        mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))
+        ref = inter[f"node_attr{l + 1}"]
+        assert rel_err(mine[:, :ref.shape[1]], ref) < REL, l
 
 
 def test_full_size_properties():
