@@ -631,7 +631,35 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
                              c.ar_edge_base), s);
   }
   c.rec_node_enc = nullptr;
-  if (!m.rec_emb_layers.empty()) {
+  if (!m.rec_emb_layers.empty() && cfg.all_atoms) {
+    // aa_model.py:296-318: embedding layers over the sigma-free residue + atom graph, groups [rr, ar, aa, ra]; run in the
+    // full node numbering (ligand rows unused) so that the interaction-layer CSRs serve unchanged
+    const int aB = nL + nR, nA = c.nA;
+    float* ea = dalloc<float>(m, nullptr, {N, XS}, true);
+    float* eb = dalloc<float>(m, nullptr, {N, XS}, true);
+    DDMI_CHECK_HIP(hipMemcpyAsync(ea + (size_t)nL * XS, c.rec_node_base, (size_t)nR * XS * 4, hipMemcpyDeviceToDevice, s));
+    DDMI_CHECK_HIP(hipMemcpyAsync(ea + (size_t)aB * XS, c.atom_node_base, (size_t)nA * XS * 4, hipMemcpyDeviceToDevice, s));
+    RunGroup e_rr{nL, nR, nL, nR, c.rr_goff, c.rr_tgt, c.rr_tslot, c.rr_arow, c.rec_edge_base, c.Err, nullptr, nullptr, nullptr,
+                  c.rr_nvec, c.rr_ew, 1.f, c.msg_aa[3]};
+    RunGroup e_ar{nL, nR, aB, nA, c.se_ar.goff, c.se_ar.tgt, c.se_ar.tslot, c.se_ar.arow, c.ar_edge_base, c.Ear, nullptr, nullptr,
+                  nullptr, c.ar_nvec, nullptr, 1.f, c.msg_aa[8]};
+    RunGroup e_aa{aB, nA, aB, nA, c.se_aa.goff, c.se_aa.tgt, c.se_aa.tslot, c.se_aa.arow, c.atom_edge_base, c.Eaa, nullptr, nullptr,
+                  nullptr, c.aa_nvec, c.aa_ew, 1.f, c.msg_aa[6]};
+    RunGroup e_ra{aB, nA, nL, nR, c.se_ra.goff, c.se_ra.tgt, c.se_ra.tslot, c.se_ra.arow, c.ar_edge_base, c.Ear, nullptr, nullptr,
+                  nullptr, c.ar_nvec, nullptr, 1.f, c.msg_aa[5]};
+    e_rr.vn = 1; e_ar.vn = 8; e_aa.vn = 6; e_ra.vn = 5;
+    std::vector<ReduceGroup> re = {{c.rr_toff, c.msg_aa[3], nL, nR}, {c.se_ar.toff, c.msg_aa[8], aB, nA},
+                                   {c.se_aa.toff, c.msg_aa[6], aB, nA}, {c.se_ra.toff, c.msg_aa[5], nL, nR}};
+    ReduceGroup* rg_emb = m.cpool.upload(re);
+    float *xin = ea, *xout = eb;
+    for (size_t i = 0; i < m.rec_emb_layers.size(); ++i) {
+      run_conv(m, m.rec_emb_layers[i], {e_rr, e_ar, e_aa, e_ra}, rg_emb, 4, xin, xout, nL, nR + nA, s);
+      std::swap(xin, xout);
+      c.rec_base_dim = m.rec_emb_layers[i].D_out;
+    }
+    DDMI_CHECK_HIP(hipMemcpyAsync(c.rec_node_base, xin + (size_t)nL * XS, (size_t)nR * XS * 4, hipMemcpyDeviceToDevice, s));
+    DDMI_CHECK_HIP(hipMemcpyAsync(c.atom_node_base, xin + (size_t)aB * XS, (size_t)nA * XS * 4, hipMemcpyDeviceToDevice, s));
+  } else if (!m.rec_emb_layers.empty()) {
     c.rec_node_enc = dalloc<float>(m, nullptr, {nR, XS}, true);
     DDMI_CHECK_HIP(hipMemcpyAsync(c.rec_node_enc, c.rec_node_base, (size_t)nR * XS * 4, hipMemcpyDeviceToDevice, s));
     // rec_emb_layers run on the sigma-free receptor graph (cg_model.py:288-290), node ids local to the receptor
@@ -758,7 +786,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   if (cfg.all_atoms) {
     // ---- all-atom model (aa_model.py:364-436): atom rows, ligand<->atom radius graph, nine edge groups
     const int nA = c.nA, aB = nL + nR;
-    launch_add_rowvec(c.X[xi] + (size_t)aB * XS, XS, c.atom_node_base, XS, c.rec_sig, ns, c.atom_batch, nA, ns, ns, s);
+    launch_add_rowvec(c.X[xi] + (size_t)aB * XS, XS, c.atom_node_base, XS, c.rec_sig, ns, c.atom_batch, nA, c.rec_base_dim, ns, s);
     launch_cross_count(lig_pos, c.atom_pos, c.lig_batch, c.atom_batch, c.lig_ptr, c.atom_ptr, nL, nA, c.maxNa, nullptr,
                        cfg.lig_max_radius, nullptr, c.la_pairrank, c.la_cnt_l, c.la_cnt_a, s);
     launch_exclusive_scan(c.la_cnt_l, c.la_offs_l, nL, s);

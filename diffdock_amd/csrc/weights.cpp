@@ -118,7 +118,6 @@ void build_weight_spec(Model& m) {
   encoder("lig_node_embedding", LIG_DIMS, 16, sd);
   mlp("lig_edge_embedding", m.nf + sd + m.D, ns, ns);
   if (c.all_atoms) {   // models/aa_model.py:90-103
-    DDMI_REQUIRE(K == 0, DDMI_ERR_ARG, "all_atoms with receptor embedding layers is not built");
     DDMI_REQUIRE(m.D == m.Dc, DDMI_ERR_ARG, "AAModel feeds lig_distance_expansion into la_edge_embedding: distance_embed_dim must equal cross_distance_embed_dim");
     mlp("rec_sigma_embedding", sd, ns, ns);
     encoder("rec_node_embedding", REC_DIMS, 1, m.lm);
@@ -142,7 +141,7 @@ void build_weight_spec(Model& m) {
   m.conv_layers.assign(Lc, ConvW());
   for (int i = 0; i < K; ++i) {
     init_conv_meta(c, m.rec_emb_layers[i], "rec_emb_layers." + std::to_string(i), layer_irreps(c, i), sh,
-                   layer_irreps(c, i + 1), 3 * ns, 1, faster, true, true);
+                   layer_irreps(c, i + 1), 3 * ns, (c.all_atoms && c.differentiate_convolutions) ? 4 : 1, faster, true, true);
     conv(m.rec_emb_layers[i]);
   }
   for (int i = 0; i < (int)m.lig_emb_layers.size(); ++i) {

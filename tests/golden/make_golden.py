@@ -142,6 +142,9 @@ def main():
                            n_res=24, n_lig=10, n_samples=2, seed=5, t=0.6),
         "tiny_aa_l2": dict(cfg=TINY.replace(all_atoms=True, num_conv_layers=4, sh_lmax=2, fixed_center_conv=True),
                            n_res=20, n_lig=9, n_samples=2, seed=6, t=0.4),
+        # ... with embedding layers over the residue + atom graph (aa_model.py:296-318) and over the ligand graph
+        "tiny_aa_l2_emb": dict(cfg=TINY.replace(all_atoms=True, num_conv_layers=2, num_prot_emb_layers=2, sh_lmax=2),
+                               n_res=18, n_lig=9, n_samples=2, seed=7, t=0.5),
     }
     if len(sys.argv) > 1:
         cases = {k: v for k, v in cases.items() if k in sys.argv[1:]}

@@ -18,7 +18,7 @@ from util import fixture_case, graph_from_dict, load_fixture, oracle_model, rel_
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2"]
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb"]
 
 
 def gpu_model(cfg, sd):
@@ -50,7 +50,7 @@ def test_forward_matches_reference_fixture(name):
             assert rel_err(mine[:n, :ref_nodes.shape[1]], ref_nodes[:n]) < REL, l
 
 
-@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2"])
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb"])
 def test_device_loop_matches_reference_trajectory(name):
     fx, cfg, data_list = fixture_case(name)
     m = gpu_model(cfg, fx["state_dict"])

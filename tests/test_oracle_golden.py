@@ -13,7 +13,7 @@ from oracle.layers import faster_tensor_product, gaussian_smearing
 from oracle.sampling import sampling
 from util import fixture_case, load_fixture, oracle_model, rel_err, split_draws, tables, graph_from_dict
 
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2"]
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb"]
 
 
 @pytest.mark.parametrize("name", CASES)
