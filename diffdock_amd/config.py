@@ -60,6 +60,10 @@ class ModelConfig:
     tor_sigma_max: float = 3.14
     crop_beyond: float | None = None
     all_atoms: bool = False             # AAModel (models/aa_model.py): receptor heavy atoms as a third node type
+    # get_model(..., confidence_mode=True) (utils/utils.py:172, models/cg_model.py:181-207,353-366): same interaction
+    # layers, read-out = confidence_predictor on the graph-mean scalar ligand features; t is used raw (no t_to_sigma)
+    confidence_mode: bool = False
+    num_confidence_outputs: int = 1     # len(rmsd_classification_cutoff) + 1 when that is a list
 
     # ------------------------------------------------------------------ derived
     @property
@@ -107,8 +111,11 @@ class ModelConfig:
                  embedding_type="sinusoidal", dropout=0.0,
                  esm_embeddings_path="precomputed" if self.lm_embedding_type else None)
         for k in ('fixed_center_conv', 'lm_embedding_type', 'batch_norm', 'differentiate_convolutions',
-                  'lig_max_radius', 'rec_max_radius', 'center_max_distance', 'in_lig_edge_features'):
+                  'lig_max_radius', 'rec_max_radius', 'center_max_distance', 'in_lig_edge_features', 'confidence_mode',
+                  'num_confidence_outputs'):
             d.pop(k)
+        if self.num_confidence_outputs > 1:
+            d["rmsd_classification_cutoff"] = [2.0 + i for i in range(self.num_confidence_outputs - 1)]
         return argparse.Namespace(**d)
 
     def replace(self, **kw) -> "ModelConfig":
@@ -129,8 +136,10 @@ def config_from_args(args) -> ModelConfig:
               "pdbsidechain_esm_embeddings_path", "esm_embeddings_path"):
         if get(k, None) is not None:
             lm = "precomputed"
+    cut = get("rmsd_classification_cutoff", None)
     return ModelConfig(
         all_atoms=bool(get("all_atoms", False)),
+        num_confidence_outputs=len(cut) + 1 if isinstance(cut, list) else 1,
         ns=args.ns, nv=args.nv, num_conv_layers=args.num_conv_layers,
         num_prot_emb_layers=get("num_prot_emb_layers", 0), sh_lmax=get("sh_lmax", 2),
         sigma_embed_dim=args.sigma_embed_dim, distance_embed_dim=args.distance_embed_dim,

@@ -687,9 +687,11 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
 
 // =================================================================================== forward
 void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor, float* tr_out,
-             float* rot_out, float* tor_out, hipStream_t s) {
+             float* rot_out, float* tor_out, hipStream_t s, float* conf_out) {
   DDMI_REQUIRE(m.has_complex, DDMI_ERR_STATE, "ddmi_set_complex must precede ddmi_forward");
-  DDMI_REQUIRE(!m.cfg.scale_by_sigma || (m.so3_table && (m.cfg.no_torsion || m.torus_table)), DDMI_ERR_STATE,
+  const bool conf = m.cfg.confidence_mode != 0;
+  DDMI_REQUIRE(conf == (conf_out != nullptr), DDMI_ERR_STATE, "score models use ddmi_forward, confidence models ddmi_confidence");
+  DDMI_REQUIRE(conf || !m.cfg.scale_by_sigma || (m.so3_table && (m.cfg.no_torsion || m.torus_table)), DDMI_ERR_STATE,
                "score-norm tables not set (ddmi_set_table)");
   Cx& c = *m.cx;
   const ddmi_config& cfg = m.cfg;
@@ -704,9 +706,11 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   gemm(c.temb, sd, m.lig_enc.W0 + ns, ns + sd, m.lig_enc.b0, c.ligsig, ns, B, ns, sd, 0, s);
   gemm(c.temb, sd, m.lig_edge.W0 + m.nf, m.lig_edge.in, m.lig_edge.b0, c.ll_gvec, ns, B, ns, sd, 0, s);
   gemm(c.temb, sd, m.cross_edge.W0, m.cross_edge.in, m.cross_edge.b0, c.cross_gvec, ns, B, ns, sd, 0, s);
-  gemm(c.temb, sd, m.center_edge.W0 + m.D, m.center_edge.in, m.center_edge.b0, c.center_gvec, ns, B, ns, sd, 0, s);
-  gemm(c.temb, sd, m.tr_final.W0 + 1, 1 + sd, m.tr_final.b0, c.tr_sig, ns, B, ns, sd, 0, s);
-  gemm(c.temb, sd, m.rot_final.W0 + 1, 1 + sd, m.rot_final.b0, c.rot_sig, ns, B, ns, sd, 0, s);
+  if (!conf) {
+    gemm(c.temb, sd, m.center_edge.W0 + m.D, m.center_edge.in, m.center_edge.b0, c.center_gvec, ns, B, ns, sd, 0, s);
+    gemm(c.temb, sd, m.tr_final.W0 + 1, 1 + sd, m.tr_final.b0, c.tr_sig, ns, B, ns, sd, 0, s);
+    gemm(c.temb, sd, m.rot_final.W0 + 1, 1 + sd, m.rot_final.b0, c.rot_sig, ns, B, ns, sd, 0, s);
+  }
   // ---- node tables: ligand rows [0,nL), receptor rows [nL, nL+nR)
   float* X0 = c.X[0];
   launch_lig_node_embed(c.lig_x, nL, m.lig_emb, m.lig_emb_off, 16, ns, c.embsum, s);
@@ -759,7 +763,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   // ---- cross graph
   const float* cut_dev = nullptr;
   if (cfg.dynamic_max_cross) {  // cutoff_b = 3 * tr_sigma_b + 20 (cg_model.py:321-322)
-    launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, s);
+    launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, s, conf ? 1 : 0);
     cut_dev = c.cutoff;
   }
   launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
@@ -831,6 +835,19 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   }
   const float* XL = c.X[xi];
   PhaseTimer t_read(m, "readouts", s);
+  if (conf) {   // cg_model.py:353-366: graph-mean of the even (and, from 3 layers on, the odd) scalars -> confidence_predictor
+    const int total = cfg.num_conv_layers + cfg.num_prot_emb_layers;
+    const ConvW& Ll = m.conv_layers.back();
+    ConfHeadArgs a{};
+    a.B = B; a.X = XL; a.lig_ptr = c.lig_ptr; a.ns = ns;
+    a.n_tail = total >= 3 ? (cfg.reduce_pseudoscalars ? cfg.nv : ns) : 0;
+    a.tail_off = Ll.D_out - a.n_tail;
+    a.W0 = m.conf_W[0]; a.b0 = m.conf_b[0]; a.sc0 = m.conf_bn_scale[0]; a.sh0 = m.conf_bn_shift[0];
+    a.W1 = m.conf_W[1]; a.b1 = m.conf_b[1]; a.sc1 = m.conf_bn_scale[1]; a.sh1 = m.conf_bn_shift[1];
+    a.W2 = m.conf_W[2]; a.b2 = m.conf_b[2]; a.n_out = cfg.num_confidence_outputs; a.out = conf_out;
+    launch_conf_head(a, s);
+    return;
+  }
   // ---- translation / rotation heads (cg_model.py:368-395)
   const ConvW& F = m.final_conv;
   launch_center_edges(lig_pos, c.lig_batch, c.lig_ptr, B, nL, c.c_dist, c.c_nvec, s);

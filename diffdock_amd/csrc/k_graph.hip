@@ -237,14 +237,14 @@ void launch_cross_fill(const float* lpos, const float* rpos, const int* rbatch, 
 }
 
 // cutoff_b = 3 * tr_sigma(t_b) + 20   (models/cg_model.py:321-322, utils/diffusion_utils.py:28-32)
-__global__ void k_cross_cutoff(const float* __restrict__ t_tr, int B, float smin, float smax, float* __restrict__ out) {
+__global__ void k_cross_cutoff(const float* __restrict__ t_tr, int B, float smin, float smax, float* __restrict__ out, int raw) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const float sigma = powf(smin, 1.f - t_tr[b]) * powf(smax, t_tr[b]);
+  const float sigma = raw ? t_tr[b] : powf(smin, 1.f - t_tr[b]) * powf(smax, t_tr[b]);   // confidence models: complex_t raw (cg_model.py:314-315)
   out[b] = sigma * 3.f + 20.f;
 }
-void launch_cross_cutoff(const float* t_tr, int B, float smin, float smax, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_cross_cutoff, dim3(cdiv(B, 64)), dim3(64), 0, s, t_tr, B, smin, smax, out);
+void launch_cross_cutoff(const float* t_tr, int B, float smin, float smax, float* out, hipStream_t s, int raw) {
+  hipLaunchKernelGGL(k_cross_cutoff, dim3(cdiv(B, 64)), dim3(64), 0, s, t_tr, B, smin, smax, out, raw);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

@@ -210,6 +210,42 @@ void launch_score_heads(const ScoreHeadArgs& a, hipStream_t s) {
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(64) void k_conf_head(ConfHeadArgs a) {
+  __shared__ float feat[256], h0[128], h1[128];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int lo = a.lig_ptr[b], hi = a.lig_ptr[b + 1], n_in = a.ns + a.n_tail;
+  for (int c = lane; c < n_in; c += 64) {
+    const int col = c < a.ns ? c : a.tail_off + (c - a.ns);
+    float s = 0.f;
+    for (int i = lo; i < hi; ++i) s += a.X[(size_t)i * XS + col];
+    feat[c] = s / (float)max(hi - lo, 1);
+  }
+  __syncthreads();
+  for (int c = lane; c < a.ns; c += 64) {
+    float v = a.b0[c];
+    for (int j = 0; j < n_in; ++j) v = fmaf(a.W0[(size_t)c * n_in + j], feat[j], v);
+    h0[c] = fmaxf(v * a.sc0[c] + a.sh0[c], 0.f);
+  }
+  __syncthreads();
+  for (int c = lane; c < a.ns; c += 64) {
+    float v = a.b1[c];
+    for (int j = 0; j < a.ns; ++j) v = fmaf(a.W1[(size_t)c * a.ns + j], h0[j], v);
+    h1[c] = fmaxf(v * a.sc1[c] + a.sh1[c], 0.f);
+  }
+  __syncthreads();
+  for (int o = lane; o < a.n_out; o += 64) {
+    float v = a.b2[o];
+    for (int j = 0; j < a.ns; ++j) v = fmaf(a.W2[(size_t)o * a.ns + j], h1[j], v);
+    a.out[(size_t)b * a.n_out + o] = v;
+  }
+}
+void launch_conf_head(const ConfHeadArgs& a, hipStream_t s) {
+  if (a.B <= 0) return;
+  if (a.ns > 128 || a.ns + a.n_tail > 256) throw Error(DDMI_ERR_ARG, "confidence head: ns too large");
+  hipLaunchKernelGGL(k_conf_head, dim3(a.B), dim3(64), 0, s, a);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 // one wave per torsion bond: lane c owns hidden unit c (c, c + 64, ..), tanh, weighted wave sum
 __global__ __launch_bounds__(64) void k_tor_head(TorHeadArgs a) {
   const int t = blockIdx.x, lane = threadIdx.x;

@@ -152,7 +152,7 @@ void launch_cross_fill(const float* lpos, const float* rpos, const int* rbatch, 
                        float const_cutoff, int smooth, int* g1_tgt, int* g1_tslot, int* g3_tgt, int* g3_tslot,
                        int* pbatch, float* pdist, float* pnvec, float* pew, hipStream_t s,
                        int rbase = -1 /* first global id of the second node type; default nL */);
-void launch_cross_cutoff(const float* t_tr, int B, float smin, float smax, float* out, hipStream_t s);
+void launch_cross_cutoff(const float* t_tr, int B, float smin, float smax, float* out, hipStream_t s, int raw = 0);
 void launch_tor_radius(const float* pos, const int* ptr, const int* tor_u, const int* tor_v, const int* tor_batch, int nT,
                        float r, int cap, float smooth_max, int* cnt, int* atom, float* dist, float* nvec, float* ew,
                        float* bond_nvec, hipStream_t s);
@@ -214,6 +214,15 @@ struct ScoreHeadArgs {
   float *tr_out, *rot_out;
 };
 void launch_score_heads(const ScoreHeadArgs& a, hipStream_t s);
+// confidence = confidence_predictor(scatter_mean(cat[x[:, :ns], x[:, tail_off : tail_off + n_tail]], batch)) -- cg_model.py:353-366;
+// BatchNorm1d folded to scale / shift.  One workgroup per graph.
+struct ConfHeadArgs {
+  int B; const float* X; const int* lig_ptr;   // ligand rows of the last node table (stride XS)
+  int ns, tail_off, n_tail;                    // n_tail = 0: scalars only (fewer than 3 layers)
+  const float *W0, *b0, *sc0, *sh0, *W1, *b1, *sc1, *sh1, *W2, *b2;
+  int n_out; float* out;                       // [B][n_out]
+};
+void launch_conf_head(const ConfHeadArgs& a, hipStream_t s);
 struct TorHeadArgs {
   int nT, ns, in_dim; const float* feat;  // [nT][in_dim] after BN
   const float* W0;                        // [ns][in_dim]

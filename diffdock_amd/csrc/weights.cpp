@@ -155,6 +155,17 @@ void build_weight_spec(Model& m) {
     conv(m.conv_layers[l]);
   }
   const Irreps last_out = layer_irreps(c, K + Lc);
+  if (c.confidence_mode) {   // cg_model.py:181-207: Linear, BatchNorm1d, ReLU, Dropout, Linear, BatchNorm1d, ReLU, Dropout, Linear
+    DDMI_REQUIRE(c.num_confidence_outputs >= 1, DDMI_ERR_ARG, "num_confidence_outputs must be >= 1");
+    const int n_in = K + Lc >= 3 ? ns + (c.reduce_pseudoscalars ? c.nv : ns) : ns;
+    lin("confidence_predictor.0", n_in, ns);
+    lin("confidence_predictor.4", ns, ns);
+    lin("confidence_predictor.8", ns, c.num_confidence_outputs);
+    for (int i : {1, 5})
+      for (const char* k : {".weight", ".bias", ".running_mean", ".running_var"})
+        S.push_back({"confidence_predictor." + std::to_string(i) + k, {ns}});
+    return;
+  }
   S.push_back({"center_distance_expansion.offset", {m.D}});
   mlp("center_edge_embedding", m.D + sd, ns, ns);
   const Irreps fout = c.odd_parity ? make_irreps({{1, 1, -1}, {1, 1, 1}}) : make_irreps({{2, 1, -1}, {2, 1, 1}});
@@ -438,9 +449,26 @@ void commit_weights(Model& m) {
     m.ar_edge = up_mlp(m, "ar_edge_embedding");
     m.la_edge = up_mlp(m, "la_edge_embedding");
   }
-  m.center_edge = up_mlp(m, "center_edge_embedding");
-  m.tr_final = up_mlp(m, "tr_final_layer");
-  m.rot_final = up_mlp(m, "rot_final_layer");
+  if (c.confidence_mode) {
+    for (int i = 0; i < 3; ++i) {
+      m.conf_W[i] = up(m, "confidence_predictor." + std::to_string(4 * i) + ".weight");
+      m.conf_b[i] = up(m, "confidence_predictor." + std::to_string(4 * i) + ".bias");
+    }
+    for (int i = 0; i < 2; ++i) {   // BatchNorm1d eval folded to scale / shift
+      const std::string n = "confidence_predictor." + std::to_string(4 * i + 1);
+      const HostTensor &w = W(m, n + ".weight"), &b = W(m, n + ".bias"), &rm = W(m, n + ".running_mean"), &rv = W(m, n + ".running_var");
+      std::vector<float> sc(m.ns), sh(m.ns);
+      for (int k = 0; k < m.ns; ++k) {
+        sc[k] = w.data[k] / std::sqrt(rv.data[k] + 1e-5f);
+        sh[k] = b.data[k] - rm.data[k] * sc[k];
+      }
+      m.conf_bn_scale[i] = m.wpool.upload(sc); m.conf_bn_shift[i] = m.wpool.upload(sh);
+    }
+  } else {
+    m.center_edge = up_mlp(m, "center_edge_embedding");
+    m.tr_final = up_mlp(m, "tr_final_layer");
+    m.rot_final = up_mlp(m, "rot_final_layer");
+  }
   auto offs = [&](const std::string& k, float*& dev, float& coeff) {
     const HostTensor& t = W(m, k);
     DDMI_REQUIRE(t.data.size() >= 2, DDMI_ERR_ARG, "distance expansion needs >= 2 gaussians");
@@ -451,12 +479,12 @@ void commit_weights(Model& m) {
   offs("lig_distance_expansion.offset", m.off_lig, m.coeff_lig);
   offs("rec_distance_expansion.offset", m.off_rec, m.coeff_rec);
   offs("cross_distance_expansion.offset", m.off_cross, m.coeff_cross);
-  offs("center_distance_expansion.offset", m.off_center, m.coeff_center);
+  if (!c.confidence_mode) offs("center_distance_expansion.offset", m.off_center, m.coeff_center);
   for (auto& L : m.rec_emb_layers) commit_conv(m, L);
   for (auto& L : m.lig_emb_layers) commit_conv(m, L);
   for (auto& L : m.conv_layers) commit_conv(m, L);
-  commit_conv(m, m.final_conv);
-  if (!c.no_torsion) {
+  if (!c.confidence_mode) commit_conv(m, m.final_conv);
+  if (!c.no_torsion && !c.confidence_mode) {
     m.final_edge = up_mlp(m, "final_edge_embedding");
     commit_conv(m, m.tor_conv);
     m.tor_W0 = up(m, "tor_final_layer.0.weight");

@@ -169,6 +169,12 @@ class MIScoreModel:
         dev = self.device
         pos = data["ligand"].pos.to(dev, torch.float32).contiguous()
         t = [data.complex_t[k].to(dev, torch.float32).contiguous() for k in ("tr", "rot", "tor")]
+        if self.cfg.confidence_mode:   # (confidence, atom_confidence) -- models/cg_model.py:353-366
+            n_out = self.cfg.num_confidence_outputs
+            conf = torch.empty(self._B, n_out, device=dev)
+            _lib.check(self.lib, self.lib.ddmi_confidence(self._h, _ptr(pos), _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(conf),
+                                                          self._stream()))
+            return conf.squeeze(-1), torch.zeros(self._n_lig, device=dev)
         tr = torch.empty(self._B, 3, device=dev)
         rot = torch.empty(self._B, 3, device=dev)
         no_tor = self.cfg.no_torsion or self._n_tor == 0
@@ -251,7 +257,9 @@ def get_model(args, device, t_to_sigma=None, no_parallel=True, confidence_mode=F
     """Same signature as the reference factory (utils/utils.py:172).  `t_to_sigma` is accepted for
     compatibility; the geometric schedule it implements (utils/diffusion_utils.py:28-32) is evaluated
     in-library from the sigma bounds in `args`."""
-    if confidence_mode or old:
-        raise NotImplementedError("confidence / legacy models are outside the built path (SURVEY.md 8f)")
+    if old:
+        raise NotImplementedError("legacy model classes (models/old_cg_model.py, get_model(old=True)) are outside the built path")
     cfg = args if isinstance(args, ModelConfig) else config_from_args(args)
+    if confidence_mode != cfg.confidence_mode:
+        cfg = cfg.replace(confidence_mode=bool(confidence_mode))
     return MIScoreModel(cfg, device=device, lib_path=lib_path)

@@ -5,9 +5,10 @@
 
 Differences, all documented: the Gaussian draws come from a counter-based generator keyed by
 (seed, global sample index, step, component) instead of the global torch RNG (so that a run sharded over GPUs
-reproduces the single-GPU trajectories), or are injected through `noise=`; the confidence model
-(sampling.py:208-227) and visualisation hooks are not on the built path yet and raise
-NotImplementedError when requested.  Per-step `crop_beyond` (sampling.py:104-109) runs on the device as a residue
+reproduces the single-GPU trajectories), or are injected through `noise=`; the confidence model is called after each
+batch exactly as in the reference (sampling.py:208-227: fresh ligand positions copied into the confidence graphs,
+t = 0) when it is a confidence-mode model of the built classes; visualisation hooks / full trajectories / feature
+returns are not on the built path and raise NotImplementedError.  Per-step `crop_beyond` (sampling.py:104-109) runs on the device as a residue
 mask + contact-graph re-compaction instead of the reference's deepcopy / to_data_list / from_data_list round trip.
 """
 from __future__ import annotations
@@ -61,8 +62,14 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
              confidence_data_list=None, confidence_model_args=None, t_schedule=None, batch_size=32,
              no_final_step_noise=False, pivot=None, return_full_trajectory=False, temp_sampling=1.0, temp_psi=0.0,
              temp_sigma_data=0.5, return_features=False, seed=0, noise=None, sample_id_offset=0, native_loop=True):
-    if confidence_model is not None or visualization_list is not None or return_full_trajectory or return_features or pivot:
-        raise NotImplementedError("confidence model / visualisation / trajectories are outside the built path (SURVEY.md 8f)")
+    if visualization_list is not None or return_full_trajectory or return_features or pivot:
+        raise NotImplementedError("visualisation / trajectories / feature returns are outside the built path")
+    confidence = [] if confidence_model is not None else None
+    conf_batches = None
+    if confidence_model is not None and confidence_data_list is not None:
+        if getattr(confidence_model_args, "crop_beyond", None) is not None:
+            raise NotImplementedError("crop_beyond on the confidence graphs (sampling.py:213-217)")
+        conf_batches = iter([c for _, c in _batches(confidence_data_list, batch_size)])   # DataLoader order, sampling.py:87
     crop = getattr(model_args, "crop_beyond", None) if model_args is not None else getattr(model.cfg, "crop_beyond", None)
     N = len(data_list)
     schedules = (np.asarray(tr_schedule, dtype=np.float64), np.asarray(rot_schedule, dtype=np.float64),
@@ -109,4 +116,19 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             pos = pos.reshape(b, n, 3)
             for i in range(b):
                 data_list[lo + i]["ligand"].pos = pos[i]
-    return data_list, None
+            if confidence_model is not None:   # sampling.py:208-227
+                if conf_batches is not None:
+                    cbatch = _collate(next(conf_batches))
+                    cbatch["ligand"].pos = pos.reshape(b * n, 3).to(cbatch["ligand"].pos.device)
+                    if device is not None:
+                        cbatch = cbatch.to(device)
+                    set_time(cbatch, 0, 0, 0, b, device=cbatch["ligand"].pos.device)
+                    out = confidence_model(cbatch)
+                else:   # the sampling batch itself, still carrying the last step's times (sampling.py:113-114, 223)
+                    batch["ligand"].pos = pos.reshape(b * n, 3)
+                    set_time(batch, schedules[0][-1], schedules[1][-1], schedules[2][-1], b, device=batch["ligand"].pos.device)
+                    out = confidence_model(batch)
+                confidence.append(out[0] if isinstance(out, tuple) else out)
+    if confidence is not None:
+        confidence = torch.nan_to_num(torch.cat(confidence, dim=0), nan=-1000)
+    return data_list, confidence

@@ -101,6 +101,17 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
         a, b = cfg.layer_irreps(K + l)
         conv(f"conv_layers.{l}", a, sh, b, 3 * ns, 3 * ns, cfg.conv_groups(l), cfg.faster)
     last_out = cfg.layer_irreps(K + L - 1)[1]
+    if cfg.confidence_mode:   # cg_model.py:181-207: Linear, BatchNorm1d, ReLU, Dropout, Linear, BatchNorm1d, ReLU, Dropout, Linear
+        n_in = ns + (cfg.nv if cfg.reduce_pseudoscalars else ns) if K + L >= 3 else ns
+        lin("confidence_predictor.0", n_in, ns)
+        lin("confidence_predictor.4", ns, ns)
+        lin("confidence_predictor.8", ns, cfg.num_confidence_outputs)
+        for i in (1, 5):   # get_model never passes confidence_no_batchnorm: BatchNorm1d is always there
+            spec[f"confidence_predictor.{i}.weight"] = ((ns,), "bn_w")
+            spec[f"confidence_predictor.{i}.bias"] = ((ns,), "bn_b")
+            spec[f"confidence_predictor.{i}.running_mean"] = ((ns,), "bn_mean")
+            spec[f"confidence_predictor.{i}.running_var"] = ((ns,), "bn_var")
+        return spec
     spec["center_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:center")
     mlp("center_edge_embedding", cfg.distance_embed_dim + sd, ns, ns)
     conv("final_conv", last_out, sh, final_conv_out(cfg), 2 * ns, 2 * ns, 1, False)

@@ -53,6 +53,9 @@ typedef struct ddmi_config {
   float embedding_scale;
   float tr_sigma_min, tr_sigma_max, rot_sigma_min, rot_sigma_max, tor_sigma_min, tor_sigma_max;
   int32_t all_atoms; /* get_model's model_class switch (utils/utils.py:221-224): 1 = AAModel (models/aa_model.py) */
+  /* get_model(..., confidence_mode=True): same interaction layers, confidence_predictor read-out (cg_model.py:181-207,
+   * 353-366); the model is evaluated with ddmi_confidence instead of ddmi_forward */
+  int32_t confidence_mode, num_confidence_outputs;
 } ddmi_config;
 
 /* Static description of one collated batch of complexes = the fields of the PyG Batch the
@@ -131,6 +134,12 @@ int ddmi_set_complex(ddmi_model* m, const ddmi_complex* c, ddmi_stream stream);
  * lig_pos [n_lig,3]; t_* [B] = batch.complex_t[...]; outputs tr [B,3], rot [B,3], tor [n_tor]. */
 int ddmi_forward(ddmi_model* m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor,
                  float* tr_out, float* rot_out, float* tor_out, ddmi_stream stream);
+
+/* confidence, atom_confidence = confidence_model(batch) -- utils/sampling.py:221, models/cg_model.py:353-366 /
+ * models/aa_model.py:431-452 (atom_confidence is identically zero unless atom_confidence_loss_weight > 0: not built).
+ * Requires ddmi_config.confidence_mode.  t_* are used raw (sampling() passes 0).  conf_out [B, num_confidence_outputs]. */
+int ddmi_confidence(ddmi_model* m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor,
+                    float* conf_out, ddmi_stream stream);
 
 /* crop_beyond(graph, cutoff) -- utils/utils.py:388-413 as applied by sampling() before each model call
  * (utils/sampling.py:104-109): subsequent ddmi_forward calls drop the residues farther than `cutoff` from every

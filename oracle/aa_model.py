@@ -110,7 +110,7 @@ class AAModelOracle(CGModelOracle):
     # ------------------------------------------------------------------ forward (aa_model.py:364-436)
     def __call__(self, data, return_intermediates=False):
         c, sd, ns = self.cfg, self.sd, self.cfg.ns
-        tr_sigma, rot_sigma, tor_sigma = t_to_sigma(c, *[data.complex_t[k] for k in ("tr", "rot", "tor")])
+        tr_sigma, rot_sigma, tor_sigma = self._sigmas(data)
         (lig_node_attr, lig_ei, lig_edge_attr, lig_edge_sh, lig_ew,
          rec_node_attr, rec_ei, rec_edge_attr, rec_edge_sh, rec_ew,
          atom_node_attr, atom_ei, atom_edge_attr, atom_edge_sh, atom_ew,
@@ -152,4 +152,7 @@ class AAModelOracle(CGModelOracle):
             node_attr = layer(node_attr, edge_index[:, :e], ea, edge_sh[:e], edge_weight=edge_weight[:e])
             if inter is not None:
                 inter[f"node_attr{l + 1}"] = node_attr.clone()
+        if c.confidence_mode:   # aa_model.py:431-452 (atom_confidence=False, parallel=1)
+            out = self._confidence(data, node_attr[:n_lig])
+            return out + (inter,) if return_intermediates else out
         return self._readouts(data, node_attr[:n_lig], tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates)

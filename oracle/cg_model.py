@@ -54,6 +54,8 @@ class CGModelOracle:
         self.lig_emb_layers = [mk(f"lig_emb_layers.{i}", i, 1) for i in range(K)] if c.embed_also_ligand else []
         self.conv_layers = [mk(f"conv_layers.{l}", K + l, c.conv_groups(l)) for l in range(L)]
         last_out = c.layer_irreps(K + L - 1)[1]
+        if c.confidence_mode:
+            return
         self.final_conv = TPConv(sd, "final_conv", last_out, self.sh_irreps,
                                  "2x1o + 2x1e" if not c.odd_parity else "1x1o + 1x1e",
                                  residual=False, batch_norm=c.batch_norm)
@@ -170,10 +172,34 @@ class CGModelOracle:
         return self.ligand_embedding(data) + (node_attr, rr.edge_index, edge_attr, edge_sh, ew)
 
     # ------------------------------------------------------------------ forward
+    def _sigmas(self, data):
+        """cg_model.py:312-315: confidence models use complex_t raw."""
+        ts = [data.complex_t[k] for k in ("tr", "rot", "tor")]
+        return tuple(ts) if self.cfg.confidence_mode else t_to_sigma(self.cfg, *ts)
+
+    def _confidence(self, data, lig_node_attr):
+        """cg_model.py:353-366 (atom_confidence=False): (confidence, atom_confidence)."""
+        c, sd, ns = self.cfg, self.sd, self.cfg.ns
+        if c.num_conv_layers + c.num_prot_emb_layers >= 3:
+            x = torch.cat([lig_node_attr[:, :ns], lig_node_attr[:, -(c.nv if c.reduce_pseudoscalars else ns):]], 1)
+        else:
+            x = lig_node_attr[:, :ns]
+        batch = data["ligand"].batch
+        x = torch.zeros(data.num_graphs, x.shape[1], dtype=x.dtype).index_add_(0, batch, x) / \
+            torch.bincount(batch, minlength=data.num_graphs).clamp(min=1).unsqueeze(1).to(x.dtype)
+
+        def bn1d(i, v):
+            p = f"confidence_predictor.{i}"
+            return (v - sd[p + ".running_mean"]) / torch.sqrt(sd[p + ".running_var"] + 1e-5) * sd[p + ".weight"] + sd[p + ".bias"]
+        lin = lambda i, v: torch.nn.functional.linear(v, sd[f"confidence_predictor.{i}.weight"], sd[f"confidence_predictor.{i}.bias"])
+        x = torch.relu(bn1d(1, lin(0, x)))
+        x = torch.relu(bn1d(5, lin(4, x)))
+        return lin(8, x).squeeze(dim=-1), torch.zeros(len(lig_node_attr), dtype=x.dtype)
+
     def __call__(self, data, return_intermediates=False):
         c, sd, ns = self.cfg, self.sd, self.cfg.ns
         lig = data["ligand"]
-        tr_sigma, rot_sigma, tor_sigma = t_to_sigma(c, *[data.complex_t[k] for k in ("tr", "rot", "tor")])
+        tr_sigma, rot_sigma, tor_sigma = self._sigmas(data)
         (lig_node_attr, lig_edge_index, lig_edge_attr, lig_edge_sh, lig_ew,
          rec_node_attr, rec_edge_index, rec_edge_attr, rec_edge_sh, rec_ew) = self.embedding(data)
 
@@ -213,6 +239,9 @@ class CGModelOracle:
             if inter is not None:
                 inter[f"node_attr{l + 1}"] = node_attr.clone()
         lig_node_attr = node_attr[:n_lig]
+        if c.confidence_mode:
+            out = self._confidence(data, lig_node_attr)
+            return out + (inter,) if return_intermediates else out
         return self._readouts(data, lig_node_attr, tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates)
 
     def _readouts(self, data, lig_node_attr, tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates):

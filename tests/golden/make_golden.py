@@ -146,6 +146,10 @@ def main():
         "tiny_aa_l2_emb": dict(cfg=TINY.replace(all_atoms=True, num_conv_layers=2, num_prot_emb_layers=2, sh_lmax=2),
                                n_res=18, n_lig=9, n_samples=2, seed=7, t=0.5),
     }
+    # confidence models (get_model(..., confidence_mode=True)): evaluated at t = 0 by sampling() (utils/sampling.py:220)
+    cases["tiny_conf_l2"] = dict(cfg=TINY.replace(confidence_mode=True, sh_lmax=2, num_confidence_outputs=3), n_res=30, n_lig=11,
+                                 n_samples=3, seed=8, t=0.0)
+    cases["tiny_conf_aa_l1"] = dict(cfg=TINY.replace(confidence_mode=True, all_atoms=True, num_conv_layers=3, lig_max_radius=10.0), n_res=20, n_lig=9, n_samples=2, seed=9, t=0.25)
     if len(sys.argv) > 1:
         cases = {k: v for k, v in cases.items() if k in sys.argv[1:]}
     for name, c in cases.items():
@@ -155,11 +159,12 @@ def main():
         if cfg.fixed_center_conv:
             args.not_fixed_center_conv = False
         t_to_sigma = partial(t_to_sigma_compl, args=args)
-        model = get_model(args, torch.device("cpu"), t_to_sigma=t_to_sigma, no_parallel=True)
+        model = get_model(args, torch.device("cpu"), t_to_sigma=t_to_sigma, no_parallel=True,
+                          confidence_mode=cfg.confidence_mode)
         g, data_list, sd = build_case(cfg, c["n_res"], c["n_lig"], c["n_samples"], c["seed"], c["t"])
-        ref_keys = {k for k in model.state_dict().keys()}
+        ref_keys = {k for k in model.state_dict().keys() if not k.endswith("num_batches_tracked")}   # BatchNorm1d step counter
         assert ref_keys == set(state_dict_spec(cfg).keys()), (sorted(ref_keys ^ set(state_dict_spec(cfg).keys())))
-        model.load_state_dict(sd, strict=True)
+        model.load_state_dict(sd, strict=False)   # strict=False only for the num_batches_tracked counters filtered above
         model.eval()
 
         # ---- single forward at time t, with per-layer node tables via hooks
@@ -169,13 +174,19 @@ def main():
         layer_out = []
         hooks = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone())) for l in model.conv_layers]
         with torch.no_grad():
-            tr, rot, tor, _ = model(batch)
+            out = model(batch)
         for h in hooks:
             h.remove()
         fixture = {"cfg": cfg.__dict__.copy(), "graph": graph_to_dict(g),
                    "poses": torch.stack([d["ligand"].pos for d in data_list]), "t": c["t"],
-                   "state_dict": {k: v.clone() for k, v in sd.items()},
-                   "forward": {"tr": tr, "rot": rot, "tor": tor, "conv_out": layer_out}}
+                   "state_dict": {k: v.clone() for k, v in sd.items()}}
+        if cfg.confidence_mode:   # (confidence, atom_confidence), cg_model.py:353-366; no sampling loop of its own
+            fixture["forward"] = {"confidence": out[0], "atom_confidence": out[1], "conv_out": layer_out}
+            torch.save(fixture, os.path.join(HERE, f"{name}.pt"))
+            print(name, "confidence", out[0].tolist())
+            continue
+        tr, rot, tor, _ = out
+        fixture["forward"] = {"tr": tr, "rot": rot, "tor": tor, "conv_out": layer_out}
 
         # ---- reference sampling() with recorded Gaussian draws
         steps = 4

@@ -188,3 +188,38 @@ def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
             assert rel_err(o, r) < 1e-4
     for a_, b_ in zip(outs["1"], outs["0"]):
         assert rel_err(a_, b_) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1"])
+def test_confidence_mode_matches_reference_fixture(name, emu_lib):
+    """get_model(..., confidence_mode=True) for CGModel / AAModel (cg_model.py:353-366), fixture from the reference."""
+    fx, cfg, data_list = fixture_case(name)
+    m = MIScoreModel(cfg, device="cpu", lib_path=emu_lib)
+    m.load_state_dict(fx["state_dict"])
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    conf, atom_conf = m(batch)
+    ref = fx["forward"]
+    assert conf.shape == ref["confidence"].shape and rel_err(conf, ref["confidence"]) < 1e-4
+    assert atom_conf.shape == ref["atom_confidence"].shape and not atom_conf.any()
+
+
+def test_sampling_calls_confidence_model(emu_lib):
+    """sampling(..., confidence_model=...) (utils/sampling.py:208-231): confidences of the final poses, both with separate
+    confidence graphs (t = 0) and on the sampling batch itself (last step's t), against the oracle on the returned poses."""
+    import copy
+    from diffdock_amd.sampling import sampling
+    fx, cfg, data_list = fixture_case("tiny_l2")
+    fc, ccfg, _ = fixture_case("tiny_conf_l2")
+    score = make_model(cfg, fx["state_dict"], emu_lib)
+    conf_model = MIScoreModel(ccfg, device="cpu", lib_path=emu_lib)
+    conf_model.load_state_dict(fc["state_dict"])
+    sched = get_t_schedule(3)
+    for own_graphs, t_conf in ((True, 0.0), (False, float(sched[-1]))):
+        out, conf = sampling(copy.deepcopy(data_list), score, 3, sched, sched, sched, model_args=cfg, confidence_model=conf_model,
+                             confidence_data_list=copy.deepcopy(data_list) if own_graphs else None, batch_size=2,
+                             no_final_step_noise=True, seed=3)
+        b = HeteroBatch.from_data_list(out)
+        set_time(b, t_conf, t_conf, t_conf, b.num_graphs)
+        assert conf.shape == (len(data_list), ccfg.num_confidence_outputs)
+        assert rel_err(conf, oracle_model(ccfg, fc["state_dict"])(b)[0]) < 1e-4

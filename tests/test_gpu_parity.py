@@ -98,6 +98,17 @@ def test_ddl_synth_forward_matches_oracle(lmax, t):
     assert rel_err(tr2.cpu(), tr) < REL and rel_err(rot2.cpu(), rot) < REL and rel_err(tor2.cpu(), tor) < REL
 
 
+@pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1"])
+def test_confidence_mode_matches_reference_fixture(name):
+    fx, cfg, data_list = fixture_case(name)
+    m = MIScoreModel(cfg, device="cuda:0")
+    m.load_state_dict(fx["state_dict"])
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    conf, atom_conf = m(to_gpu(batch))
+    assert conf.is_cuda and rel_err(conf.cpu(), fx["forward"]["confidence"]) < REL and not atom_conf.any()
+
+
 def test_all_atom_ddl_width_matches_oracle():
     """AAModel (models/aa_model.py) at the DDL-synth channel widths: 120 residues / ~900 receptor atoms / 24 ligand atoms,
     2 poses started inside the pocket (so that the ligand<->atom radius graph is populated), nine edge groups per layer,

@@ -33,6 +33,21 @@ def test_forward_matches_reference(name):
     assert rel_err(tor, ref["tor"]) < 2e-5
 
 
+@pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1"])
+def test_confidence_matches_reference(name):
+    """get_model(..., confidence_mode=True) executed by the reference (CGModel / AAModel, cg_model.py:353-366)."""
+    fx, cfg, data_list = fixture_case(name)
+    model = oracle_model(cfg, fx["state_dict"])
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    conf, atom_conf, inter = model(batch, return_intermediates=True)
+    ref = fx["forward"]
+    for l, ref_nodes in enumerate(ref["conv_out"]):
+        assert rel_err(inter[f"node_attr{l + 1}"], ref_nodes) < 2e-5, l
+    assert conf.shape == ref["confidence"].shape and rel_err(conf, ref["confidence"]) < 2e-5
+    assert torch.equal(atom_conf, ref["atom_confidence"])
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_sampling_matches_reference(name):
     fx, cfg, data_list = fixture_case(name)
