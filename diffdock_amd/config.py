@@ -64,6 +64,10 @@ class ModelConfig:
     # layers, read-out = confidence_predictor on the graph-mean scalar ligand features; t is used raw (no t_to_sigma)
     confidence_mode: bool = False
     num_confidence_outputs: int = 1     # len(rmsd_classification_cutoff) + 1 when that is a list
+    # get_model(..., old=True) (utils/utils.py:180-219): the legacy class models/old_cg_model.py -- what the released DiffDock-L
+    # confidence checkpoint is (`old_confidence_model: true`).  Built in confidence mode only; always sh_lmax = 2, one output.
+    old: bool = False
+    use_old_atom_encoder: bool = True
 
     # ------------------------------------------------------------------ derived
     @property
@@ -112,7 +116,7 @@ class ModelConfig:
                  esm_embeddings_path="precomputed" if self.lm_embedding_type else None)
         for k in ('fixed_center_conv', 'lm_embedding_type', 'batch_norm', 'differentiate_convolutions',
                   'lig_max_radius', 'rec_max_radius', 'center_max_distance', 'in_lig_edge_features', 'confidence_mode',
-                  'num_confidence_outputs'):
+                  'num_confidence_outputs', 'old'):
             d.pop(k)
         if self.num_confidence_outputs > 1:
             d["rmsd_classification_cutoff"] = [2.0 + i for i in range(self.num_confidence_outputs - 1)]

@@ -133,6 +133,7 @@ struct RunGroup {
   int esplit = 1;
   int vn = -1;     // >= 0: virtual-node list id -> eligible for the fused kernel
   bool load = false;   // gather nodes are ligand atoms (few nodes, possibly many edges each): load mode of the fused kernel
+  bool swap_pq = false;   // first Linear sees [edge, GATHER node, TARGET node] (legacy lig->rec layer, old_cg_model.py:263)
 };
 
 // One TensorProductConvLayer in the node-contracted form (k_conv.hip).
@@ -171,8 +172,8 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     if (fuse_mm) {
       PhaseTimer t(m, "conv_fc1_gemms", gs);
       if (g.sig) { gemm(g.sig, ns, W1, L.n_edge, nullptr, rowbias, H, c.B, H, ns, 0, gs); rb = rowbias; }
-      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
-      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
+      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + (g.swap_pq ? 2 : 1) * ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
+      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + (g.swap_pq ? 1 : 2) * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
     } else {
       PhaseTimer t(m, "conv_fc1_gemms", gs);
       if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]
@@ -180,8 +181,8 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         rb = rowbias;
       }
       gemm(g.ea, ns, W1, L.n_edge, nullptr, HE, H, g.ea_rows, H, ns, 0, gs, g.ea_rows_dev, rb, g.sig_idx, H);
-      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
-      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + 2 * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
+      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + (g.swap_pq ? 2 : 1) * ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
+      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + (g.swap_pq ? 1 : 2) * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
     }
     if (fuse) {
       Cx::VnSet& vs = c.vn[g.vn];
@@ -477,7 +478,8 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.rot_sig = dalloc<float>(m, nullptr, {B, ns}); c.cutoff = dalloc<float>(m, "cross_cutoff", {B});
   c.rr_rowbias = dalloc<float>(m, nullptr, {B, H});
   c.embsum = dalloc<float>(m, nullptr, {nL, ns});
-  const int n_layers = (int)m.conv_layers.size(), K = (int)m.lig_emb_layers.size();
+  // node tables: one per layer boundary (+ two update tables for the legacy class, whose four layers are summed afterwards)
+  const int n_layers = cfg.old_model ? cfg.num_conv_layers + 2 : (int)m.conv_layers.size(), K = (int)m.lig_emb_layers.size();
   for (int l = 0; l <= n_layers + K; ++l) {
     static const char* names[] = {"x0", "x1", "x2", "x3", "x4", "x5", "x6", "x7", "x8", "x9", "x10", "x11", "x12"};
     c.X.push_back(dalloc<float>(m, l < 13 ? names[l] : nullptr, {N, XS}, true));
@@ -502,24 +504,22 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.Q_b = dalloc<float>(m, nullptr, {N, H}); c.rowbias_b = dalloc<float>(m, nullptr, {B, H});
   int HKp = 0, NTs = 0;
   auto upd = [&](const ConvW& L) { HKp = std::max(HKp, L.HKp); NTs = std::max(NTs, L.NTs); };
-  for (auto& L : m.conv_layers) upd(L);
-  for (auto& L : m.lig_emb_layers) upd(L);
-  for (auto& L : m.rec_emb_layers) upd(L);
+  std::vector<const ConvW*> all_layers;
+  for (auto* fam : {&m.conv_layers, &m.lig_emb_layers, &m.rec_emb_layers, &m.old_lig, &m.old_rec, &m.old_l2r, &m.old_r2l})
+    for (auto& L : *fam) all_layers.push_back(&L);
+  for (auto* L : all_layers) upd(*L);
   if (const char* e = getenv("DDMI_Y_CHUNK")) c.y_chunk = atoi(e);
   if (const char* e = getenv("DDMI_ESPLIT")) c.esplit_lig = std::max(0, atoi(e));
   // rows of the HBM-resident contracted table: receptor / atom gather groups only need them when the fused kernel is off
   const int y_big = std::max(std::max(nL, nR), m.fused ? 0 : c.nA);
   const int y_nodes = c.y_chunk > 0 ? std::min(c.y_chunk, y_big) : y_big;
   int ycols = NTs;   // granule-major rows (load mode of k_conv_fused) are 64 columns per granule
-  for (auto& L : m.conv_layers) ycols = std::max(ycols, 64 * L.n_fgran);
-  for (auto& L : m.lig_emb_layers) ycols = std::max(ycols, 64 * L.n_fgran);
+  for (auto* L : all_layers) ycols = std::max(ycols, 64 * L->n_fgran);
   c.Y = dalloc<float>(m, nullptr, {y_nodes, HKp, ycols}, true);
   c.Y_b = dalloc<float>(m, nullptr, {c.y_chunk > 0 ? std::min(c.y_chunk, nL) : nL, HKp, ycols}, true);
   if (m.fused) {
     int HKq = 0;
-    for (auto& L : m.conv_layers) HKq = std::max(HKq, L.HKq);
-    for (auto& L : m.rec_emb_layers) HKq = std::max(HKq, L.HKq);
-    for (auto& L : m.lig_emb_layers) HKq = std::max(HKq, L.HKq);
+    for (auto* L : all_layers) HKq = std::max(HKq, L->HKq);
     // virtual-node lists: 0 lig<-rec, 1 rec-rec, 2 lig-lig, 3 rec<-lig; all_atoms: 4 lig<-atom, 5 rec<-atom, 6 atom-atom,
     // 7 atom<-lig, 8 atom<-rec.  Ligand-gather lists (2, 3, 7) are load-mode lists (every node padded to an even count).
     const int ecap_v[9] = {c.Elr_cap, c.Err, c.Ell_cap, c.Elr_cap, c.Ela_cap, c.Ear, c.Eaa, c.Ela_cap, c.Ear};
@@ -609,9 +609,27 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   // ---- receptor-side constants (CGModel.embedding caches these on the data object, cg_model.py:273-295)
   launch_rec_edge_geom(c.rec_pos, c.rr_src, c.rr_dst, c.Err, cfg.smooth_edges ? cfg.rec_max_radius : 0.f, c.rr_dist, c.rr_nvec,
                        c.rr_ew, s);
-  launch_edge_mlp(mlp_args(m.rec_edge, ns, c.Err, nullptr, c.rr_dist, m.off_rec, m.D, m.coeff_rec, 0, m.rec_edge.b0, nullptr,
-                           c.rec_edge_base), s);
-  if (m.lm > 0) {
+  if (!cfg.old_model)
+    launch_edge_mlp(mlp_args(m.rec_edge, ns, c.Err, nullptr, c.rr_dist, m.off_rec, m.D, m.coeff_rec, 0, m.rec_edge.b0, nullptr,
+                             c.rec_edge_base), s);
+  if (cfg.old_model) {
+    // OldAtomEncoder on rows [restype | ESM | sigma] (models/layers.py:104-118): scalar slice = ESM[:sd], language-model
+    // slice = [ESM[sd:] | sigma].  Static per-residue part here; the sigma columns are a per-graph vector added per forward.
+    std::vector<int> ident(nR);
+    std::iota(ident.begin(), ident.end(), 0);
+    int* rid = m.cpool.upload(ident);
+    float* cat = dalloc<float>(m, nullptr, {nR, ns + m.lm});
+    launch_concat_rec_input(cc.rec_x, 1 + m.lm, m.rec_emb, ns, m.lm, nR, cat, s);   // [E[restype] | ESM]
+    if (m.lm > 0) {
+      float* emb1 = dalloc<float>(m, nullptr, {nR, ns});
+      gemm(cat + ns, ns + m.lm, m.old_rec_lin.W0, sd, m.old_rec_lin.b0, emb1, ns, nR, ns, sd, 0, s, nullptr, cat, rid, ns + m.lm);
+      gemm(emb1, ns, m.old_lm_W, ns + m.lm, m.old_lm_b, c.rec_node_base, XS, nR, ns, ns, 0, s);
+      gemm(cat + ns + sd, ns + m.lm, m.old_lm_W + ns, ns + m.lm, nullptr, c.rec_node_base, XS, nR, ns, m.lm - sd, 0, s, nullptr,
+           c.rec_node_base, rid, XS);
+    } else {
+      launch_add_rowvec(c.rec_node_base, XS, cat, ns, nullptr, 0, nullptr, nR, ns, 0, s);
+    }
+  } else if (m.lm > 0) {
     float* cat = dalloc<float>(m, nullptr, {nR, ns + m.lm});
     launch_concat_rec_input(cc.rec_x, 1 + m.lm, m.rec_emb, ns, m.lm, nR, cat, s);
     gemm(cat, ns + m.lm, m.rec_enc_W, ns + m.lm, m.rec_enc_b, c.rec_node_base, XS, nR, ns, ns + m.lm, 0, s);
@@ -685,12 +703,102 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   m.has_complex = true;
 }
 
+// ============================================================ legacy class, confidence mode
+// models/old_cg_model.py:203-291 (CGOldModel.forward with confidence_mode): four separate OldTensorProductConvLayers per
+// interaction layer, each = fc + tensor product + its own mean + BatchNorm (tensor_layers.py:338-380), summed onto the
+// zero-padded node features.
+static void forward_old_confidence(Model& m, const float* lig_pos, const float* t_tr, float* conf_out, hipStream_t s) {
+  Cx& c = *m.cx;
+  const ddmi_config& cfg = m.cfg;
+  const int ns = m.ns, sd = m.sd, B = c.B, nL = c.nL, nR = c.nR, Lc = cfg.num_conv_layers;
+  ++c.epoch;
+  PhaseTimer t_fwd(m, "forward_total", s);
+  std::unique_ptr<PhaseTimer> t_phase(new PhaseTimer(m, "embed_and_graphs", s));
+  launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, c.temb, s);
+  // OldAtomEncoder: ligand = sum of embeddings + linear(sigma) ; receptor = static part + the sigma columns of lm_embedding_layer
+  gemm(c.temb, sd, m.old_lig_lin.W0, sd, m.old_lig_lin.b0, c.ligsig, ns, B, ns, sd, 0, s);
+  if (m.lm > 0) gemm(c.temb, sd, m.old_lm_W + ns + m.lm - sd, ns + m.lm, nullptr, c.rec_sig, ns, B, ns, sd, 0, s);
+  else gemm(c.temb, sd, m.old_rec_lin.W0, sd, m.old_rec_lin.b0, c.rec_sig, ns, B, ns, sd, 0, s);
+  gemm(c.temb, sd, m.lig_edge.W0 + m.nf, m.lig_edge.in, m.lig_edge.b0, c.ll_gvec, ns, B, ns, sd, 0, s);
+  gemm(c.temb, sd, m.cross_edge.W0, m.cross_edge.in, m.cross_edge.b0, c.cross_gvec, ns, B, ns, sd, 0, s);
+  gemm(c.temb, sd, m.rec_edge.W0, m.rec_edge.in, m.rec_edge.b0, c.center_gvec, ns, B, ns, sd, 0, s);   // receptor-edge sigma term
+  float* X0 = c.X[0];
+  launch_lig_node_embed(c.lig_x, nL, m.lig_emb, m.lig_emb_off, 16, ns, c.embsum, s);
+  launch_add_rowvec(X0, XS, c.embsum, ns, c.ligsig, ns, c.lig_batch, nL, ns, ns, s);
+  launch_add_rowvec(X0 + (size_t)nL * XS, XS, c.rec_node_base, XS, c.rec_sig, ns, c.rec_batch, nR, ns, ns, s);
+  // ligand graph, receptor edge attributes (with sigma, old_cg_model.py:411-413), cross graph with the raw-t cutoff
+  launch_lig_radius(lig_pos, c.lig_batch, c.lig_ptr, nL, c.maxNl, cfg.lig_max_radius, c.lig_cap, c.adjrank, c.cnt_g, s);
+  launch_ll_count(c.adjrank, c.lig_batch, c.lig_ptr, nL, c.maxNl, c.bg, c.bt, c.cnt_g, c.cnt_t, s);
+  launch_exclusive_scan(c.cnt_g, c.goff_ll, nL, s);
+  launch_exclusive_scan(c.cnt_t, c.toff_ll, nL, s);
+  launch_ll_fill(lig_pos, c.lig_batch, c.lig_ptr, nL, c.maxNl, c.adjrank, c.goff_ll, c.toff_ll, c.bg, c.bt, c.Eb, c.bond_src,
+                 c.bond_dst, c.bond_grank, c.bond_trank, cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.ll_tgt, c.ll_tslot,
+                 c.ll_featidx, c.ll_batch, c.ll_dist, c.ll_nvec, c.ll_ew, s);
+  {
+    EdgeMlpArgs a = mlp_args(m.lig_edge, ns, c.Ell_cap, c.goff_ll + nL, c.ll_dist, m.off_lig, m.D, m.coeff_lig, m.nf + sd,
+                             c.ll_gvec, c.ll_batch, c.ll_ea);
+    a.feat = c.bond_attr; a.featidx = c.ll_featidx; a.nfeat = m.nf; a.W0f = m.lig_edge.W0; a.ldw0f = m.lig_edge.in;
+    launch_edge_mlp(a, s);
+  }
+  launch_edge_mlp(mlp_args(m.rec_edge, ns, c.Err, nullptr, c.rr_dist, m.off_rec, m.D, m.coeff_rec, sd, c.center_gvec, c.rr_batch,
+                           c.rec_edge_base), s);
+  const float* cut_dev = nullptr;
+  if (cfg.dynamic_max_cross) {
+    launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, s, 1);
+    cut_dev = c.cutoff;
+  }
+  launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
+                     cfg.cross_max_distance, nullptr, c.pairrank, c.cnt_l, c.cnt_r, s);
+  launch_exclusive_scan(c.cnt_l, c.offs_l, nL, s);
+  launch_exclusive_scan(c.cnt_r, c.offs_r, nR, s);
+  launch_cross_fill(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, c.pairrank, c.offs_l, c.offs_r,
+                    cut_dev, cfg.cross_max_distance, cfg.smooth_edges, c.g1_tgt, c.g1_tslot, c.g3_tgt, c.g3_tslot, c.pbatch,
+                    c.pdist, c.pnvec, c.pew, s);
+  launch_edge_mlp(mlp_args(m.cross_edge, ns, c.Elr_cap, c.offs_l + nL, c.pdist, m.off_cross, m.Dc, m.coeff_cross, sd,
+                           c.cross_gvec, c.pbatch, c.cross_ea), s);
+  RunGroup g_ll{0, nL, 0, nL, c.goff_ll, c.ll_tgt, c.ll_tslot, nullptr, c.ll_ea, c.Ell_cap, c.goff_ll + nL, nullptr,
+                nullptr, c.ll_nvec, c.ll_ew, 1.f, c.msg[0]};
+  RunGroup g_lr{nL, nR, 0, nL, c.offs_r, c.g1_tgt, c.g1_tslot, c.g1_tslot, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
+                nullptr, c.pnvec, c.pew, 1.f, c.msg[1]};
+  RunGroup g_rr{nL, nR, nL, nR, c.rr_goff, c.rr_tgt, c.rr_tslot, c.rr_arow, c.rec_edge_base, c.Err, nullptr, nullptr, nullptr,
+                c.rr_nvec, c.rr_ew, 1.f, c.msg[2]};
+  RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
+                nullptr, c.pnvec, c.pew, 1.f, c.msg[3]};   // same spherical harmonics as rec->lig (old_cg_model.py:264)
+  g_ll.vn = 2; g_ll.load = true; g_lr.vn = 0; g_rr.vn = 1; g_rl.vn = 3; g_rl.load = true; g_rl.swap_pq = true;
+  g_rl.esplit = c.esplit_lig > 0 ? c.esplit_lig : std::max(1, std::min(8, (c.Elr_cap / std::max(nL, 1) + 63) / 64));
+  float *Ua = c.X[Lc + 1], *Ub = c.X[Lc + 2];
+  t_phase.reset();
+  for (int l = 0; l < Lc; ++l) {
+    const bool last = l == Lc - 1;
+    const float* Xin = c.X[l];
+    run_conv(m, m.old_lig[l], {g_ll}, c.rg_all + 0, 1, Xin, Ua, 0, nL, s);
+    run_conv(m, m.old_r2l[l], {g_lr}, c.rg_all + 1, 1, Xin, Ub, 0, nL, s);
+    if (!last) {
+      run_conv(m, m.old_rec[l], {g_rr}, c.rg_all + 2, 1, Xin, Ua, nL, nR, s);
+      run_conv(m, m.old_l2r[l], {g_rl}, c.rg_all + 3, 1, Xin, Ub, nL, nR, s);
+    }
+    const ConvW& L = m.old_lig[l];
+    PhaseTimer t(m, "k_reduce_bn", s);
+    launch_add3(c.X[l + 1], Xin, L.D_in, Ua, Ub, last ? nL : nL + nR, L.D_out, s);
+  }
+  PhaseTimer t_read(m, "readouts", s);
+  ConfHeadArgs a{};
+  a.B = B; a.X = c.X[Lc]; a.lig_ptr = c.lig_ptr; a.ns = ns;
+  a.n_tail = Lc >= 3 ? ns : 0;
+  a.tail_off = m.old_lig[Lc - 1].D_out - a.n_tail;
+  a.W0 = m.conf_W[0]; a.b0 = m.conf_b[0]; a.sc0 = m.conf_bn_scale[0]; a.sh0 = m.conf_bn_shift[0];
+  a.W1 = m.conf_W[1]; a.b1 = m.conf_b[1]; a.sc1 = m.conf_bn_scale[1]; a.sh1 = m.conf_bn_shift[1];
+  a.W2 = m.conf_W[2]; a.b2 = m.conf_b[2]; a.n_out = 1; a.out = conf_out;
+  launch_conf_head(a, s);
+}
+
 // =================================================================================== forward
 void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor, float* tr_out,
              float* rot_out, float* tor_out, hipStream_t s, float* conf_out) {
   DDMI_REQUIRE(m.has_complex, DDMI_ERR_STATE, "ddmi_set_complex must precede ddmi_forward");
   const bool conf = m.cfg.confidence_mode != 0;
   DDMI_REQUIRE(conf == (conf_out != nullptr), DDMI_ERR_STATE, "score models use ddmi_forward, confidence models ddmi_confidence");
+  if (m.cfg.old_model) { forward_old_confidence(m, lig_pos, t_tr, conf_out, s); return; }
   DDMI_REQUIRE(conf || !m.cfg.scale_by_sigma || (m.so3_table && (m.cfg.no_torsion || m.torus_table)), DDMI_ERR_STATE,
                "score-norm tables not set (ddmi_set_table)");
   Cx& c = *m.cx;

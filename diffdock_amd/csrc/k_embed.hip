@@ -233,6 +233,21 @@ void launch_rec_edge_geom(const float* pos, const int* src, const int* dst, int 
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
+// X_out[r][c] = pad(X_in[r])[c] + U1[r][c] + U2[r][c]  (legacy class: node features + the two layer updates, old_cg_model.py:276-285)
+__global__ void k_add3(float* __restrict__ out, const float* __restrict__ x, int d_in, const float* __restrict__ u1,
+                       const float* __restrict__ u2, int rows, int d_out) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)rows * d_out) return;
+  const int r = (int)(t / d_out), c = (int)(t - (long)r * d_out);
+  const size_t o = (size_t)r * XS + c;
+  out[o] = (c < d_in ? x[o] : 0.f) + u1[o] + u2[o];
+}
+void launch_add3(float* out, const float* x, int d_in, const float* u1, const float* u2, int rows, int d_out, hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_add3, dim3(cdiv((long)rows * d_out, 256)), dim3(256), 0, s, out, x, d_in, u1, u2, rows, d_out);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 // out[j] = [ emb[restype_j] (ns) | rec_x[j][1:1+lm] ]  -- input of additional_features_embedder
 __global__ void k_concat_rec_input(const float* __restrict__ rec_x, int ldx, const float* __restrict__ emb, int ns,
                                    int lm, int nR, float* __restrict__ out) {

@@ -179,6 +179,7 @@ void launch_edge_mlp(const EdgeMlpArgs& a, hipStream_t s);
 // vec = pos_dst[dst] - pos[src] (pos_dst = nullptr: same array): static receptor / atom relations
 void launch_rec_edge_geom(const float* pos, const int* src, const int* dst, int E, float smooth_max, float* dist,
                           float* nvec, float* ew, hipStream_t s, const float* pos_dst = nullptr);
+void launch_add3(float* out, const float* x, int d_in, const float* u1, const float* u2, int rows, int d_out, hipStream_t s);
 void launch_concat_rec_input(const float* rec_x, int ldx, const float* emb, int ns, int lm, int nR, float* out,
                              hipStream_t s);
 

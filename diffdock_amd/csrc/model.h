@@ -76,6 +76,9 @@ struct Model {
   float coeff_lig = 0, coeff_rec = 0, coeff_cross = 0, coeff_center = 0;
   std::vector<ConvW> rec_emb_layers, lig_emb_layers, conv_layers;
   ConvW final_conv, tor_conv;
+  std::vector<ConvW> old_lig, old_rec, old_l2r, old_r2l;   // legacy class: four separate layers per interaction layer
+  Mlp2W old_lig_lin, old_rec_lin;                          // OldAtomEncoder.linear (W0/b0 only)
+  float *old_lm_W = nullptr, *old_lm_b = nullptr;          // OldAtomEncoder.lm_embedding_layer [ns][1280 + ns]
   float *tor_W0 = nullptr, *tor_W3 = nullptr;
   float* tor_T = nullptr; int tor_ds = 0, tor_dts = 0;  // FullTensorProduct(sh, 2e) dense table
   float* time_freq = nullptr;

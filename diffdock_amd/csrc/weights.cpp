@@ -115,6 +115,43 @@ void build_weight_spec(Model& m) {
   const Irreps sh = sh_irreps(c.sh_lmax);
   const bool faster = c.sh_lmax == 1 && !c.use_second_order_repr;
   const int K = c.num_prot_emb_layers, Lc = c.num_conv_layers;
+  if (c.old_model) {   // models/old_cg_model.py:18-160 (confidence mode), models/layers.py:70-118, models/tensor_layers.py:338-380
+    DDMI_REQUIRE(c.confidence_mode && c.sh_lmax == 2 && !c.all_atoms && K == 0, DDMI_ERR_ARG,
+                 "legacy class: confidence mode, sh_lmax = 2, CG graphs, no embedding layers");
+    auto old_encoder = [&](const std::string& n, const int* dims, int nd, bool lm) {
+      for (int i = 0; i < nd; ++i) S.push_back({n + ".atom_embedding_list." + std::to_string(i) + ".weight", {dims[i], ns}});
+      lin(n + ".linear", sd, ns);
+      if (lm) lin(n + ".lm_embedding_layer", 1280 + ns, ns);
+    };
+    old_encoder("lig_node_embedding", LIG_DIMS, 16, false);
+    mlp("lig_edge_embedding", m.nf + sd + m.D, ns, ns);
+    old_encoder("rec_node_embedding", REC_DIMS, 1, m.lm > 0);
+    mlp("rec_edge_embedding", sd + m.D, ns, ns);
+    mlp("cross_edge_embedding", sd + m.Dc, ns, ns);
+    S.push_back({"lig_distance_expansion.offset", {m.D}});
+    S.push_back({"rec_distance_expansion.offset", {m.D}});
+    S.push_back({"cross_distance_expansion.offset", {m.Dc}});
+    ddmi_config co = c;
+    co.reduce_pseudoscalars = 0;
+    m.rec_emb_layers.clear(); m.lig_emb_layers.clear(); m.conv_layers.clear();
+    std::vector<ConvW>* fams[4] = {&m.old_lig, &m.old_rec, &m.old_l2r, &m.old_r2l};
+    const char* names[4] = {"lig_conv_layers.", "rec_conv_layers.", "lig_to_rec_conv_layers.", "rec_to_lig_conv_layers."};
+    for (int f = 0; f < 4; ++f) {
+      fams[f]->assign(Lc, ConvW());
+      for (int l = 0; l < Lc; ++l) {
+        init_conv_meta(c, (*fams[f])[l], names[f] + std::to_string(l), layer_irreps(co, l), sh, layer_irreps(co, l + 1), 3 * ns, 1,
+                       false, false, true);
+        conv((*fams[f])[l]);
+      }
+    }
+    lin("confidence_predictor.0", Lc >= 3 ? 2 * ns : ns, ns);
+    lin("confidence_predictor.4", ns, ns);
+    lin("confidence_predictor.8", ns, 1);
+    for (int i : {1, 5})
+      for (const char* k : {".weight", ".bias", ".running_mean", ".running_var"})
+        S.push_back({"confidence_predictor." + std::to_string(i) + k, {ns}});
+    return;
+  }
   encoder("lig_node_embedding", LIG_DIMS, 16, sd);
   mlp("lig_edge_embedding", m.nf + sd + m.D, ns, ns);
   if (c.all_atoms) {   // models/aa_model.py:90-103
@@ -421,10 +458,52 @@ void commit_weights(Model& m) {
     }
     m.lig_emb = m.wpool.upload(emb);
     m.lig_emb_off = m.wpool.upload(off);
-    m.lig_enc.W0 = up(m, "lig_node_embedding.additional_features_embedder.weight");
-    m.lig_enc.b0 = up(m, "lig_node_embedding.additional_features_embedder.bias");
+    if (!c.old_model) {
+      m.lig_enc.W0 = up(m, "lig_node_embedding.additional_features_embedder.weight");
+      m.lig_enc.b0 = up(m, "lig_node_embedding.additional_features_embedder.bias");
+    }
   }
   m.rec_emb = up(m, "rec_node_embedding.atom_embedding_list.0.weight");
+  if (c.old_model) {
+    m.old_lig_lin.W0 = up(m, "lig_node_embedding.linear.weight"); m.old_lig_lin.b0 = up(m, "lig_node_embedding.linear.bias");
+    m.old_rec_lin.W0 = up(m, "rec_node_embedding.linear.weight"); m.old_rec_lin.b0 = up(m, "rec_node_embedding.linear.bias");
+    if (m.lm > 0) { m.old_lm_W = up(m, "rec_node_embedding.lm_embedding_layer.weight"); m.old_lm_b = up(m, "rec_node_embedding.lm_embedding_layer.bias"); }
+    m.lig_edge = up_mlp(m, "lig_edge_embedding");
+    m.rec_edge = up_mlp(m, "rec_edge_embedding");
+    m.cross_edge = up_mlp(m, "cross_edge_embedding");
+    for (int i = 0; i < 3; ++i) {
+      m.conf_W[i] = up(m, "confidence_predictor." + std::to_string(4 * i) + ".weight");
+      m.conf_b[i] = up(m, "confidence_predictor." + std::to_string(4 * i) + ".bias");
+    }
+    for (int i = 0; i < 2; ++i) {
+      const std::string n = "confidence_predictor." + std::to_string(4 * i + 1);
+      const HostTensor &w = W(m, n + ".weight"), &b = W(m, n + ".bias"), &rm = W(m, n + ".running_mean"), &rv = W(m, n + ".running_var");
+      std::vector<float> sc(m.ns), sh(m.ns);
+      for (int k = 0; k < m.ns; ++k) { sc[k] = w.data[k] / std::sqrt(rv.data[k] + 1e-5f); sh[k] = b.data[k] - rm.data[k] * sc[k]; }
+      m.conf_bn_scale[i] = m.wpool.upload(sc); m.conf_bn_shift[i] = m.wpool.upload(sh);
+    }
+    auto offs_old = [&](const std::string& k, float*& dev, float& coeff) {
+      const HostTensor& t = W(m, k);
+      DDMI_REQUIRE(t.data.size() >= 2, DDMI_ERR_ARG, "distance expansion needs >= 2 gaussians");
+      dev = m.wpool.upload(t.data);
+      const float d = t.data[1] - t.data[0];
+      coeff = (float)(-0.5 / ((double)d * (double)d));
+    };
+    offs_old("lig_distance_expansion.offset", m.off_lig, m.coeff_lig);
+    offs_old("rec_distance_expansion.offset", m.off_rec, m.coeff_rec);
+    offs_old("cross_distance_expansion.offset", m.off_cross, m.coeff_cross);
+    for (auto* fam : {&m.old_lig, &m.old_rec, &m.old_l2r, &m.old_r2l})
+      for (auto& L : *fam) commit_conv(m, L);
+    const int half = m.sd / 2;
+    if ((int)m.time_freq_host.size() != half) {
+      m.time_freq_host.resize(half);
+      const double e = std::log(10000.0) / (half - 1);
+      for (int k = 0; k < half; ++k) m.time_freq_host[k] = std::exp((float)((float)k * (float)(-e)));
+    }
+    m.time_freq = m.wpool.upload(m.time_freq_host);
+    m.committed = true;
+    return;
+  }
   if (m.lm > 0) {
     m.rec_enc_W = up(m, "rec_node_embedding.additional_features_embedder.weight");
     m.rec_enc_b = up(m, "rec_node_embedding.additional_features_embedder.bias");

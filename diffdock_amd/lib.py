@@ -31,7 +31,8 @@ class Config(C.Structure):
                                          "odd_parity", "no_torsion", "scale_by_sigma", "fixed_center_conv")] + \
                [(n, C.c_float) for n in ("embedding_scale", "tr_sigma_min", "tr_sigma_max", "rot_sigma_min",
                                          "rot_sigma_max", "tor_sigma_min", "tor_sigma_max")] + \
-               [("all_atoms", C.c_int32), ("confidence_mode", C.c_int32), ("num_confidence_outputs", C.c_int32)]
+               [("all_atoms", C.c_int32), ("confidence_mode", C.c_int32), ("num_confidence_outputs", C.c_int32),
+                ("old_model", C.c_int32)]
 
 
 class Complex(C.Structure):
@@ -56,6 +57,8 @@ def make_config(cfg) -> Config:
     for name, _ in Config._fields_:
         if name == "lm_embedding_dim":
             c.lm_embedding_dim = cfg.lm_embedding_dim
+        elif name == "old_model":
+            c.old_model = int(cfg.old)
         else:
             setattr(c, name, getattr(cfg, name))
     return c

@@ -174,6 +174,8 @@ class MIScoreModel:
             conf = torch.empty(self._B, n_out, device=dev)
             _lib.check(self.lib, self.lib.ddmi_confidence(self._h, _ptr(pos), _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(conf),
                                                           self._stream()))
+            if self.cfg.old:   # the legacy class returns the bare tensor (old_cg_model.py:287-291)
+                return conf.squeeze(-1)
             return conf.squeeze(-1), torch.zeros(self._n_lig, device=dev)
         tr = torch.empty(self._B, 3, device=dev)
         rot = torch.empty(self._B, 3, device=dev)
@@ -257,9 +259,17 @@ def get_model(args, device, t_to_sigma=None, no_parallel=True, confidence_mode=F
     """Same signature as the reference factory (utils/utils.py:172).  `t_to_sigma` is accepted for
     compatibility; the geometric schedule it implements (utils/diffusion_utils.py:28-32) is evaluated
     in-library from the sigma bounds in `args`."""
-    if old:
-        raise NotImplementedError("legacy model classes (models/old_cg_model.py, get_model(old=True)) are outside the built path")
     cfg = args if isinstance(args, ModelConfig) else config_from_args(args)
+    if old:   # utils/utils.py:180-219: CGOldModel; no sh_lmax / embedding-layer / pseudoscalar arguments reach it
+        if not confidence_mode or cfg.all_atoms:
+            raise NotImplementedError("the legacy classes are built in confidence mode on CG graphs only (models/old_cg_model.py)")
+        cfg = cfg.replace(old=True, confidence_mode=True, sh_lmax=2, num_prot_emb_layers=0, reduce_pseudoscalars=False,
+                          num_confidence_outputs=1,
+                          use_old_atom_encoder=getattr(args, "use_old_atom_encoder", True) if not isinstance(args, ModelConfig)
+                          else cfg.use_old_atom_encoder)
+        if not cfg.use_old_atom_encoder:
+            raise NotImplementedError("CGOldModel with the new AtomEncoder cannot be constructed by the reference either "
+                                      "(AtomEncoder has no lm_embedding_type argument)")
     if confidence_mode != cfg.confidence_mode:
         cfg = cfg.replace(confidence_mode=bool(confidence_mode))
     return MIScoreModel(cfg, device=device, lib_path=lib_path)

@@ -12,7 +12,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from .config import ModelConfig, LIG_FEATURE_DIMS, REC_RESIDUE_FEATURE_DIMS, REC_ATOM_FEATURE_DIMS
+from .config import ModelConfig, LIG_FEATURE_DIMS, LM_EMBEDDING_DIM, REC_RESIDUE_FEATURE_DIMS, REC_ATOM_FEATURE_DIMS
 from .irreps import parse_irreps, irreps_num, sh_irreps, full_tp_irreps, tp_weight_numel
 
 
@@ -68,6 +68,8 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
         if cfg.batch_norm:
             bn(f"{name}.batch_norm", out_irr)
 
+    if cfg.old:
+        return _old_confidence_spec(cfg, spec, lin, mlp, bn)
     sh = sh_irreps(cfg.sh_lmax)
     encoder("lig_node_embedding", LIG_FEATURE_DIMS, sd)
     mlp("lig_edge_embedding", cfg.in_lig_edge_features + sd + cfg.distance_embed_dim, ns, ns)
@@ -122,6 +124,47 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
         conv("tor_bond_conv", last_out, tor_sh_irreps(cfg), tor_conv_out(cfg), 3 * ns, 3 * ns, 1, False)
         lin("tor_final_layer.0", 2 * ns if not cfg.odd_parity else ns, ns, bias=False)
         lin("tor_final_layer.3", ns, 1, bias=False)
+    return spec
+
+
+def _old_confidence_spec(cfg, spec, lin, mlp, bn):
+    """models/old_cg_model.py:18-160 in confidence mode (CGOldModel + OldAtomEncoder + OldTensorProductConvLayer)."""
+    assert cfg.confidence_mode and cfg.use_old_atom_encoder and cfg.sh_lmax == 2 and not cfg.all_atoms, \
+        "legacy class: confidence mode, OldAtomEncoder, sh_lmax = 2 (get_model(old=True) passes no sh_lmax), CG graphs"
+    ns, sd = cfg.ns, cfg.sigma_embed_dim
+
+    def old_encoder(name, dims, lm):
+        for i, d in enumerate(dims):
+            spec[f"{name}.atom_embedding_list.{i}.weight"] = ((d, ns), "emb")
+        lin(f"{name}.linear", sd, ns)
+        if lm:
+            lin(f"{name}.lm_embedding_layer", LM_EMBEDDING_DIM + ns, ns)
+    old_encoder("lig_node_embedding", LIG_FEATURE_DIMS, False)
+    mlp("lig_edge_embedding", cfg.in_lig_edge_features + sd + cfg.distance_embed_dim, ns, ns)
+    old_encoder("rec_node_embedding", REC_RESIDUE_FEATURE_DIMS, cfg.lm_embedding_type is not None)
+    mlp("rec_edge_embedding", sd + cfg.distance_embed_dim, ns, ns)
+    mlp("cross_edge_embedding", sd + cfg.cross_distance_embed_dim, ns, ns)
+    spec["lig_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:lig")
+    spec["rec_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:rec")
+    spec["cross_distance_expansion.offset"] = ((cfg.cross_distance_embed_dim,), "offset:cross")
+    sh = sh_irreps(2)
+    old_cfg = cfg.replace(reduce_pseudoscalars=False)
+    for fam in ("lig_conv_layers", "rec_conv_layers", "lig_to_rec_conv_layers", "rec_to_lig_conv_layers"):
+        for l in range(cfg.num_conv_layers):
+            a, b = old_cfg.layer_irreps(l)
+            W = tp_weight_numel(a, sh, b, False)
+            lin(f"{fam}.{l}.fc.0", 3 * ns, 3 * ns)
+            lin(f"{fam}.{l}.fc.3", 3 * ns, W)
+            if cfg.batch_norm:
+                bn(f"{fam}.{l}.batch_norm", b)
+    lin("confidence_predictor.0", 2 * ns if cfg.num_conv_layers >= 3 else ns, ns)
+    lin("confidence_predictor.4", ns, ns)
+    lin("confidence_predictor.8", ns, 1)
+    for i in (1, 5):
+        spec[f"confidence_predictor.{i}.weight"] = ((ns,), "bn_w")
+        spec[f"confidence_predictor.{i}.bias"] = ((ns,), "bn_b")
+        spec[f"confidence_predictor.{i}.running_mean"] = ((ns,), "bn_mean")
+        spec[f"confidence_predictor.{i}.running_var"] = ((ns,), "bn_var")
     return spec
 
 

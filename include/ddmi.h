@@ -56,6 +56,9 @@ typedef struct ddmi_config {
   /* get_model(..., confidence_mode=True): same interaction layers, confidence_predictor read-out (cg_model.py:181-207,
    * 353-366); the model is evaluated with ddmi_confidence instead of ddmi_forward */
   int32_t confidence_mode, num_confidence_outputs;
+  /* get_model(..., old=True) (utils/utils.py:180-219): legacy class models/old_cg_model.py (the released DiffDock-L
+   * confidence checkpoint, `old_confidence_model: true`).  Built in confidence mode, OldAtomEncoder, sh_lmax = 2. */
+  int32_t old_model;
 } ddmi_config;
 
 /* Static description of one collated batch of complexes = the fields of the PyG Batch the

@@ -84,7 +84,8 @@ def install_stubs():
 def build_case(cfg, n_res, n_lig, n_samples, seed, t):
     from diffdock_amd.synth import make_complex, make_pose_list
     from diffdock_amd.weights import init_state_dict
-    g = make_complex(seed=seed, n_res=n_res, n_lig=n_lig, all_atoms=cfg.all_atoms, atoms_per_res=(3, 7))
+    g = make_complex(seed=seed, n_res=n_res, n_lig=n_lig, all_atoms=cfg.all_atoms, atoms_per_res=(3, 7),
+                     lm_dim=cfg.lm_embedding_dim)
     # all-atom cases start inside the pocket: the ligand<-atom group (5 A radius) must not be empty, FasterTensorProduct
     # cannot reshape an empty edge group (reference defect, see header)
     data_list = make_pose_list(g, n_samples, tr_sigma_max=cfg.tr_sigma_max, seed=seed + 100,
@@ -150,6 +151,12 @@ def main():
     cases["tiny_conf_l2"] = dict(cfg=TINY.replace(confidence_mode=True, sh_lmax=2, num_confidence_outputs=3), n_res=30, n_lig=11,
                                  n_samples=3, seed=8, t=0.0)
     cases["tiny_conf_aa_l1"] = dict(cfg=TINY.replace(confidence_mode=True, all_atoms=True, num_conv_layers=3, lig_max_radius=10.0), n_res=20, n_lig=9, n_samples=2, seed=9, t=0.25)
+    # the legacy class the released DiffDock-L confidence checkpoint uses (get_model(old=True), models/old_cg_model.py)
+    cases["tiny_oldconf"] = dict(cfg=TINY.replace(old=True, confidence_mode=True, sh_lmax=2, num_conv_layers=3), n_res=28, n_lig=10,
+                                 n_samples=3, seed=10, t=0.0)
+    cases["tiny_oldconf_2l"] = dict(cfg=TINY.replace(old=True, confidence_mode=True, sh_lmax=2, num_conv_layers=2,
+                                                      lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=25.0),
+                                    n_res=22, n_lig=9, n_samples=2, seed=11, t=0.3)
     if len(sys.argv) > 1:
         cases = {k: v for k, v in cases.items() if k in sys.argv[1:]}
     for name, c in cases.items():
@@ -160,7 +167,7 @@ def main():
             args.not_fixed_center_conv = False
         t_to_sigma = partial(t_to_sigma_compl, args=args)
         model = get_model(args, torch.device("cpu"), t_to_sigma=t_to_sigma, no_parallel=True,
-                          confidence_mode=cfg.confidence_mode)
+                          confidence_mode=cfg.confidence_mode, old=cfg.old)
         g, data_list, sd = build_case(cfg, c["n_res"], c["n_lig"], c["n_samples"], c["seed"], c["t"])
         ref_keys = {k for k in model.state_dict().keys() if not k.endswith("num_batches_tracked")}   # BatchNorm1d step counter
         assert ref_keys == set(state_dict_spec(cfg).keys()), (sorted(ref_keys ^ set(state_dict_spec(cfg).keys())))
@@ -172,7 +179,8 @@ def main():
         B = batch.num_graphs
         set_time(batch, None, c["t"], c["t"], c["t"], B, cfg.all_atoms, torch.device("cpu"))
         layer_out = []
-        hooks = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone())) for l in model.conv_layers]
+        hooks = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone()))
+                 for l in (model.conv_layers if not cfg.old else [])]
         with torch.no_grad():
             out = model(batch)
         for h in hooks:
@@ -181,9 +189,12 @@ def main():
                    "poses": torch.stack([d["ligand"].pos for d in data_list]), "t": c["t"],
                    "state_dict": {k: v.clone() for k, v in sd.items()}}
         if cfg.confidence_mode:   # (confidence, atom_confidence), cg_model.py:353-366; no sampling loop of its own
-            fixture["forward"] = {"confidence": out[0], "atom_confidence": out[1], "conv_out": layer_out}
+            if cfg.old:   # legacy class returns the bare confidence tensor (old_cg_model.py:290-291)
+                fixture["forward"] = {"confidence": out}
+            else:
+                fixture["forward"] = {"confidence": out[0], "atom_confidence": out[1], "conv_out": layer_out}
             torch.save(fixture, os.path.join(HERE, f"{name}.pt"))
-            print(name, "confidence", out[0].tolist())
+            print(name, "confidence", fixture["forward"]["confidence"].tolist())
             continue
         tr, rot, tor, _ = out
         fixture["forward"] = {"tr": tr, "rot": rot, "tor": tor, "conv_out": layer_out}

@@ -204,6 +204,22 @@ def test_confidence_mode_matches_reference_fixture(name, emu_lib):
     assert atom_conf.shape == ref["atom_confidence"].shape and not atom_conf.any()
 
 
+@pytest.mark.parametrize("name", ["tiny_oldconf", "tiny_oldconf_2l"])
+def test_legacy_confidence_class_matches_reference_fixture(name, emu_lib, monkeypatch):
+    """models/old_cg_model.py in confidence mode (get_model(old=True)): OldAtomEncoder, four separately normalised layers per
+    interaction layer, the swapped [edge, gather, target] input of the lig->rec layer; fused and unfused kernels."""
+    fx, cfg, data_list = fixture_case(name)
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DDMI_FUSED", fused)
+        m = MIScoreModel(cfg, device="cpu", lib_path=emu_lib)
+        m.load_state_dict(fx["state_dict"])
+        conf = m(batch)
+        assert torch.is_tensor(conf) and conf.shape == fx["forward"]["confidence"].shape
+        assert rel_err(conf, fx["forward"]["confidence"]) < 1e-4
+
+
 def test_sampling_calls_confidence_model(emu_lib):
     """sampling(..., confidence_model=...) (utils/sampling.py:208-231): confidences of the final poses, both with separate
     confidence graphs (t = 0) and on the sampling batch itself (last step's t), against the oracle on the returned poses."""

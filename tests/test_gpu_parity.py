@@ -109,6 +109,33 @@ def test_confidence_mode_matches_reference_fixture(name):
     assert conf.is_cuda and rel_err(conf.cpu(), fx["forward"]["confidence"]) < REL and not atom_conf.any()
 
 
+@pytest.mark.parametrize("name", ["tiny_oldconf", "tiny_oldconf_2l"])
+def test_legacy_confidence_class_matches_reference_fixture(name):
+    fx, cfg, data_list = fixture_case(name)
+    m = MIScoreModel(cfg, device="cuda:0")
+    m.load_state_dict(fx["state_dict"])
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    conf = m(to_gpu(batch))
+    assert conf.is_cuda and rel_err(conf.cpu(), fx["forward"]["confidence"]) < REL
+
+
+def test_legacy_confidence_class_full_width_matches_oracle():
+    """The legacy confidence class at DiffDock-L-like widths (ns=24, nv=6, 5 layers, sh_lmax=2) on a 200-residue / 28-atom
+    complex, 3 poses, t = 0 (cross cutoff 20 A) -- static-shape and generic fused kernels, load mode, against the oracle."""
+    cfg = DDL_SYNTH.replace(old=True, confidence_mode=True, sh_lmax=2, ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32,
+                            distance_embed_dim=32, cross_distance_embed_dim=32, embed_also_ligand=False)
+    sd = init_state_dict(cfg, seed=5)
+    g = make_complex(seed=21, n_res=200, n_lig=28)
+    dl = make_pose_list(g, 3, tr_sigma_max=cfg.tr_sigma_max, seed=22, initial_noise_std_proportion=0.2)
+    batch = HeteroBatch.from_data_list(dl)
+    set_time(batch, 0, 0, 0, 3)
+    ref = oracle_model(cfg, sd)(batch)
+    m = MIScoreModel(cfg, device="cuda:0")
+    m.load_state_dict(sd)
+    assert rel_err(m(to_gpu(batch)).cpu(), ref) < REL
+
+
 def test_all_atom_ddl_width_matches_oracle():
     """AAModel (models/aa_model.py) at the DDL-synth channel widths: 120 residues / ~900 receptor atoms / 24 ligand atoms,
     2 poses started inside the pocket (so that the ligand<->atom radius graph is populated), nine edge groups per layer,

@@ -48,6 +48,17 @@ def test_confidence_matches_reference(name):
     assert torch.equal(atom_conf, ref["atom_confidence"])
 
 
+@pytest.mark.parametrize("name", ["tiny_oldconf", "tiny_oldconf_2l"])
+def test_legacy_confidence_matches_reference(name):
+    """get_model(..., old=True, confidence_mode=True) executed by the reference: models/old_cg_model.py CGOldModel with
+    OldAtomEncoder and OldTensorProductConvLayer -- the class of the released DiffDock-L confidence checkpoint."""
+    fx, cfg, data_list = fixture_case(name)
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    conf = oracle_model(cfg, fx["state_dict"])(batch)
+    assert conf.shape == fx["forward"]["confidence"].shape and rel_err(conf, fx["forward"]["confidence"]) < 2e-5
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_sampling_matches_reference(name):
     fx, cfg, data_list = fixture_case(name)

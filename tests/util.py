@@ -53,6 +53,9 @@ def oracle_model(cfg, state_dict, so3_t=None, tor_t=None, dtype=torch.float32):
     from oracle.cg_model import CGModelOracle
     if so3_t is None:
         so3_t, tor_t = tables()
+    if cfg.old:
+        from oracle.old_cg_model import CGOldConfidenceOracle
+        return CGOldConfidenceOracle(cfg, state_dict, so3_t, tor_t, dtype)
     return (AAModelOracle if cfg.all_atoms else CGModelOracle)(cfg, state_dict, so3_t, tor_t, dtype)
 
 
