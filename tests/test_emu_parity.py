@@ -239,3 +239,31 @@ def test_sampling_calls_confidence_model(emu_lib):
         set_time(b, t_conf, t_conf, t_conf, b.num_graphs)
         assert conf.shape == (len(data_list), ccfg.num_confidence_outputs)
         assert rel_err(conf, oracle_model(ccfg, fc["state_dict"])(b)[0]) < 1e-4
+
+
+def test_all_atom_ragged_batch_and_empty_ligand_atom_group(emu_lib):
+    """AAModel on a batch of two DIFFERENT complexes (residue / atom / ligand counts differ), first with one ligand out of
+    reach of every receptor atom, then with the ligand<->atom group completely empty (the reference's FasterTensorProduct
+    cannot run that; sh_lmax = 2 can), against the oracle."""
+    from diffdock_amd.config import TINY
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = TINY.replace(all_atoms=True, sh_lmax=2, num_conv_layers=3, dynamic_max_cross=False, cross_max_distance=60.0)
+    sd = init_state_dict(cfg, seed=2)
+    g1 = make_complex(seed=31, n_res=14, n_lig=7, all_atoms=True, atoms_per_res=(2, 5))
+    g2 = make_complex(seed=32, n_res=19, n_lig=11, all_atoms=True, atoms_per_res=(2, 5))
+    d1 = make_pose_list(g1, 1, tr_sigma_max=5.0, seed=1, initial_noise_std_proportion=0.05)[0]
+    d2 = make_pose_list(g2, 1, tr_sigma_max=5.0, seed=2, initial_noise_std_proportion=0.05)[0]
+    d2["ligand"].pos = d2["ligand"].pos + torch.tensor([30.0, 0.0, 0.0])
+    m = make_model(cfg, sd, emu_lib)
+    for empty in (False, True):
+        if empty:
+            d1["ligand"].pos = d1["ligand"].pos + torch.tensor([0.0, 40.0, 0.0])
+        batch = HeteroBatch.from_data_list([d1, d2])
+        set_time(batch, 0.5, 0.5, 0.5, 2)
+        ref = oracle_model(cfg, sd)(batch, return_intermediates=True)
+        assert (ref[4]["edge_counts"][2] == 0) == empty
+        out = m(batch)
+        assert int(m.debug_buffer("offs_la_l")[-1]) == ref[4]["edge_counts"][2]
+        for o, r in zip(out[:3], ref[:3]):
+            assert rel_err(o, r) < 1e-4
