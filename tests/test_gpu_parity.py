@@ -197,6 +197,42 @@ def test_full_size_properties():
         assert rel_err(tor_s.cpu(), tor[lo * R:(lo + 20) * R].cpu()) < 1e-5
 
 
+def test_all_atom_full_size_properties():
+    """The all-atom model at the BASELINE configs[2] shape (40 poses x 300 residues x ~2250 receptor atoms x 30 ligand atoms,
+    0.7 M atom-atom edges): determinism, SE(3) equivariance of the scores, and shard invariance -- no oracle at this size."""
+    cfg = DDL_SYNTH.replace(all_atoms=True, fixed_center_conv=True, dynamic_max_cross=False, cross_max_distance=80.0)
+    sd = init_state_dict(cfg, seed=99)
+    m = gpu_model(cfg, sd)
+    B = 40
+    g = make_complex(seed=14, n_res=300, n_lig=30, all_atoms=True)
+    dl = make_pose_list(g, B, tr_sigma_max=cfg.tr_sigma_max, seed=15, initial_noise_std_proportion=0.2)
+
+    def run(lst, rot=None, shift=None):
+        b = HeteroBatch.from_data_list(lst)
+        if rot is not None:
+            for nt in ("ligand", "receptor", "atom"):
+                b[nt].pos = b[nt].pos @ rot.T + shift
+        set_time(b, 0.5, 0.5, 0.5, len(lst))
+        return m(to_gpu(b))[:3]
+    tr, rot, tor = run(dl)
+    tr_b, rot_b, tor_b = run(dl)
+    assert torch.equal(tr, tr_b) and torch.equal(rot, rot_b) and torch.equal(tor, tor_b)
+    assert torch.isfinite(tr).all() and torch.isfinite(rot).all() and torch.isfinite(tor).all()
+    assert int(m.debug_buffer("offs_la_l")[-1]) > 0
+    q = torch.tensor([0.2, 0.6, -0.3, 0.7], dtype=torch.float64)
+    q = q / q.norm()
+    w, x, y, z = q
+    Rm = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]).float()
+    tr_r, rot_r, tor_r = run(dl, Rm, torch.tensor([[-4.0, 1.0, 2.5]]))
+    assert rel_err(tr_r.cpu(), tr.cpu() @ Rm.T) < 2e-3 and rel_err(rot_r.cpu(), rot.cpu() @ Rm.T) < 2e-3
+    assert rel_err(tor_r.cpu(), tor.cpu()) < 2e-3
+    R = tor.numel() // B
+    tr_s, rot_s, tor_s = run(dl[10:20])
+    assert rel_err(tr_s.cpu(), tr[10:20].cpu()) < 1e-5 and rel_err(tor_s.cpu(), tor[10 * R:20 * R].cpu()) < 1e-5
+
+
 def test_sharded_sampling_is_sample_invariant():
     """Counter-based noise keyed by sample id: sampling 8 poses at once == sampling them as 2 shards."""
     cfg = DDL_SYNTH.replace(num_conv_layers=3, tr_sigma_max=5.0, fixed_center_conv=True)
