@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DDMI_NT_LOAD(ptr) (*(ptr))
 #define DDMI_WAVE_SYNC() hipemu_wave_sync()
 #define DDMI_UNIFORM(x) (x)
+#define DDMI_SCHED_FENCE() ((void)0)
 #else
 // wave-uniform value -> scalar register
 #define DDMI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
@@ -39,6 +40,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* LDS only: global stores stay in flight */ \
     __builtin_amdgcn_wave_barrier();                                                         \
   } while (0)
+// nothing is scheduled across this point (hand-placed issue order of the MFMA main loops)
+#define DDMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define DDMI_NT_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
 #define DDMI_NT_LOAD(ptr) __builtin_nontemporal_load((ptr))
 #endif

@@ -15,7 +15,14 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <type_traits>
+#include <utility>
+
 #include "kernels.h"
+
+#ifndef FC_MANUAL
+#define FC_MANUAL 1   // dense-row main loop with the hand-placed issue order (0: compiler-scheduled loop, for A/B runs)
+#endif
 
 namespace ddmi {
 
@@ -46,12 +53,12 @@ __device__ __forceinline__ float4 nt_load4(const float* p) {
 // Rows u >= mul_in of the packed weights are zero, so the x fragments need no predicate there (they read the
 // neighbouring block of the finite x row).
 template <int NSTEPS>
-__device__ __forceinline__ void nc_chain(const float* __restrict__ bp, int bstride, const float* __restrict__ xp,
+__device__ __forceinline__ void nc_chain(const float* __restrict__ bp, const float* __restrict__ xp,
                                          int xstride, f32x4& acc0, f32x4& acc1, int dbg) {
   float bv[NSTEPS], a0[NSTEPS], a1[NSTEPS];
 #pragma unroll
   for (int j = 0; j < NSTEPS; ++j) {
-    bv[j] = (dbg & 256) ? 0.f : bp[(size_t)j * bstride];
+    bv[j] = (dbg & 256) ? 0.f : bp[j];   // a lane's fragments of one chain are contiguous: vector loads
     a0[j] = xp[j * xstride];
     a1[j] = xp[16 * NC_XS + j * xstride];
   }
@@ -64,15 +71,20 @@ __device__ __forceinline__ void nc_chain(const float* __restrict__ bp, int bstri
   }
 }
 
-struct NcSlotRt { const float* bp; const float* xp; int bstride, xstride, steps; };   // per-lane, k-invariant part
+// Packed second-layer weights of one (k, path): [16-w tile][lane = 16*lq + lr][step j] with u = 4j + lq, w = 16*tile + lr,
+// i.e. the B fragments of one chain lie side by side per lane (a wave's request covers whole cache lines).
+__device__ __forceinline__ int nc_lane_off(const NcSlot& S, int w0, int lr, int lq) {
+  const int steps = S.u_pad >> 2;
+  return ((w0 >> 4) * 64 + lq * 16 + lr) * steps;
+}
+struct NcSlotRt { const float* bp; const float* xp; int xstride, steps; };   // per-lane, k-invariant part
 
 __device__ __forceinline__ NcSlotRt nc_slot_setup(const NcSlot S, const float* __restrict__ wpack, const float* __restrict__ xbuf,
                                                   int w0, int lr, int lq) {
   NcSlotRt R;
   R.steps = S.din == 0 ? 0 : (S.u_pad >> 2);
-  R.bp = wpack + S.wk_off + (size_t)lq * S.w_pad + w0 + lr;
+  R.bp = wpack + S.wk_off + nc_lane_off(S, w0, lr, lq);
   R.xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
-  R.bstride = 4 * S.w_pad;
   R.xstride = 4 * S.din;
   return R;
 }
@@ -83,12 +95,12 @@ __device__ __forceinline__ void nc_slot(const NcSlotRt& R, size_t koff, f32x4& a
   const float* __restrict__ bp = R.bp + koff;
   const float* __restrict__ xp = R.xp;
   int steps = R.steps;
-  while (steps >= 12) { nc_chain<12>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg); bp += 12 * (size_t)R.bstride; xp += 12 * R.xstride; steps -= 12; }
-  if (steps >= 8) { nc_chain<8>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg); bp += 8 * (size_t)R.bstride; xp += 8 * R.xstride; steps -= 8; }
-  if (steps >= 4) { nc_chain<4>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg); bp += 4 * (size_t)R.bstride; xp += 4 * R.xstride; steps -= 4; }
-  if (steps == 3) nc_chain<3>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg);
-  else if (steps == 2) nc_chain<2>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg);
-  else if (steps == 1) nc_chain<1>(bp, R.bstride, xp, R.xstride, acc0, acc1, dbg);
+  while (steps >= 12) { nc_chain<12>(bp, xp, R.xstride, acc0, acc1, dbg); bp += 12; xp += 12 * R.xstride; steps -= 12; }
+  if (steps >= 8) { nc_chain<8>(bp, xp, R.xstride, acc0, acc1, dbg); bp += 8; xp += 8 * R.xstride; steps -= 8; }
+  if (steps >= 4) { nc_chain<4>(bp, xp, R.xstride, acc0, acc1, dbg); bp += 4; xp += 4 * R.xstride; steps -= 4; }
+  if (steps == 3) nc_chain<3>(bp, xp, R.xstride, acc0, acc1, dbg);
+  else if (steps == 2) nc_chain<2>(bp, xp, R.xstride, acc0, acc1, dbg);
+  else if (steps == 1) nc_chain<1>(bp, xp, R.xstride, acc0, acc1, dbg);
 }
 
 // Workgroup = 32 gather nodes (two 16-row MFMA sub-tiles) x KC consecutive k.  The x rows sit in LDS (read-only after
@@ -562,15 +574,14 @@ constexpr int FC_VN = 16, FC_KC = 8, FC_WAVES = 8, FC_CAP0 = 12, FC_CAPN = 4;
 constexpr int FC_YROW = 72, FC_YVN = FC_KC * FC_YROW + 4, FC_YB = FC_VN * FC_YVN;
 
 // k-invariant per-lane part of one slot chain: uniform weight base + 32-bit lane offset (scalar-base global loads)
-struct FcSlotRt { const float* wb; const float* xp; int loff, bstride, xstride, steps; };
+struct FcSlotRt { const float* wb; const float* xp; int loff, xstride, steps; };
 __device__ __forceinline__ FcSlotRt fc_slot_setup(const NcSlot S, const float* __restrict__ wpack, const float* __restrict__ xbuf,
                                                   int w0, int lr, int lq) {
   FcSlotRt R;
   R.steps = S.din == 0 ? 0 : (S.u_pad >> 2);
   R.wb = wpack + S.wk_off;
-  R.loff = lq * S.w_pad + w0 + lr;
+  R.loff = nc_lane_off(S, w0, lr, lq);
   R.xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
-  R.bstride = 4 * S.w_pad;
   R.xstride = 4 * S.din;
   return R;
 }
@@ -584,7 +595,7 @@ template <int N>
 __device__ __forceinline__ void fc_fetch_n(const FcSlotRt& R, size_t koff, float* bv) {
   const float* __restrict__ wb = R.wb + koff;
 #pragma unroll
-  for (int j = 0; j < N; ++j) bv[j] = (wb + (size_t)j * R.bstride)[R.loff];
+  for (int j = 0; j < N; ++j) bv[j] = (wb + j)[R.loff];
 }
 template <int N>
 __device__ __forceinline__ f32x4 fc_apply_n(const FcSlotRt& R, const float* bv) {
@@ -599,7 +610,7 @@ __device__ __forceinline__ void fc_fetch(const FcSlotRt& R, size_t koff, float* 
   const float* __restrict__ wb = R.wb + koff;
 #pragma unroll
   for (int j = 0; j < CAP; ++j)
-    if (j < R.steps) bv[j] = (wb + (size_t)j * R.bstride)[R.loff];
+    if (j < R.steps) bv[j] = (wb + j)[R.loff];
 }
 template <int CAP>
 __device__ __forceinline__ f32x4 fc_apply(const FcSlotRt& R, size_t koff, const float* bv) {
@@ -609,14 +620,14 @@ __device__ __forceinline__ f32x4 fc_apply(const FcSlotRt& R, size_t koff, const 
   for (int j = 0; j < CAP; ++j)
     if (j < R.steps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], bv[j], acc, 0, 0, 0);
   for (int j = CAP; j < R.steps; ++j)   // chains longer than the prefetch capacity (ns > 48)
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], (R.wb + koff + (size_t)j * R.bstride)[R.loff], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], (R.wb + koff + j)[R.loff], acc, 0, 0, 0);
   return acc;
 }
 template <int N>
 __device__ __forceinline__ void fc_direct_n(const FcSlotRt& R, size_t koff, int j0, f32x4& acc) {
   float bv[N], av[N];   // all fragments requested before the first MFMA: one L2 round trip per chain piece
 #pragma unroll
-  for (int j = 0; j < N; ++j) { bv[j] = (R.wb + koff + (size_t)(j0 + j) * R.bstride)[R.loff]; av[j] = R.xp[(j0 + j) * R.xstride]; }
+  for (int j = 0; j < N; ++j) { bv[j] = (R.wb + koff + (j0 + j))[R.loff]; av[j] = R.xp[(j0 + j) * R.xstride]; }
 #pragma unroll
   for (int j = 0; j < N; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
 }
@@ -667,7 +678,16 @@ __device__ __forceinline__ void fc_store_rows(const float* __restrict__ stg, int
 // straight-line code per 8-k group -- the k-invariant x fragments stay in registers, the weight fragments arrive one
 // iteration ahead, and the four slot chains are issued interleaved (a dependent f32 MFMA costs 40 cycles, an independent
 // one 32).
-template <int S0, int SN>
+__device__ __forceinline__ float2 fc_ld2nt(const float* p) {
+#ifdef DDMI_HIPEMU
+  return *reinterpret_cast<const float2*>(p);
+#else
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+  return make_float2(v.x, v.y);
+#endif
+}
+template <int S0, int SN, bool DENSE>
 __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotRt& s0, const FcSlotRt& s1, const FcSlotRt& s2,
                                             const FcSlotRt& s3, int KS, int NG8, int wave, const float* __restrict__ hfrag,
                                             const int (&vne)[2], float* ywr, const float* yrd) {
@@ -685,11 +705,11 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
   const size_t gstep = (size_t)8 * KS;
 #define FC_FETCH()                                                                       \
   do {                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < S0; ++j) b0[j] = (w0 + (size_t)j * s0.bstride)[s0.loff]; \
+    _Pragma("unroll") for (int j = 0; j < S0; ++j) b0[j] = (w0 + j)[s0.loff]; \
     _Pragma("unroll") for (int j = 0; j < SN; ++j) {                                     \
-      b1[j] = (w1 + (size_t)j * s1.bstride)[s1.loff];                                    \
-      b2[j] = (w2 + (size_t)j * s2.bstride)[s2.loff];                                    \
-      b3[j] = (w3 + (size_t)j * s3.bstride)[s3.loff];                                    \
+      b1[j] = (w1 + j)[s1.loff];                                    \
+      b2[j] = (w2 + j)[s2.loff];                                    \
+      b3[j] = (w3 + j)[s3.loff];                                    \
     }                                                                                    \
     w0 += gstep; w1 += gstep; w2 += gstep; w3 += gstep;                                  \
   } while (0)
@@ -710,55 +730,274 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
   float2 hC[2][2], hN[2][2];
   const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
   const float* __restrict__ hp = hfrag;
+#ifdef FC_HB_NT
+#define FC_LDH(p) fc_ld2nt(p)
+#else
+#define FC_LDH(p) (*reinterpret_cast<const float2*>(p))
+#endif
 #define FC_LOADH(dst)                                                                    \
   do {                                                                                   \
-    dst[0][0] = *reinterpret_cast<const float2*>(hp);                                    \
-    dst[0][1] = two0 ? *reinterpret_cast<const float2*>(hp + (size_t)NG8 * 128) : make_float2(0.f, 0.f);     \
-    dst[1][0] = *reinterpret_cast<const float2*>(hp + (size_t)2 * NG8 * 128);            \
-    dst[1][1] = two1 ? *reinterpret_cast<const float2*>(hp + (size_t)3 * NG8 * 128) : make_float2(0.f, 0.f); \
+    dst[0][0] = FC_LDH(hp);                                                              \
+    dst[0][1] = (DENSE || two0) ? FC_LDH(hp + (size_t)NG8 * 128) : make_float2(0.f, 0.f);     \
+    dst[1][0] = FC_LDH(hp + (size_t)2 * NG8 * 128);                                      \
+    dst[1][1] = (DENSE || two1) ? FC_LDH(hp + (size_t)3 * NG8 * 128) : make_float2(0.f, 0.f); \
     hp += 128;                                                                           \
+  } while (0)
+#define FC_EDGE_GEMM(buf)                                                                \
+  do {                                                                                   \
+    const float* __restrict__ yb0 = yrd + (buf) * FC_YB;                                 \
+    _Pragma("unroll") for (int vi = 0; vi < 2; ++vi) {                                   \
+      _Pragma("unroll") for (int sub = 0; sub < 2; ++sub) {                              \
+        const float* __restrict__ yb = yb0 + vi * FC_YVN + sub * FC_YROW;                \
+        const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];                   \
+        const float a0 = sub == 0 ? hC[vi][0].x : hC[vi][0].y;                          \
+        acc[vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[vi][0][0], 0, 0, 0); \
+        acc[vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[vi][0][1], 0, 0, 0); \
+        acc[vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[vi][0][2], 0, 0, 0); \
+        acc[vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[vi][0][3], 0, 0, 0); \
+        if (DENSE || (vi == 0 ? two0 : two1)) {                                          \
+          const float a1 = sub == 0 ? hC[vi][1].x : hC[vi][1].y;                          \
+          acc[vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[vi][1][0], 0, 0, 0); \
+          acc[vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[vi][1][1], 0, 0, 0); \
+          acc[vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[vi][1][2], 0, 0, 0); \
+          acc[vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[vi][1][3], 0, 0, 0); \
+        }                                                                                \
+      }                                                                                  \
+    }                                                                                    \
+  } while (0)
+#define FC_ROLL()                                                                        \
+  do {                                                                                   \
+    _Pragma("unroll") for (int vi = 0; vi < 2; ++vi)                                     \
+      _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];          \
   } while (0)
   FC_FETCH();
   FC_LOADH(hC);
+#ifdef FC_HB_DEPTH3
+  float2 hM[2][2];             // hidden rows two chunks ahead (the re-reads of a tile's rows come from MALL/HBM, not L2)
+  if (NG8 > 1) FC_LOADH(hN);
+#endif
   FC_CONTRACT(0);
   if (NG8 > 1) FC_FETCH();
   __syncthreads();
-  for (int g = 0; g < NG8; ++g) {
-    if (g + 1 < NG8) {
-      FC_CONTRACT((g + 1) & 1);
-      if (g + 2 < NG8) FC_FETCH();
-      FC_LOADH(hN);
-    }
-    const float* __restrict__ yb0 = yrd + (g & 1) * FC_YB;
-#pragma unroll
-    for (int vi = 0; vi < 2; ++vi) {
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const float* __restrict__ yb = yb0 + vi * FC_YVN + sub * FC_YROW;
-        const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];
-        const float a0 = sub == 0 ? hC[vi][0].x : hC[vi][0].y;
-        acc[vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[vi][0][0], 0, 0, 0);
-        acc[vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[vi][0][1], 0, 0, 0);
-        acc[vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[vi][0][2], 0, 0, 0);
-        acc[vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[vi][0][3], 0, 0, 0);
-        if (vi == 0 ? two0 : two1) {
-          const float a1 = sub == 0 ? hC[vi][1].x : hC[vi][1].y;
-          acc[vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[vi][1][0], 0, 0, 0);
-          acc[vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[vi][1][1], 0, 0, 0);
-          acc[vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[vi][1][2], 0, 0, 0);
-          acc[vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[vi][1][3], 0, 0, 0);
-        }
+  int g = 0;
+  for (; g + 2 < NG8; ++g) {   // steady state: straight-line body (with DENSE no branch at all between two barriers)
+    FC_CONTRACT((g + 1) & 1);
+    FC_FETCH();
+#ifdef FC_HB_DEPTH3
+    FC_LOADH(hM);
+#else
+    FC_LOADH(hN);
+#endif
+    FC_EDGE_GEMM(g & 1);
+#if defined(FC_SCHED) && !defined(DDMI_HIPEMU)
+    if (DENSE) {   // issue order of the block: the loads and LDS traffic ride in the MFMA shadows instead of in bursts between them
+      constexpr int NC = S0 + 3 * SN;
+      _Pragma("unroll") for (int i = 0; i < NC; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // hidden-row fragments of the next chunk
+        if (i >= NC - 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // first B fragments of the edge product
+      }
+      _Pragma("unroll") for (int i = 0; i < 32; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < NC) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // weight fragments two chunks ahead
+        if (i >= FC_SCHED && i < FC_SCHED + 16) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // contracted rows -> LDS
+        if (i % 4 == 1 && i < 24) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
     }
+#endif
     __syncthreads();
+    FC_ROLL();
+#ifdef FC_HB_DEPTH3
+    _Pragma("unroll") for (int vi = 0; vi < 2; ++vi)
+      _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) hN[vi][rt] = hM[vi][rt];
+#endif
+  }
+  if (g + 1 < NG8) {           // last contraction: nothing left to request
+    FC_CONTRACT((g + 1) & 1);
+#ifndef FC_HB_DEPTH3
+    FC_LOADH(hN);
+#endif
+    FC_EDGE_GEMM(g & 1);
+    __syncthreads();
+    FC_ROLL();
+    ++g;
+  }
+  FC_EDGE_GEMM(g & 1);
+  __syncthreads();
+#undef FC_EDGE_GEMM
+#undef FC_LDH
+#undef FC_ROLL
+#undef FC_FETCH
+#undef FC_CONTRACT
+#undef FC_LOADH
+}
+
+// Dense-row main loop with a hand-placed issue order.  Two waves share a SIMD and meet at a barrier every chunk, so they
+// run the same phase at the same time: whatever is not an MFMA has to ride in the 32-cycle shadow of one, not sit in a
+// burst between two MFMA phases.  Per chunk: the NC contraction MFMAs of chunk g+1 (with the four hidden-row fragment
+// requests of chunk g+1 and the first B-fragment reads of chunk g between them), then the 32 edge MFMAs of chunk g with,
+// one per MFMA, the NC weight-fragment requests of chunk g+2 (uniform base + 32-bit lane offset), the 8 paired LDS stores
+// of the rows just contracted and the B-fragment reads of the next (virtual node, k pair).  sched_barrier fences pin it.
+template <int I, int N, class F>
+__device__ __forceinline__ void fc_sfor(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); fc_sfor<I + 1, N>(f); }
+}
+template <int S0, int SN>
+struct FcOrder {   // issue order of the four slot chains: slot 0 alternating with slots 1, 2, 3 (dependent MFMAs 40 cycles apart)
+  static constexpr int NC = S0 + 3 * SN, NJ = S0 > 3 * SN ? S0 : 3 * SN;
+  static constexpr int find(int i, bool want_slot) {
+    int c = 0;
+    for (int j = 0; j < NJ; ++j) {
+      if (j < S0) { if (c == i) return want_slot ? 0 : j; ++c; }
+      if (j < 3 * SN) { if (c == i) return want_slot ? 1 + j % 3 : j / 3; ++c; }
+    }
+    return 0;
+  }
+  static constexpr int slot(int i) { return find(i, true); }
+  static constexpr int step(int i) { return find(i, false); }
+};
+template <int S0, int SN>
+__device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
+                                                  int KS, int NG8, int wave, const float* __restrict__ hfrag, float* ywr,
+                                                  const float* yrd) {
+  using O = FcOrder<S0, SN>;
+  constexpr int NC = O::NC;
+  float xa[NC];
+  float bw[4][S0 > 3 ? S0 : 3];   // weight fragments [slot][step] (slot 0: S0 steps, slots 1..3: SN steps)
+  fc_sfor<0, NC>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    xa[i] = sl[O::slot(i)].xp[O::step(i) * sl[O::slot(i)].xstride];
+  });
+  int woff[4];                 // uniform: row k = 8g + wave of each slot's packed weights
+  unsigned lo[4];              // per-lane byte offset of the lane's run of fragments
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    woff[t] = DDMI_UNIFORM((int)(sl[t].wb - wpack) + wave * KS);
+    lo[t] = (unsigned)sl[t].loff * 4u;
+  }
+  const int gstep = 8 * KS;
+  // vector requests: slot 0 in pieces of 4 steps (or one piece of 3), slots 1..3 one piece of 3 each
+  constexpr int NL0 = S0 >= 4 ? S0 / 4 : (S0 > 0 ? 1 : 0), NL = NL0 + (SN > 0 ? 3 : 0);
+  static_assert(S0 % 4 == 0 || S0 == 3, "slot-0 chains are whole 4-step pieces or one 3-step piece");
+  static_assert(SN == 0 || SN == 3, "slots 1..3 hold 3-step chains");
+  struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
+  auto loadw = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int t = i < NL0 ? 0 : 1 + (i - NL0);
+    const char* __restrict__ ub = reinterpret_cast<const char*>(wpack + woff[t]) + lo[t];
+    if constexpr (t == 0 && S0 >= 4) {
+      const float4 v = *reinterpret_cast<const float4*>(ub + 16 * i);
+      bw[0][4 * i] = v.x; bw[0][4 * i + 1] = v.y; bw[0][4 * i + 2] = v.z; bw[0][4 * i + 3] = v.w;
+    } else {
+      const F3 v = *reinterpret_cast<const F3*>(ub);
+      bw[t][0] = v.a; bw[t][1] = v.b; bw[t][2] = v.c;
+    }
+  };
+  float2 hC[2][2], hN[2][2];
+  const float* __restrict__ hp = hfrag;
+  auto loadh = [&](float2 (&dst)[2][2], int piece) __attribute__((always_inline)) {
+    dst[piece >> 1][piece & 1] = *reinterpret_cast<const float2*>(hp + (size_t)piece * NG8 * 128);
+  };
+  f32x4 r[4];
+  float q[2][4];               // B fragments of the edge product: [parity of the (virtual node, k pair) group][column block]
+  auto readq = [&](int par, int buf, int grp) __attribute__((always_inline)) {
+    const float* __restrict__ yb = yrd + buf * FC_YB + (grp >> 1) * FC_YVN + (grp & 1) * FC_YROW;
+    q[par][0] = yb[0]; q[par][1] = yb[16]; q[par][2] = yb[32]; q[par][3] = yb[48];
+  };
+  auto store_piece = [&](int buf, int piece) __attribute__((always_inline)) {   // rows of node quarter `rr`, slots 2h and 2h+1
+    float* yw = ywr + buf * FC_YB;
+    const int rr = piece & 3, h = piece >> 2;
+    yw[rr * FC_YVN + 16 * (2 * h)] = r[2 * h][rr];
+    yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
+  };
+  // one chunk step: contraction of chunk g+1 into buffer cb (DO_C), weight requests for chunk g+2 (DO_W), hidden rows of
+  // chunk g+1 (DO_H), edge product of chunk g out of buffer eb
+  auto step = [&](auto do_c, auto do_w, auto do_h, int cb, int eb) __attribute__((always_inline)) {
+    constexpr bool DO_C = decltype(do_c)::value, DO_W = decltype(do_w)::value, DO_H = decltype(do_h)::value;
+    if constexpr (DO_C) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      fc_sfor<0, NC>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int t = O::slot(i);
+        r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[t][O::step(i)], r[t], 0, 0, 0);
+#ifndef FC_EXP_NOH
+        if constexpr (DO_H) { if (i < 4) loadh(hN, i); }
+#endif
+        if (i == NC - 3) readq(0, eb, 0);
+        DDMI_SCHED_FENCE();
+      });
+    } else {
+      readq(0, eb, 0);
+    }
+    fc_sfor<0, 32>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int grp = m >> 3, t8 = m & 7, vi = grp >> 1, sub = grp & 1, rt = t8 >> 2, c = t8 & 3;
+      const float av = sub == 0 ? hC[vi][rt].x : hC[vi][rt].y;
+      acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
+#ifndef FC_EXP_NOW
+      if constexpr (DO_W) { if constexpr (m % 2 == 0 && m / 2 < NL) loadw(std::integral_constant<int, m / 2>{}); }
+#endif
+#ifndef FC_EXP_NOST
+      if constexpr (DO_C) { if (m >= 2 && m < 10) store_piece(cb, m - 2); }
+#endif
+#ifndef FC_EXP_NORD
+      if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
+#endif
+      DDMI_SCHED_FENCE();
+    });
+    if constexpr (DO_W) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) woff[t] += gstep;
+    }
+    if constexpr (DO_H) hp += 128;
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  // prologue: chunk 0 contracted, chunk 1 requested
+  fc_sfor<0, NL>(loadw);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) woff[t] += gstep;
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
+  hp += 128;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fc_sfor<0, NC>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int t = O::slot(i);
+    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[t][O::step(i)], r[t], 0, 0, 0);
+  });
+#pragma unroll
+  for (int pc = 0; pc < 8; ++pc) store_piece(0, pc);
+  if (NG8 > 1) {
+    fc_sfor<0, NL>(loadw);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) woff[t] += gstep;
+  }
+  __syncthreads();
+  int g = 0;
+  for (; g + 2 < NG8; ++g) {
+    step(T{}, T{}, T{}, (g + 1) & 1, g & 1);
+#ifndef FC_EXP_NOBAR
+    __syncthreads();
+#endif
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
   }
-#undef FC_FETCH
-#undef FC_CONTRACT
-#undef FC_LOADH
+  if (g + 1 < NG8) {
+    step(T{}, F{}, T{}, (g + 1) & 1, g & 1);
+    __syncthreads();
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+    ++g;
+  }
+  step(F{}, F{}, F{}, 0, g & 1);
+  __syncthreads();
 }
 
 // Load mode (gather nodes with many edges each, e.g. ligand atoms towards all residues): the contracted rows come
@@ -855,7 +1094,8 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const
 // double-buffered in LDS; per iteration a wave contracts row w of group g+1 (weights requested one iteration earlier),
 // requests the weights of group g+2 and the hidden fragments of g+1, and multiplies group g into its edge accumulators:
 // one barrier per 8 k.  The bias row of the packed second layer (h = 1) is added outside the MFMA loop.
-// MODE 0: static chain shapes, 1: generic (predicated) contraction, 2: load mode (rows from k_node_contract)
+// MODE 0: static chain shapes, 1: generic (predicated) contraction, 2: load mode (rows from k_node_contract),
+// 3: static shapes, dense rows (both 16-edge row tiles of every virtual node are multiplied: branch-free main loop)
 template <int MAXD, int SHD, int MODE>
 __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
@@ -938,7 +1178,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   if (MODE == 2) { vslot[0] = stab[16 + 2 * wave]; vslot[1] = stab[17 + 2 * wave]; }
   const int H = a.HK - 1;
   const int NG8 = a.NG8;
-  const float* __restrict__ hfrag = a.Hb + ((size_t)(v0 + 2 * wave) * 2 * NG8) * 128 + 2 * lane;   // + ((vi*2 + rt)*NG8 + g)*128
+  const float* __restrict__ hfrag = a.Hb + ((size_t)(((a.dbg & 512) ? 0 : v0) + 2 * wave) * 2 * NG8) * 128 + 2 * lane;   // + ((vi*2 + rt)*NG8 + g)*128
   float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
   constexpr int NGR = MODE == 2 ? 2 : 1;   // granules per pass
@@ -986,10 +1226,19 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.w0, lr, lq);
-      if (MODE == 0) {
-        if (Gd.shape == 1) fc_mainloop<12, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
-        else if (Gd.shape == 2) fc_mainloop<3, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
-        else fc_mainloop<12, 0>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+#if FC_MANUAL
+      if (MODE == 3) {
+        const FcSlotRt sl[4] = {s0, s1, s2, s3};
+        if (Gd.shape == 1) fc_mainloop_dense<12, 3>(acc, sl, a.wpack, a.KS, NG8, wave, hfrag, ywr, yrd);
+        else if (Gd.shape == 2) fc_mainloop_dense<3, 3>(acc, sl, a.wpack, a.KS, NG8, wave, hfrag, ywr, yrd);
+        else fc_mainloop_dense<12, 0>(acc, sl, a.wpack, a.KS, NG8, wave, hfrag, ywr, yrd);
+      } else
+#endif
+      if (MODE == 0 || MODE == 3) {
+        constexpr bool DN = MODE == 3;
+        if (Gd.shape == 1) fc_mainloop<12, 3, DN>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+        else if (Gd.shape == 2) fc_mainloop<3, 3, DN>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+        else fc_mainloop<12, 0, DN>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
       } else {
       FcPre pre;
       const int shape = Gd.shape;
@@ -1170,11 +1419,13 @@ static void launch_conv_fused_t(const FusedConvArgs& a, hipStream_t s) {
     DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     lds_opt_in = true;
   }
   dim3 grid(cdiv(a.vcap, FC_VN), a.ysplit);
   if (a.Yg) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 2>), grid, dim3(64 * FC_WAVES), smem, s, a);
   else if (a.generic) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 1>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  else if (a.dense) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 3>), grid, dim3(64 * FC_WAVES), smem, s, a);
   else hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 0>), grid, dim3(64 * FC_WAVES), smem, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }

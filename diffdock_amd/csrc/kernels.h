@@ -118,6 +118,7 @@ struct FusedConvArgs {
   const FGran* gran; int ysplit; int gsplit[9];   // blockIdx.y walks granules [gsplit[y], gsplit[y+1])
   const GEntry* gmap; const float* ctab; int maxd;
   int generic;                           // some granule has no static chain shape: predicated kernel variant
+  int dense;                             // most virtual nodes hold > 16 edges: multiply both row tiles unconditionally
   float* msg;                            // [E][XS]
   int dbg = 0;
 };

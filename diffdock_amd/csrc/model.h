@@ -93,6 +93,7 @@ struct Model {
   int fused_lig = 1;        // ligand-gather groups through k_conv_fused in load mode: 1 = when a node carries >= 64 edges,
                             // 2 = always, 0 = never (k_edge_conv) -- DDMI_FUSED_LIG
   bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden
+  int fused_dense = 1;      // branch-free dense-row main loop: 0 never, 1 groups with >= 20 edges per gather node, 2 always
   int fused_ysplit = 1;     // workgroups per 16-virtual-node tile (granule ranges)
   double crop_cutoff = 0.0;  // > 0: receptor cropped to this distance from the ligand in ddmi_forward (crop_beyond)
   DevicePool cpool;

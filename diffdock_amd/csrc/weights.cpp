@@ -295,7 +295,7 @@ static void commit_conv(Model& m, ConvW& L) {
   L.qdesc = m.wpool.upload(qdesc);
   L.gmap = m.wpool.upload(gmap); L.GN = (int)gmap.size();
   // dense layers --------------------------------------------------------------------
-  // packed second layer for the node contraction: [k][path][u_pad4][w_pad16], k = H is the bias row
+  // packed second layer for the node contraction: [k][path][16-w tile][lane 64][step], k = H is the bias row
   std::vector<int> wk_off(L.table.paths.size(), 0);
   int KS = 0;
   for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
@@ -317,12 +317,14 @@ static void commit_conv(Model& m, ConvW& L) {
     std::vector<float> pack((size_t)HK * KS, 0.f);
     for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
       const TPPath& p = L.table.paths[pi];
-      const int wpad = (int)round_up(p.mul_out, 16);
+      const int steps = (int)round_up(p.mul_in, 4) / 4;
       for (int k = 0; k < HK; ++k)
         for (int u = 0; u < p.mul_in; ++u)
           for (int w = 0; w < p.mul_out; ++w) {
             const size_t slot = (size_t)p.w_off + (size_t)u * p.mul_out + w;
-            pack[(size_t)k * KS + wk_off[pi] + (size_t)u * wpad + w] = k < H ? w2.data[slot * H + k] : b2.data[slot];
+            // [16-w tile][lane = 16*(u%4) + w%16][step u/4]: the fragments of one chain are contiguous per lane
+            const size_t at = ((size_t)(w / 16) * 64 + (size_t)(u % 4) * 16 + (size_t)(w % 16)) * steps + (size_t)(u / 4);
+            pack[(size_t)k * KS + wk_off[pi] + at] = k < H ? w2.data[slot * H + k] : b2.data[slot];
           }
     }
     L.wpack.push_back(m.wpool.upload(pack));
