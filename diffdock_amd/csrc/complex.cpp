@@ -208,7 +208,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
       f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.gmap = L.gmap;
       f.ctab = L.ctab; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
-      f.dense = m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount)) ? 1 : 0;
+      f.dense = L.H % 16 == 0 && (m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount))) ? 1 : 0;
       const int ys = std::max(1, std::min(std::min(m.fused_ysplit, 8), L.n_fgran));
       f.ysplit = ys;
       f.gsplit[0] = 0;
@@ -537,8 +537,8 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
       vmax = std::max(vmax, vs.vcap);
       if (lig_v[i]) vmax_b = std::max(vmax_b, vs.vcap);
     }
-    c.Hb = HKq > 0 ? dalloc<float>(m, nullptr, {vmax, 32, HKq}) : nullptr;
-    c.Hb_b = HKq > 0 ? dalloc<float>(m, nullptr, {vmax_b, 32, HKq}) : nullptr;
+    c.Hb = HKq > 0 ? dalloc<float>(m, nullptr, {vmax, 32, round_up(HKq, 16)}) : nullptr;   // whole pairs of 8-k groups
+    c.Hb_b = HKq > 0 ? dalloc<float>(m, nullptr, {vmax_b, 32, round_up(HKq, 16)}) : nullptr;
   }
   const int ecap[4] = {c.Ell_cap, c.Elr_cap, c.Err, c.Elr_cap};
   for (int g = 0; g < 4; ++g) c.msg[g] = dalloc<float>(m, nullptr, {ecap[g], XS});

@@ -428,9 +428,14 @@ void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* 
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
-// Hidden rows of the edge MLP in virtual-node order and in the A-fragment order of k_conv_fused:
-//   Hb[v][rt][g][lane = 16q + r][sub] = relu(HE[arow] + P[tgt] + Q[d])[k = 8g + 2q + sub]   for edge row el = 16rt + r
-// (zero for k >= H and for the padding rows el >= ne), so that a wave fetches one (row tile, 8-k group) as 512 contiguous bytes.
+// Hidden rows of the edge MLP in virtual-node order and in the A-fragment order of k_conv_fused, two 8-k groups per float4:
+//   Hb[v][rt][g >> 1][lane = 16q + r][2 (g & 1) + sub] = relu(HE[arow] + P[tgt] + Q[d])[k = 8g + 2q + sub]   (edge row el = 16rt + r)
+// (zero for k >= H and for the padding rows el >= ne): a wave fetches one (row tile, PAIR of 8-k groups) as 1 KB contiguous,
+// and the MFMA first layer (k_edge_hidden_mm) writes it with one float4 per lane.
+__host__ __device__ __forceinline__ int fc_ngp(int NG8) { return (NG8 + 1) >> 1; }
+__device__ __forceinline__ size_t fc_hb_off(int v, int rt, int g, int lane, int NGP) {
+  return ((((size_t)v * 2 + rt) * NGP + (g >> 1)) * 64 + lane) * 4 + 2 * (g & 1);
+}
 __global__ __launch_bounds__(256) void k_edge_hidden(const int* __restrict__ nvn, const int* __restrict__ vn_node,
                                                     const int* __restrict__ vn_e0, const int* __restrict__ goff,
                                                     const int* __restrict__ arow, const int* __restrict__ tgt, int tbase,
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(256) void k_edge_hidden(const int* __restrict__ nvn
   if (v >= *nvn) return;
   const int d = vn_node[v], e0 = vn_e0[v];
   const int ne = min(32, goff[d + 1] - e0);
-  const int q4 = 2 * NG8;
+  const int NGP = fc_ngp(NG8), q4 = 4 * NGP;   // 4-k pieces per row, padded to whole group pairs
   for (int idx = threadIdx.x; idx < 32 * q4; idx += blockDim.x) {
     const int el = idx / q4, k = 4 * (idx - el * q4);
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -454,9 +459,8 @@ __global__ __launch_bounds__(256) void k_edge_hidden(const int* __restrict__ nvn
       o.z = fmaxf(x.z + p.z + q.z, 0.f); o.w = fmaxf(x.w + p.w + q.w, 0.f);
     }
     const int rt = el >> 4, r = el & 15, g = k >> 3, q0 = (k & 7) >> 1;
-    float* hp = Hb + ((((size_t)v * 2 + rt) * NG8 + g) * 64 + q0 * 16 + r) * 2;
-    *reinterpret_cast<float2*>(hp) = make_float2(o.x, o.y);
-    *reinterpret_cast<float2*>(hp + 32) = make_float2(o.z, o.w);
+    *reinterpret_cast<float2*>(Hb + fc_hb_off(v, rt, g, q0 * 16 + r, NGP)) = make_float2(o.x, o.y);
+    *reinterpret_cast<float2*>(Hb + fc_hb_off(v, rt, g, (q0 + 1) * 16 + r, NGP)) = make_float2(o.z, o.w);
   }
 }
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
@@ -488,34 +492,33 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
   const int lr = lane & 15, lq = lane >> 4;
   const int nvn = *a.nvn;
   if ((int)blockIdx.x * 4 >= nvn) return;
+  // Output position 4a + i of a 16-block holds hidden unit 8 (i >> 1) + 2a + (i & 1): lane (row, quarter a) then ends with
+  // k = 8g + 2a + {0, 1} of BOTH 8-k groups g = 2nb, 2nb + 1 -- the float4 of fragment lane 16a + row.
   for (int idx = tid; idx < H * 4 * KS; idx += 256) {   // k fastest: coalesced reads of the weight rows
     const int k = idx % (4 * KS), n = idx / (4 * KS);
     const int q = k / KS, t = k - q * KS;
-    wl[(t * 4 + q) * H + n] = a.W1[(size_t)n * a.ldw + k];
+    const int pos = n & 15, unit = (n & ~15) + 8 * ((pos & 3) >> 1) + 2 * (pos >> 2) + (pos & 1);
+    wl[(t * 4 + q) * H + n] = a.W1[(size_t)unit * a.ldw + k];
   }
   __syncthreads();
   for (int v = blockIdx.x * 4 + wave; v < nvn; v += gridDim.x * 4) {
     const int d = a.vn_node[v], e0 = a.vn_e0[v];
     const int ne = min(32, a.goff[d + 1] - e0);
-    const float* __restrict__ qrow = a.Q + (size_t)d * H + 4 * lq;
+    const float* __restrict__ qrow = a.Q + (size_t)d * H + 2 * lq;
     const float* __restrict__ rbrow = nullptr;
-    if (a.rowbias && ne > 0) rbrow = a.rowbias + (size_t)a.ridx[a.arow ? a.arow[e0] : e0] * H + 4 * lq;
+    if (a.rowbias && ne > 0) rbrow = a.rowbias + (size_t)a.ridx[a.arow ? a.arow[e0] : e0] * H + 2 * lq;
 #pragma unroll 1
     for (int rt = 0; rt < 2; ++rt) {
-      // lane (row lr, q) owns hidden k = 16nb + 4q + {0..3}: group g = 2nb + (q >> 1), fragment lanes 16(2(q&1) + {0,1}) + row
-      float* __restrict__ hp = a.Hb + (((size_t)v * 2 + rt) * NG8 + (lq >> 1)) * 128 + (32 * (lq & 1) + lr) * 2;
+      float* __restrict__ hp = a.Hb + fc_hb_off(v, rt, 0, lane, NG8 / 2);   // + 256 per pair of 8-k groups
       const int el = 16 * rt + lr;
       const bool live = el < ne;
       if (16 * rt >= ne) {   // empty row tile: zero fragments
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          *reinterpret_cast<float2*>(hp + (size_t)nb * 256) = make_float2(0.f, 0.f);
-          *reinterpret_cast<float2*>(hp + (size_t)nb * 256 + 32) = make_float2(0.f, 0.f);
-        }
+        for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<float4*>(hp + (size_t)nb * 256) = make_float4(0.f, 0.f, 0.f, 0.f);
         continue;
       }
       float4 ae[NSQ];
-      const float* __restrict__ prow = a.P + 4 * lq;
+      const float* __restrict__ prow = a.P + 2 * lq;
       if (live) {
         const int e = e0 + el;
         const int ar = a.arow ? a.arow[e] : e;
@@ -529,9 +532,13 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        float4 pq = *reinterpret_cast<const float4*>(qrow + 16 * nb);
-        if (rbrow) { const float4 t = *reinterpret_cast<const float4*>(rbrow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
-        if (live) { const float4 t = *reinterpret_cast<const float4*>(prow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
+        auto ld22 = [](const float* __restrict__ p) __attribute__((always_inline)) {   // units 2a + {0,1} and 8 + 2a + {0,1}
+          const float2 u = *reinterpret_cast<const float2*>(p), w = *reinterpret_cast<const float2*>(p + 8);
+          return make_float4(u.x, u.y, w.x, w.y);
+        };
+        float4 pq = ld22(qrow + 16 * nb);
+        if (rbrow) { const float4 t = ld22(rbrow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
+        if (live) { const float4 t = ld22(prow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
         f32x4 acc = f32x4{pq.x, pq.y, pq.z, pq.w}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: a dependent f32 MFMA waits 40 cycles
         const float* __restrict__ wp = wl + lq * H + 16 * nb + lr;
 #pragma unroll
@@ -541,13 +548,12 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 2) * 4 * H], ae[j].z, acc, 0, 0, 0);
           acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 3) * 4 * H], ae[j].w, acc2, 0, 0, 0);
         }
-        float2 o0 = make_float2(0.f, 0.f), o1 = o0;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) {
-          o0.x = fmaxf(acc[0] + acc2[0], 0.f); o0.y = fmaxf(acc[1] + acc2[1], 0.f);
-          o1.x = fmaxf(acc[2] + acc2[2], 0.f); o1.y = fmaxf(acc[3] + acc2[3], 0.f);
+          o.x = fmaxf(acc[0] + acc2[0], 0.f); o.y = fmaxf(acc[1] + acc2[1], 0.f);
+          o.z = fmaxf(acc[2] + acc2[2], 0.f); o.w = fmaxf(acc[3] + acc2[3], 0.f);
         }
-        *reinterpret_cast<float2*>(hp + (size_t)nb * 256) = o0;
-        *reinterpret_cast<float2*>(hp + (size_t)nb * 256 + 32) = o1;
+        *reinterpret_cast<float4*>(hp + (size_t)nb * 256) = o;
       }
     }
   }
@@ -730,6 +736,8 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
   float2 hC[2][2], hN[2][2];
   const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
   const float* __restrict__ hp = hfrag;
+  const size_t rts = (size_t)fc_ngp(NG8) * 256;   // row-tile stride of the hidden rows
+  int hg = 0;
 #ifdef FC_HB_NT
 #define FC_LDH(p) fc_ld2nt(p)
 #else
@@ -738,10 +746,10 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
 #define FC_LOADH(dst)                                                                    \
   do {                                                                                   \
     dst[0][0] = FC_LDH(hp);                                                              \
-    dst[0][1] = (DENSE || two0) ? FC_LDH(hp + (size_t)NG8 * 128) : make_float2(0.f, 0.f);     \
-    dst[1][0] = FC_LDH(hp + (size_t)2 * NG8 * 128);                                      \
-    dst[1][1] = (DENSE || two1) ? FC_LDH(hp + (size_t)3 * NG8 * 128) : make_float2(0.f, 0.f); \
-    hp += 128;                                                                           \
+    dst[0][1] = (DENSE || two0) ? FC_LDH(hp + rts) : make_float2(0.f, 0.f);              \
+    dst[1][0] = FC_LDH(hp + 2 * rts);                                                    \
+    dst[1][1] = (DENSE || two1) ? FC_LDH(hp + 3 * rts) : make_float2(0.f, 0.f);          \
+    hp += (hg & 1) ? 254 : 2; ++hg;   /* second half of the float4, then the next pair of groups */ \
   } while (0)
 #define FC_EDGE_GEMM(buf)                                                                \
   do {                                                                                   \
@@ -893,10 +901,11 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
       bw[t][0] = v.a; bw[t][1] = v.b; bw[t][2] = v.c;
     }
   };
-  float2 hC[2][2], hN[2][2];
+  float4 hC[2][2], hN[2][2];   // hidden-row fragments of the current / next PAIR of chunks: [virtual node][row tile]
   const float* __restrict__ hp = hfrag;
-  auto loadh = [&](float2 (&dst)[2][2], int piece) __attribute__((always_inline)) {
-    dst[piece >> 1][piece & 1] = *reinterpret_cast<const float2*>(hp + (size_t)piece * NG8 * 128);
+  const size_t rts = (size_t)(NG8 >> 1) * 256;
+  auto loadh = [&](float4 (&dst)[2][2], int piece) __attribute__((always_inline)) {
+    dst[piece >> 1][piece & 1] = *reinterpret_cast<const float4*>(hp + (size_t)piece * rts);
   };
   f32x4 r[4];
   float q[2][4];               // B fragments of the edge product: [parity of the (virtual node, k pair) group][column block]
@@ -910,10 +919,11 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
     yw[rr * FC_YVN + 16 * (2 * h)] = r[2 * h][rr];
     yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
   };
-  // one chunk step: contraction of chunk g+1 into buffer cb (DO_C), weight requests for chunk g+2 (DO_W), hidden rows of
-  // chunk g+1 (DO_H), edge product of chunk g out of buffer eb
-  auto step = [&](auto do_c, auto do_w, auto do_h, int cb, int eb) __attribute__((always_inline)) {
+  // one chunk step (chunk g = 2 * pair + ODD): contraction of chunk g+1 into buffer ODD ^ 1 (DO_C), weight requests for
+  // chunk g+2 (DO_W), hidden rows of the next pair of chunks (DO_H), edge product of chunk g out of buffer ODD
+  auto step = [&](auto do_c, auto do_w, auto do_h, auto odd) __attribute__((always_inline)) {
     constexpr bool DO_C = decltype(do_c)::value, DO_W = decltype(do_w)::value, DO_H = decltype(do_h)::value;
+    constexpr int ODD = decltype(odd)::value, eb = ODD, cb = ODD ^ 1;
     if constexpr (DO_C) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -921,9 +931,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
         constexpr int i = decltype(ic)::value;
         constexpr int t = O::slot(i);
         r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[t][O::step(i)], r[t], 0, 0, 0);
-#ifndef FC_EXP_NOH
         if constexpr (DO_H) { if (i < 4) loadh(hN, i); }
-#endif
         if (i == NC - 3) readq(0, eb, 0);
         DDMI_SCHED_FENCE();
       });
@@ -933,34 +941,36 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
     fc_sfor<0, 32>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       constexpr int grp = m >> 3, t8 = m & 7, vi = grp >> 1, sub = grp & 1, rt = t8 >> 2, c = t8 & 3;
-      const float av = sub == 0 ? hC[vi][rt].x : hC[vi][rt].y;
+      const float av = ODD ? (sub == 0 ? hC[vi][rt].z : hC[vi][rt].w) : (sub == 0 ? hC[vi][rt].x : hC[vi][rt].y);
       acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
-#ifndef FC_EXP_NOW
       if constexpr (DO_W) { if constexpr (m % 2 == 0 && m / 2 < NL) loadw(std::integral_constant<int, m / 2>{}); }
-#endif
-#ifndef FC_EXP_NOST
       if constexpr (DO_C) { if (m >= 2 && m < 10) store_piece(cb, m - 2); }
-#endif
-#ifndef FC_EXP_NORD
       if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
-#endif
       DDMI_SCHED_FENCE();
     });
     if constexpr (DO_W) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) woff[t] += gstep;
     }
-    if constexpr (DO_H) hp += 128;
+    if constexpr (DO_H) hp += 256;
+  };
+  auto roll = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
   };
   using T = std::true_type;
   using F = std::false_type;
-  // prologue: chunk 0 contracted, chunk 1 requested
+  using Even = std::integral_constant<int, 0>;
+  using Odd = std::integral_constant<int, 1>;
+  // prologue: chunk 0 contracted, chunk 1 requested  (NG8 is even and >= 2 here: the host selects this loop for H % 16 == 0)
   fc_sfor<0, NL>(loadw);
 #pragma unroll
   for (int t = 0; t < 4; ++t) woff[t] += gstep;
 #pragma unroll
   for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
-  hp += 128;
+  hp += 256;
 #pragma unroll
   for (int t = 0; t < 4; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   fc_sfor<0, NC>([&](auto ic) {
@@ -970,33 +980,20 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
   });
 #pragma unroll
   for (int pc = 0; pc < 8; ++pc) store_piece(0, pc);
-  if (NG8 > 1) {
-    fc_sfor<0, NL>(loadw);
+  fc_sfor<0, NL>(loadw);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) woff[t] += gstep;
-  }
+  for (int t = 0; t < 4; ++t) woff[t] += gstep;
   __syncthreads();
-  int g = 0;
-  for (; g + 2 < NG8; ++g) {
-    step(T{}, T{}, T{}, (g + 1) & 1, g & 1);
-#ifndef FC_EXP_NOBAR
+  for (int g = 0; g + 2 < NG8; g += 2) {   // pairs with a successor pair
+    step(T{}, T{}, T{}, Even{});
     __syncthreads();
-#endif
-#pragma unroll
-    for (int vi = 0; vi < 2; ++vi)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
-  }
-  if (g + 1 < NG8) {
-    step(T{}, F{}, T{}, (g + 1) & 1, g & 1);
+    step(T{}, T{}, F{}, Odd{});
     __syncthreads();
-#pragma unroll
-    for (int vi = 0; vi < 2; ++vi)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
-    ++g;
+    roll();
   }
-  step(F{}, F{}, F{}, 0, g & 1);
+  step(T{}, F{}, F{}, Even{});             // last pair: one contraction left, nothing to request
+  __syncthreads();
+  step(F{}, F{}, F{}, Odd{});
   __syncthreads();
 }
 
@@ -1033,13 +1030,15 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const
   float2 hC[2][2], hN[2][2];
   const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
   const float* __restrict__ hp = hfrag;
+  const size_t rts = (size_t)fc_ngp(NG8) * 256;
+  int hg = 0;
 #define FC_LOADH(dst_)                                                                   \
   do {                                                                                   \
     dst_[0][0] = *reinterpret_cast<const float2*>(hp);                                   \
-    dst_[0][1] = two0 ? *reinterpret_cast<const float2*>(hp + (size_t)NG8 * 128) : make_float2(0.f, 0.f);     \
-    dst_[1][0] = *reinterpret_cast<const float2*>(hp + (size_t)2 * NG8 * 128);           \
-    dst_[1][1] = two1 ? *reinterpret_cast<const float2*>(hp + (size_t)3 * NG8 * 128) : make_float2(0.f, 0.f); \
-    hp += 128;                                                                           \
+    dst_[0][1] = two0 ? *reinterpret_cast<const float2*>(hp + rts) : make_float2(0.f, 0.f);     \
+    dst_[1][0] = *reinterpret_cast<const float2*>(hp + 2 * rts);                         \
+    dst_[1][1] = two1 ? *reinterpret_cast<const float2*>(hp + 3 * rts) : make_float2(0.f, 0.f); \
+    hp += (hg & 1) ? 254 : 2; ++hg;                                                      \
   } while (0)
   FC_FETCHY(0);
   FC_LOADH(hC);
@@ -1178,7 +1177,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   if (MODE == 2) { vslot[0] = stab[16 + 2 * wave]; vslot[1] = stab[17 + 2 * wave]; }
   const int H = a.HK - 1;
   const int NG8 = a.NG8;
-  const float* __restrict__ hfrag = a.Hb + ((size_t)(((a.dbg & 512) ? 0 : v0) + 2 * wave) * 2 * NG8) * 128 + 2 * lane;   // + ((vi*2 + rt)*NG8 + g)*128
+  const float* __restrict__ hfrag = a.Hb + fc_hb_off(((a.dbg & 512) ? 0 : v0) + 2 * wave, 0, 0, lane, fc_ngp(NG8));   // + fc_hb_off(vi, rt, g, 0)
   float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
   constexpr int NGR = MODE == 2 ? 2 : 1;   // granules per pass
@@ -1292,7 +1291,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
           for (int rt = 0; rt < 2; ++rt) {
             hA[vi][rt] = make_float2(0.f, 0.f);
             if (g < NG8 && vne[vi] > 16 * rt)
-              hA[vi][rt] = *reinterpret_cast<const float2*>(hfrag + ((size_t)(vi * 2 + rt) * NG8 + g) * 128);
+              hA[vi][rt] = *reinterpret_cast<const float2*>(hfrag + fc_hb_off(vi, rt, g, 0, fc_ngp(NG8)));
           }
       };
       float2 hC[2][2], hN[2][2];
