@@ -1027,61 +1027,64 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const
     _Pragma("unroll") for (int p = 0; p < 4; ++p)                                         \
       if (on[p]) *reinterpret_cast<float4*>(dst + (buf) * FC_YB + 2 * p * FC_YVN) = yq[p]; \
   } while (0)
-  float2 hC[2][2], hN[2][2];
+  float4 hC[2][2], hN[2][2];   // hidden-row fragments of the current / next pair of 8-k groups
   const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
   const float* __restrict__ hp = hfrag;
   const size_t rts = (size_t)fc_ngp(NG8) * 256;
-  int hg = 0;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define FC_LOADH(dst_)                                                                   \
   do {                                                                                   \
-    dst_[0][0] = *reinterpret_cast<const float2*>(hp);                                   \
-    dst_[0][1] = two0 ? *reinterpret_cast<const float2*>(hp + rts) : make_float2(0.f, 0.f);     \
-    dst_[1][0] = *reinterpret_cast<const float2*>(hp + 2 * rts);                         \
-    dst_[1][1] = two1 ? *reinterpret_cast<const float2*>(hp + 3 * rts) : make_float2(0.f, 0.f); \
-    hp += (hg & 1) ? 254 : 2; ++hg;                                                      \
+    dst_[0][0] = *reinterpret_cast<const float4*>(hp);                                   \
+    dst_[0][1] = two0 ? *reinterpret_cast<const float4*>(hp + rts) : z4;                 \
+    dst_[1][0] = *reinterpret_cast<const float4*>(hp + 2 * rts);                         \
+    dst_[1][1] = two1 ? *reinterpret_cast<const float4*>(hp + 3 * rts) : z4;             \
+    hp += 256;                                                                           \
+  } while (0)
+#define FC_LOAD_STEP(g_, ODD_)                                                           \
+  do {                                                                                   \
+    if ((g_) + 1 < NG8) {                                                                \
+      FC_STOREY(((g_) + 1) & 1);                                                         \
+      if ((g_) + 2 < NG8) FC_FETCHY((g_) + 2);                                           \
+      if (!(ODD_) && (g_) + 2 < NG8) FC_LOADH(hN);                                       \
+    }                                                                                    \
+    const float* __restrict__ yb0 = ybuf + ((g_) & 1) * FC_YB + (2 * lq) * FC_YROW + lr; \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                      \
+      if (u >= ng) break;                                                                \
+      _Pragma("unroll") for (int vi = 0; vi < 2; ++vi) {                                 \
+        _Pragma("unroll") for (int sub = 0; sub < 2; ++sub) {                            \
+          const float* __restrict__ yb = yb0 + (u * 8 + vslot[vi]) * FC_YVN + sub * FC_YROW; \
+          const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];                 \
+          const float a0 = (ODD_) ? (sub == 0 ? hC[vi][0].z : hC[vi][0].w) : (sub == 0 ? hC[vi][0].x : hC[vi][0].y); \
+          acc[u][vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[u][vi][0][0], 0, 0, 0); \
+          acc[u][vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[u][vi][0][1], 0, 0, 0); \
+          acc[u][vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[u][vi][0][2], 0, 0, 0); \
+          acc[u][vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[u][vi][0][3], 0, 0, 0); \
+          if (vi == 0 ? two0 : two1) {                                                   \
+            const float a1 = (ODD_) ? (sub == 0 ? hC[vi][1].z : hC[vi][1].w) : (sub == 0 ? hC[vi][1].x : hC[vi][1].y); \
+            acc[u][vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[u][vi][1][0], 0, 0, 0); \
+            acc[u][vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[u][vi][1][1], 0, 0, 0); \
+            acc[u][vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[u][vi][1][2], 0, 0, 0); \
+            acc[u][vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[u][vi][1][3], 0, 0, 0); \
+          }                                                                              \
+        }                                                                                \
+      }                                                                                  \
+    }                                                                                    \
+    __syncthreads();                                                                     \
   } while (0)
   FC_FETCHY(0);
   FC_LOADH(hC);
   FC_STOREY(0);
   if (NG8 > 1) FC_FETCHY(1);
   __syncthreads();
-  for (int g = 0; g < NG8; ++g) {
-    if (g + 1 < NG8) {
-      FC_STOREY((g + 1) & 1);
-      if (g + 2 < NG8) FC_FETCHY(g + 2);
-      FC_LOADH(hN);
-    }
-    const float* __restrict__ yb0 = ybuf + (g & 1) * FC_YB + (2 * lq) * FC_YROW + lr;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (u >= ng) break;
-#pragma unroll
-      for (int vi = 0; vi < 2; ++vi) {
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-          const float* __restrict__ yb = yb0 + (u * 8 + vslot[vi]) * FC_YVN + sub * FC_YROW;
-          const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];
-          const float a0 = sub == 0 ? hC[vi][0].x : hC[vi][0].y;
-          acc[u][vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[u][vi][0][0], 0, 0, 0);
-          acc[u][vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[u][vi][0][1], 0, 0, 0);
-          acc[u][vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[u][vi][0][2], 0, 0, 0);
-          acc[u][vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[u][vi][0][3], 0, 0, 0);
-          if (vi == 0 ? two0 : two1) {
-            const float a1 = sub == 0 ? hC[vi][1].x : hC[vi][1].y;
-            acc[u][vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[u][vi][1][0], 0, 0, 0);
-            acc[u][vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[u][vi][1][1], 0, 0, 0);
-            acc[u][vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[u][vi][1][2], 0, 0, 0);
-            acc[u][vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[u][vi][1][3], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();
+  for (int g = 0; g < NG8; g += 2) {
+    FC_LOAD_STEP(g, 0);
+    if (g + 1 < NG8) FC_LOAD_STEP(g + 1, 1);
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
   }
+#undef FC_LOAD_STEP
 #undef FC_FETCHY
 #undef FC_STOREY
 #undef FC_LOADH
