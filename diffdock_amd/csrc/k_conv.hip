@@ -908,16 +908,19 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
     dst[piece >> 1][piece & 1] = *reinterpret_cast<const float4*>(hp + (size_t)piece * rts);
   };
   f32x4 r[4];
-  float q[2][4];               // B fragments of the edge product: [parity of the (virtual node, k pair) group][column block]
+  // live 16-column blocks of the granule: a (12,-,-,-) granule (one item column) multiplies only block 0 in the edge product
+  constexpr int NCB = SN == 0 ? 1 : 4, NE = 8 * NCB, NP = SN == 0 ? 4 : 8;
+  float q[2][NCB];             // B fragments of the edge product: [parity of the (virtual node, k pair) group][column block]
   auto readq = [&](int par, int buf, int grp) __attribute__((always_inline)) {
     const float* __restrict__ yb = yrd + buf * FC_YB + (grp >> 1) * FC_YVN + (grp & 1) * FC_YROW;
-    q[par][0] = yb[0]; q[par][1] = yb[16]; q[par][2] = yb[32]; q[par][3] = yb[48];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) q[par][c] = yb[16 * c];
   };
   auto store_piece = [&](int buf, int piece) __attribute__((always_inline)) {   // rows of node quarter `rr`, slots 2h and 2h+1
     float* yw = ywr + buf * FC_YB;
     const int rr = piece & 3, h = piece >> 2;
     yw[rr * FC_YVN + 16 * (2 * h)] = r[2 * h][rr];
-    yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
+    if (SN > 0) yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
   };
   // one chunk step (chunk g = 2 * pair + ODD): contraction of chunk g+1 into buffer ODD ^ 1 (DO_C), weight requests for
   // chunk g+2 (DO_W), hidden rows of the next pair of chunks (DO_H), edge product of chunk g out of buffer ODD
@@ -938,13 +941,14 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
     } else {
       readq(0, eb, 0);
     }
-    fc_sfor<0, 32>([&](auto mc) {
+    static_assert(NE >= 2 * NL && NE >= NP + 2, "edge-product slots for the weight requests and the row stores");
+    fc_sfor<0, NE>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      constexpr int grp = m >> 3, t8 = m & 7, vi = grp >> 1, sub = grp & 1, rt = t8 >> 2, c = t8 & 3;
+      constexpr int grp = m / (2 * NCB), t8 = m % (2 * NCB), vi = grp >> 1, sub = grp & 1, rt = t8 / NCB, c = t8 % NCB;
       const float av = ODD ? (sub == 0 ? hC[vi][rt].z : hC[vi][rt].w) : (sub == 0 ? hC[vi][rt].x : hC[vi][rt].y);
       acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
       if constexpr (DO_W) { if constexpr (m % 2 == 0 && m / 2 < NL) loadw(std::integral_constant<int, m / 2>{}); }
-      if constexpr (DO_C) { if (m >= 2 && m < 10) store_piece(cb, m - 2); }
+      if constexpr (DO_C) { if (m >= 2 && m < 2 + NP) store_piece(cb, m - 2); }
       if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
       DDMI_SCHED_FENCE();
     });
@@ -979,7 +983,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
     r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[t][O::step(i)], r[t], 0, 0, 0);
   });
 #pragma unroll
-  for (int pc = 0; pc < 8; ++pc) store_piece(0, pc);
+  for (int pc = 0; pc < NP; ++pc) store_piece(0, pc);
   fc_sfor<0, NL>(loadw);
 #pragma unroll
   for (int t = 0; t < 4; ++t) woff[t] += gstep;
