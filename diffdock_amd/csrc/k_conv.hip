@@ -1105,10 +1105,10 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const
 template <int MAXD, int SHD, int MODE>
 __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
-  constexpr int GS2 = 4 * MAXD + 1, ES = SHD + 3, CGN = 4 * MAXD * SHD;
+  constexpr int GS2 = 4 * MAXD + 8, ES = SHD + 3, CGN = 4 * MAXD * SHD;
   float* xbuf = smem;                                  // [16][XS+1]
   float* ybuf = xbuf + FC_VN * NC_XS;                  // [2][16 x FC_YVN]
-  float* gscr = ybuf + 2 * FC_YB;                      // per wave: [32][GS2] coupling rows of the current (granule, virtual node)
+  float* gscr = ybuf + 2 * FC_YB;                      // per wave: [32 edge rows][MAXD][4 slots] (+8 pad) coupling rows of the current (granule, virtual node)
   float* escr = gscr + FC_WAVES * 32 * GS2;            // per wave: [2][32][ES] edge rows: sh (SHD), weight, message row
   float* cgt = escr + FC_WAVES * 2 * 32 * ES;          // [granules of this workgroup][4 slots][MAXD][SHD] dense coupling rows
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1359,15 +1359,14 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 #pragma unroll
         for (int j = 0; j < SHD; ++j) sh[j] = erow[el * ES + j];
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-          const int sl = 2 * half + ss;
+        for (int k = 0; k < MAXD; ++k) {
+          float2 v = make_float2(0.f, 0.f);
 #pragma unroll
-          for (int k = 0; k < MAXD; ++k) {
-            float v = 0.f;
-#pragma unroll
-            for (int j = 0; j < SHD; ++j) v = fmaf(cg[(sl * MAXD + k) * SHD + j], sh[j], v);
-            gw[el * GS2 + sl * MAXD + k] = v;
+          for (int j = 0; j < SHD; ++j) {
+            v.x = fmaf(cg[((2 * half) * MAXD + k) * SHD + j], sh[j], v.x);
+            v.y = fmaf(cg[((2 * half + 1) * MAXD + k) * SHD + j], sh[j], v.y);
           }
+          *reinterpret_cast<float2*>(gw + el * GS2 + 4 * k + 2 * half) = v;   // the four slots of (row, k') side by side
         }
       }
       DDMI_WAVE_SYNC();
@@ -1387,10 +1386,11 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 #pragma unroll
             for (int k = 0; k < MAXD; ++k) {
               if (k < Gd.dout) {
-                float v = G[k] * t0;
-                v = fmaf(G[MAXD + k], t1, v);
-                v = fmaf(G[2 * MAXD + k], t2, v);
-                v = fmaf(G[3 * MAXD + k], t3, v);
+                const float4 g4 = *reinterpret_cast<const float4*>(G + 4 * k);
+                float v = g4.x * t0;
+                v = fmaf(g4.y, t1, v);
+                v = fmaf(g4.z, t2, v);
+                v = fmaf(g4.w, t3, v);
                 stg[row * RS + lr * Gd.dout + k] = v * we;
               }
             }
@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 
 template <int MAXD, int SHD>
 static void launch_conv_fused_t(const FusedConvArgs& a, hipStream_t s) {
-  constexpr int GS2 = 4 * MAXD + 1, ES = SHD + 3, CGN = 4 * MAXD * SHD;
+  constexpr int GS2 = 4 * MAXD + 8, ES = SHD + 3, CGN = 4 * MAXD * SHD;
   int max_local = 0;
   for (int y = 0; y < a.ysplit; ++y) max_local = std::max(max_local, a.gsplit[y + 1] - a.gsplit[y]);
   const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FC_YB + FC_WAVES * 32 * GS2 + FC_WAVES * 2 * 32 * ES + max_local * CGN) * sizeof(float);
