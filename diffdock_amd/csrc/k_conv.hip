@@ -1446,14 +1446,19 @@ void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------- reduce + BN
-__global__ __launch_bounds__(192) void k_reduce_bn(const ReduceGroup* __restrict__ groups, int n_groups, int nbase,
+// One workgroup per target node, 4 waves: wave w sums the message rows b + w, b + w + 4, ... of every group, a lane 4
+// consecutive columns (one 16-B streaming load per row and lane, several rows in flight); the four partial rows meet in LDS.
+__global__ __launch_bounds__(256) void k_reduce_bn(const ReduceGroup* __restrict__ groups, int n_groups, int nbase,
                                                    int D_in, int D_out, const float* __restrict__ bn_mean,
                                                    const float* __restrict__ bn_scale, const float* __restrict__ bn_bias,
                                                    int residual, const float* __restrict__ X_in,
                                                    float* __restrict__ X_out, int out_stride) {
+  __shared__ float red[4][XS + 4];
   const int s = nbase + blockIdx.x;
-  const int c = threadIdx.x;
-  float acc = 0.f;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = DDMI_UNIFORM(tid >> 6);
+  const bool live = 4 * lane < D_out;      // columns past D_out inside the XS-wide row are never used
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int cnt = 0;
   for (int g = 0; g < n_groups; ++g) {
     const ReduceGroup G = groups[g];
@@ -1461,13 +1466,31 @@ __global__ __launch_bounds__(192) void k_reduce_bn(const ReduceGroup* __restrict
     if (sl < 0 || sl >= G.tcount) continue;
     const int b = G.toff[sl], e = G.toff[sl + 1];
     cnt += e - b;
-    if (c < D_out)
-      for (int r = b; r < e; ++r) acc += DDMI_NT_LOAD(G.msg + (size_t)r * XS + c);
+    if (live) {
+      const float* __restrict__ mp = G.msg + 4 * lane;
+      int r = b + wave;
+      for (; r + 12 < e; r += 16) {
+        const float4 v0 = nt_load4(mp + (size_t)r * XS), v1 = nt_load4(mp + (size_t)(r + 4) * XS);
+        const float4 v2 = nt_load4(mp + (size_t)(r + 8) * XS), v3 = nt_load4(mp + (size_t)(r + 12) * XS);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;   // same order as the one-row-at-a-time tail
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+      }
+      for (; r < e; r += 4) {
+        const float4 v0 = nt_load4(mp + (size_t)r * XS);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      }
+    }
   }
+  if (4 * lane < XS) *reinterpret_cast<float4*>(&red[wave][4 * lane]) = acc;
+  __syncthreads();
+  const int c = tid;
   if (c >= out_stride) return;
   float v = 0.f;
   if (c < D_out) {
-    v = cnt > 0 ? acc / (float)cnt : 0.f;
+    const float sum = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    v = cnt > 0 ? sum / (float)cnt : 0.f;
     if (bn_scale) v = (v - bn_mean[c]) * bn_scale[c] + bn_bias[c];
     if (residual && c < D_in) v += X_in[(size_t)s * XS + c];
   }
@@ -1478,7 +1501,7 @@ void launch_reduce_bn(const ReduceGroup* groups_dev, int n_groups, int nbase, in
                       const float* bn_mean, const float* bn_scale, const float* bn_bias, int residual,
                       const float* X_in, float* X_out, int out_stride, hipStream_t s) {
   if (ncount <= 0) return;
-  hipLaunchKernelGGL(k_reduce_bn, dim3(ncount), dim3(192), 0, s, groups_dev, n_groups, nbase, D_in, D_out, bn_mean,
+  hipLaunchKernelGGL(k_reduce_bn, dim3(ncount), dim3(256), 0, s, groups_dev, n_groups, nbase, D_in, D_out, bn_mean,
                      bn_scale, bn_bias, residual, X_in, X_out, out_stride);
   DDMI_CHECK_HIP(hipGetLastError());
 }
