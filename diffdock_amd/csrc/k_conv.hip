@@ -846,6 +846,39 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
 // requests of chunk g+1 and the first B-fragment reads of chunk g between them), then the 32 edge MFMAs of chunk g with,
 // one per MFMA, the NC weight-fragment requests of chunk g+2 (uniform base + 32-bit lane offset), the 8 paired LDS stores
 // of the rows just contracted and the B-fragment reads of the next (virtual node, k pair).  sched_barrier fences pin it.
+// Uniform-base requests (buffer resource in SGPRs + 32-bit lane offset + SGPR offset): no per-request 64-bit address
+// arithmetic in the vector ALU and no address registers -- the dense main loop issues one such request per MFMA shadow.
+#ifdef DDMI_HIPEMU
+struct FcBuf { const char* p; };
+__device__ __forceinline__ FcBuf fc_buf(const void* p, unsigned) { return FcBuf{reinterpret_cast<const char*>(p)}; }
+__device__ __forceinline__ float4 fc_buf_ld4(const FcBuf& b, unsigned voff, unsigned soff) {
+  return *reinterpret_cast<const float4*>(b.p + voff + soff);
+}
+__device__ __forceinline__ float3 fc_buf_ld3(const FcBuf& b, unsigned voff, unsigned soff) {
+  const float* q = reinterpret_cast<const float*>(b.p + voff + soff);
+  return make_float3(q[0], q[1], q[2]);
+}
+#else
+// (declared by name: the __builtin_amdgcn_raw_buffer_load_b128 of this toolchain is lowered to a one-dword load)
+typedef int fc_i32x4 __attribute__((ext_vector_type(4)));
+typedef float fc_f32x3 __attribute__((ext_vector_type(3)));
+__device__ f32x4 fc_raw_buffer_load_x4(fc_i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ fc_f32x3 fc_raw_buffer_load_x3(fc_i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v3f32");
+struct FcBuf { fc_i32x4 r; };
+__device__ __forceinline__ FcBuf fc_buf(const void* p, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const int lo = DDMI_UNIFORM((int)(unsigned)a), hi = DDMI_UNIFORM((int)((a >> 32) & 0xffffu));
+  return FcBuf{fc_i32x4{lo, hi, (int)bytes, 0x00020000}};   // base, stride 0, bytes, raw dwords (gfx9 family)
+}
+__device__ __forceinline__ float4 fc_buf_ld4(const FcBuf& b, unsigned voff, unsigned soff) {
+  const f32x4 v = fc_raw_buffer_load_x4(b.r, (int)voff, (int)soff, 0);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float3 fc_buf_ld3(const FcBuf& b, unsigned voff, unsigned soff) {
+  const fc_f32x3 v = fc_raw_buffer_load_x3(b.r, (int)voff, (int)soff, 0);
+  return make_float3(v[0], v[1], v[2]);
+}
+#endif
 template <int I, int N, class F>
 __device__ __forceinline__ void fc_sfor(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); fc_sfor<I + 1, N>(f); }
@@ -866,8 +899,8 @@ struct FcOrder {   // issue order of the four slot chains: slot 0 alternating wi
 };
 template <int S0, int SN>
 __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
-                                                  int KS, int NG8, int wave, const float* __restrict__ hfrag, float* ywr,
-                                                  const float* yrd) {
+                                                  int KS, int HK, int NG8, int wave, int lane,
+                                                  const float* __restrict__ hb_tile, float* ywr, const float* yrd) {
   using O = FcOrder<S0, SN>;
   constexpr int NC = O::NC;
   float xa[NC];
@@ -876,36 +909,37 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
     constexpr int i = decltype(ic)::value;
     xa[i] = sl[O::slot(i)].xp[O::step(i) * sl[O::slot(i)].xstride];
   });
-  int woff[4];                 // uniform: row k = 8g + wave of each slot's packed weights
+  unsigned woff[4];            // uniform byte offset of row k = 8g + wave of each slot's packed weights
   unsigned lo[4];              // per-lane byte offset of the lane's run of fragments
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    woff[t] = DDMI_UNIFORM((int)(sl[t].wb - wpack) + wave * KS);
+    woff[t] = (unsigned)DDMI_UNIFORM((int)(sl[t].wb - wpack) + wave * KS) * 4u;
     lo[t] = (unsigned)sl[t].loff * 4u;
   }
-  const int gstep = 8 * KS;
+  const unsigned gstep = 32u * (unsigned)KS;
+  const FcBuf wbuf = fc_buf(wpack, (unsigned)HK * (unsigned)KS * 4u);
   // vector requests: slot 0 in pieces of 4 steps (or one piece of 3), slots 1..3 one piece of 3 each
   constexpr int NL0 = S0 >= 4 ? S0 / 4 : (S0 > 0 ? 1 : 0), NL = NL0 + (SN > 0 ? 3 : 0);
   static_assert(S0 % 4 == 0 || S0 == 3, "slot-0 chains are whole 4-step pieces or one 3-step piece");
   static_assert(SN == 0 || SN == 3, "slots 1..3 hold 3-step chains");
-  struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
   auto loadw = [&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     constexpr int t = i < NL0 ? 0 : 1 + (i - NL0);
-    const char* __restrict__ ub = reinterpret_cast<const char*>(wpack + woff[t]) + lo[t];
     if constexpr (t == 0 && S0 >= 4) {
-      const float4 v = *reinterpret_cast<const float4*>(ub + 16 * i);
+      const float4 v = fc_buf_ld4(wbuf, lo[0] + 16u * i, woff[0]);
       bw[0][4 * i] = v.x; bw[0][4 * i + 1] = v.y; bw[0][4 * i + 2] = v.z; bw[0][4 * i + 3] = v.w;
     } else {
-      const F3 v = *reinterpret_cast<const F3*>(ub);
-      bw[t][0] = v.a; bw[t][1] = v.b; bw[t][2] = v.c;
+      const float3 v = fc_buf_ld3(wbuf, lo[t], woff[t]);
+      bw[t][0] = v.x; bw[t][1] = v.y; bw[t][2] = v.z;
     }
   };
   float4 hC[2][2], hN[2][2];   // hidden-row fragments of the current / next PAIR of chunks: [virtual node][row tile]
-  const float* __restrict__ hp = hfrag;
-  const size_t rts = (size_t)(NG8 >> 1) * 256;
+  const unsigned rts = (unsigned)(NG8 >> 1) * 1024u;                     // bytes per (virtual node, row tile)
+  const FcBuf hbuf = fc_buf(hb_tile, (unsigned)FC_VN * 2u * rts);
+  unsigned hoff = (unsigned)(2 * wave) * 2u * rts;                       // uniform: this wave's two virtual nodes, pair 0
+  const unsigned hlane = (unsigned)lane * 16u;
   auto loadh = [&](float4 (&dst)[2][2], int piece) __attribute__((always_inline)) {
-    dst[piece >> 1][piece & 1] = *reinterpret_cast<const float4*>(hp + (size_t)piece * rts);
+    dst[piece >> 1][piece & 1] = fc_buf_ld4(hbuf, hlane, hoff + (unsigned)piece * rts);
   };
   f32x4 r[4];
   // live 16-column blocks of the granule: a (12,-,-,-) granule (one item column) multiplies only block 0 in the edge product
@@ -956,7 +990,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
 #pragma unroll
       for (int t = 0; t < 4; ++t) woff[t] += gstep;
     }
-    if constexpr (DO_H) hp += 256;
+    if constexpr (DO_H) hoff += 1024u;
   };
   auto roll = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -974,7 +1008,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
   for (int t = 0; t < 4; ++t) woff[t] += gstep;
 #pragma unroll
   for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
-  hp += 256;
+  hoff += 1024u;
 #pragma unroll
   for (int t = 0; t < 4; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   fc_sfor<0, NC>([&](auto ic) {
@@ -1184,6 +1218,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   if (MODE == 2) { vslot[0] = stab[16 + 2 * wave]; vslot[1] = stab[17 + 2 * wave]; }
   const int H = a.HK - 1;
   const int NG8 = a.NG8;
+  const float* __restrict__ hb_tile = a.Hb + fc_hb_off((a.dbg & 512) ? 0 : v0, 0, 0, 0, fc_ngp(NG8));   // uniform
+  (void)hb_tile;
   const float* __restrict__ hfrag = a.Hb + fc_hb_off(((a.dbg & 512) ? 0 : v0) + 2 * wave, 0, 0, lane, fc_ngp(NG8));   // + fc_hb_off(vi, rt, g, 0)
   float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
@@ -1235,9 +1271,9 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 #if FC_MANUAL
       if (MODE == 3) {
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
-        if (Gd.shape == 1) fc_mainloop_dense<12, 3>(acc, sl, a.wpack, a.KS, NG8, wave, hfrag, ywr, yrd);
-        else if (Gd.shape == 2) fc_mainloop_dense<3, 3>(acc, sl, a.wpack, a.KS, NG8, wave, hfrag, ywr, yrd);
-        else fc_mainloop_dense<12, 0>(acc, sl, a.wpack, a.KS, NG8, wave, hfrag, ywr, yrd);
+        if (Gd.shape == 1) fc_mainloop_dense<12, 3>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, ywr, yrd);
+        else if (Gd.shape == 2) fc_mainloop_dense<3, 3>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, ywr, yrd);
+        else fc_mainloop_dense<12, 0>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, ywr, yrd);
       } else
 #endif
       if (MODE == 0 || MODE == 3) {

@@ -38,9 +38,11 @@ extern uint3_ threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
 
 struct float2 { float x, y; };
+struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
+static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
