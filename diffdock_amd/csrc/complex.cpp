@@ -166,7 +166,8 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const bool load_mode = g.load;   // ligand gather nodes: contracted rows from k_node_contract, shared by the node's virtual nodes
     // load mode pays when a gather node carries many edges (its rows are shared by >= 2 virtual nodes)
     const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb &&
-                      (!load_mode || (m.fused_lig && c.y_chunk <= 0 && (m.fused_lig > 1 || g.ea_rows >= 64 * (long)g.gcount)));
+                      (!load_mode || (m.fused_lig && c.y_chunk <= 0 && (m.fused_lig > 1 || g.ea_rows >= 64 * (long)g.gcount) &&
+                                      (size_t)g.gcount * L.n_fgran * L.HKp * 256 < 0xf0000000ull));   // 32-bit row offsets in the kernel
     float* Hb = side ? c.Hb_b : c.Hb;
     const bool fuse_mm = fuse && m.fused_mm && ns % 16 == 0 && ns <= 64;   // first Linear inside the hidden-row kernel
     if (fuse_mm) {

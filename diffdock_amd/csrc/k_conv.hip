@@ -1043,22 +1043,23 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
 // Chunk buffer: [granule 2][slot 8] row blocks.  Same pipeline: rows of group g+2 are requested while group g is multiplied.
 __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const float* __restrict__ yg, size_t gran_stride,
                                                  size_t node_stride, int ng, const int* stab, int NG8,
-                                                 const float* __restrict__ hfrag, const int (&vne)[2], const int (&vslot)[2],
-                                                 float* ybuf, int tid, int lr, int lq) {
+                                                 const float* __restrict__ hb_tile, int wave, int lane, const int (&vne)[2],
+                                                 const int (&vslot)[2], float* ybuf, int tid, int lr, int lq) {
   const int nslots = stab[32];
   const int lu = tid >> 8, ls = (tid >> 7) & 1, row = (tid >> 4) & 7, c4 = tid & 15;
-  const float* src[4];
+  const FcBuf ybuf_g = fc_buf(yg, 0xfffffff0u);   // uniform base + 32-bit lane offsets (the host keeps the rows below 4 GB)
+  unsigned src[4];
   bool on[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     on[p] = 2 * p + ls < nslots && lu < ng;
-    src[p] = yg + (on[p] ? (size_t)lu * gran_stride + (size_t)stab[2 * p + ls] * node_stride : 0) + row * 64 + 4 * c4;
+    src[p] = (unsigned)((on[p] ? (size_t)lu * gran_stride + (size_t)stab[2 * p + ls] * node_stride : 0) + row * 64 + 4 * c4) * 4u;
   }
   float* dst = ybuf + (lu * 8 + ls) * FC_YVN + row * FC_YROW + 4 * c4;
   float4 yq[4];
 #define FC_FETCHY(g)                                                                      \
   do {                                                                                    \
-    _Pragma("unroll") for (int p = 0; p < 4; ++p) if (on[p]) yq[p] = nt_load4(src[p] + (size_t)(g) * 512); \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) if (on[p]) yq[p] = fc_buf_ld4(ybuf_g, src[p], (unsigned)(g) * 2048u); \
   } while (0)
 #define FC_STOREY(buf)                                                                    \
   do {                                                                                    \
@@ -1067,16 +1068,18 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const
   } while (0)
   float4 hC[2][2], hN[2][2];   // hidden-row fragments of the current / next pair of 8-k groups
   const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
-  const float* __restrict__ hp = hfrag;
-  const size_t rts = (size_t)fc_ngp(NG8) * 256;
+  const unsigned rts = (unsigned)fc_ngp(NG8) * 1024u;                    // bytes per (virtual node, row tile)
+  const FcBuf hbuf = fc_buf(hb_tile, (unsigned)FC_VN * 2u * rts);
+  unsigned hoff = (unsigned)(2 * wave) * 2u * rts;
+  const unsigned hlane = (unsigned)lane * 16u;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define FC_LOADH(dst_)                                                                   \
   do {                                                                                   \
-    dst_[0][0] = *reinterpret_cast<const float4*>(hp);                                   \
-    dst_[0][1] = two0 ? *reinterpret_cast<const float4*>(hp + rts) : z4;                 \
-    dst_[1][0] = *reinterpret_cast<const float4*>(hp + 2 * rts);                         \
-    dst_[1][1] = two1 ? *reinterpret_cast<const float4*>(hp + 3 * rts) : z4;             \
-    hp += 256;                                                                           \
+    dst_[0][0] = fc_buf_ld4(hbuf, hlane, hoff);                                          \
+    dst_[0][1] = two0 ? fc_buf_ld4(hbuf, hlane, hoff + rts) : z4;                        \
+    dst_[1][0] = fc_buf_ld4(hbuf, hlane, hoff + 2u * rts);                               \
+    dst_[1][1] = two1 ? fc_buf_ld4(hbuf, hlane, hoff + 3u * rts) : z4;                   \
+    hoff += 1024u;                                                                       \
   } while (0)
 #define FC_LOAD_STEP(g_, ODD_)                                                           \
   do {                                                                                   \
@@ -1240,7 +1243,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       const int ng = min(NGR, g_end - gi);
       const size_t gstride = (size_t)a.HKp * 64, nstride = (size_t)a.n_gran * gstride;
       const float* __restrict__ yg = a.Yg + (size_t)gi * gstride;
-      fc_mainloop_load(acc_all, yg, gstride, nstride, ng, stab, NG8, hfrag, vne, vslot, ybuf, tid, lr, lq);
+      fc_mainloop_load(acc_all, yg, gstride, nstride, ng, stab, NG8, hb_tile, wave, lane, vne, vslot, ybuf, tid, lr, lq);
       // bias row (k = H, h = 1) of every (granule, slot) -> row 0 of buffer 0
       {
         const int bu = tid >> 7, bs = (tid >> 4) & 7;
