@@ -33,7 +33,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     if (const char* e = getenv("DDMI_FUSED_LIG")) h->m.fused_lig = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_DENSE")) h->m.fused_dense = atoi(e);
-    if (const char* e = getenv("DDMI_FUSED_YS")) h->m.fused_ysplit = std::max(1, atoi(e));
+    if (const char* e = getenv("DDMI_FUSED_YS")) h->m.fused_ysplit = std::max(0, atoi(e));
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_fork));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_join));

@@ -163,11 +163,14 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const int wg = std::min<int>((int)gi, L.G - 1);
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
-    const bool load_mode = g.load;   // ligand gather nodes: contracted rows from k_node_contract, shared by the node's virtual nodes
-    // load mode pays when a gather node carries many edges (its rows are shared by >= 2 virtual nodes)
-    const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb &&
-                      (!load_mode || (m.fused_lig && c.y_chunk <= 0 && (m.fused_lig > 1 || g.ea_rows >= 64 * (long)g.gcount) &&
-                                      (size_t)g.gcount * L.n_fgran * L.HKp * 256 < 0xf0000000ull));   // 32-bit row offsets in the kernel
+    // Ligand gather nodes (few nodes, many edges each).  fused_lig: 0 unfused (k_node_contract + k_edge_conv), 1 the fused
+    // kernel contracts per virtual node when a node carries >= 64 edges (several virtual nodes then repeat their node's
+    // contraction -- still cheaper than a round trip of the contracted rows through HBM), 2 load mode (rows from
+    // k_node_contract, shared by the node's virtual nodes), 3 fused for every such group.
+    const bool load_mode = g.load && m.fused_lig == 2;
+    const bool lig_ok = !g.load || m.fused_lig >= 2 || (m.fused_lig == 1 && g.ea_rows >= 64 * (long)g.gcount);
+    const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb && lig_ok &&
+                      (!load_mode || (c.y_chunk <= 0 && (size_t)g.gcount * L.n_fgran * L.HKp * 256 < 0xf0000000ull));   // 32-bit row offsets in the kernel
     float* Hb = side ? c.Hb_b : c.Hb;
     const bool fuse_mm = fuse && m.fused_mm && ns % 16 == 0 && ns <= 64;   // first Linear inside the hidden-row kernel
     if (fuse_mm) {
@@ -210,7 +213,13 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.gmap = L.gmap;
       f.ctab = L.ctab; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
       f.dense = L.H % 16 == 0 && (m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount))) ? 1 : 0;
-      const int ys = std::max(1, std::min(std::min(m.fused_ysplit, 8), L.n_fgran));
+      // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
+      int ys_req = m.fused_ysplit;
+      if (ys_req <= 0) {
+        const long est_tiles = std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16);
+        ys_req = (int)std::min(4L, std::max(1L, 256 / est_tiles));
+      }
+      const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
       f.ysplit = ys;
       f.gsplit[0] = 0;
       for (int y = 1; y < ys; ++y) {   // split points at unit boundaries (later granules of a unit add to the first one's stores)

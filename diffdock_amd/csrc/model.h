@@ -90,11 +90,12 @@ struct Model {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool two_streams = true;
   bool fused = true;        // receptor-gather edge groups use k_conv_fused (DDMI_FUSED=0: contracted rows through HBM)
-  int fused_lig = 1;        // ligand-gather groups through k_conv_fused in load mode: 1 = when a node carries >= 64 edges,
-                            // 2 = always, 0 = never (k_edge_conv) -- DDMI_FUSED_LIG
+  int fused_lig = 3;        // ligand-gather groups (DDMI_FUSED_LIG): 3 = k_conv_fused contracting per virtual node like every other
+                            // group, 2 = k_conv_fused load mode (rows from k_node_contract), 1 = fused when a node carries
+                            // >= 64 edges, else unfused, 0 = unfused (k_node_contract + k_edge_conv)
   bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden
   int fused_dense = 1;      // branch-free dense-row main loop: 0 never, 1 groups with >= 20 edges per gather node, 2 always
-  int fused_ysplit = 1;     // workgroups per 16-virtual-node tile (granule ranges)
+  int fused_ysplit = 0;     // workgroups per 16-virtual-node tile (granule ranges); 0 = spread launches with few tiles over the CUs
   double crop_cutoff = 0.0;  // > 0: receptor cropped to this distance from the ligand in ddmi_forward (crop_beyond)
   DevicePool cpool;
   struct Cx;  // defined in complex.cpp
