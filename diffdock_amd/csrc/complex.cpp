@@ -217,7 +217,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       int ys_req = m.fused_ysplit;
       if (ys_req <= 0) {
         const long est_tiles = std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16);
-        ys_req = (int)std::min(4L, std::max(1L, 256 / est_tiles));
+        ys_req = (int)std::min(8L, std::max(1L, 768 / est_tiles));
       }
       const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
       f.ysplit = ys;
