@@ -20,9 +20,6 @@
 
 #include "kernels.h"
 
-#ifndef FC_MANUAL
-#define FC_MANUAL 1   // dense-row main loop with the hand-placed issue order (0: compiler-scheduled loop, for A/B runs)
-#endif
 
 namespace ddmi {
 
@@ -684,16 +681,7 @@ __device__ __forceinline__ void fc_store_rows(const float* __restrict__ stg, int
 // straight-line code per 8-k group -- the k-invariant x fragments stay in registers, the weight fragments arrive one
 // iteration ahead, and the four slot chains are issued interleaved (a dependent f32 MFMA costs 40 cycles, an independent
 // one 32).
-__device__ __forceinline__ float2 fc_ld2nt(const float* p) {
-#ifdef DDMI_HIPEMU
-  return *reinterpret_cast<const float2*>(p);
-#else
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
-  return make_float2(v.x, v.y);
-#endif
-}
-template <int S0, int SN, bool DENSE>
+template <int S0, int SN>
 __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotRt& s0, const FcSlotRt& s1, const FcSlotRt& s2,
                                             const FcSlotRt& s3, int KS, int NG8, int wave, const float* __restrict__ hfrag,
                                             const int (&vne)[2], float* ywr, const float* yrd) {
@@ -738,17 +726,13 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
   const float* __restrict__ hp = hfrag;
   const size_t rts = (size_t)fc_ngp(NG8) * 256;   // row-tile stride of the hidden rows
   int hg = 0;
-#ifdef FC_HB_NT
-#define FC_LDH(p) fc_ld2nt(p)
-#else
 #define FC_LDH(p) (*reinterpret_cast<const float2*>(p))
-#endif
 #define FC_LOADH(dst)                                                                    \
   do {                                                                                   \
     dst[0][0] = FC_LDH(hp);                                                              \
-    dst[0][1] = (DENSE || two0) ? FC_LDH(hp + rts) : make_float2(0.f, 0.f);              \
+    dst[0][1] = two0 ? FC_LDH(hp + rts) : make_float2(0.f, 0.f);                         \
     dst[1][0] = FC_LDH(hp + 2 * rts);                                                    \
-    dst[1][1] = (DENSE || two1) ? FC_LDH(hp + 3 * rts) : make_float2(0.f, 0.f);          \
+    dst[1][1] = two1 ? FC_LDH(hp + 3 * rts) : make_float2(0.f, 0.f);                     \
     hp += (hg & 1) ? 254 : 2; ++hg;   /* second half of the float4, then the next pair of groups */ \
   } while (0)
 #define FC_EDGE_GEMM(buf)                                                                \
@@ -763,7 +747,7 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
         acc[vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[vi][0][1], 0, 0, 0); \
         acc[vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[vi][0][2], 0, 0, 0); \
         acc[vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[vi][0][3], 0, 0, 0); \
-        if (DENSE || (vi == 0 ? two0 : two1)) {                                          \
+        if (vi == 0 ? two0 : two1) {                                                     \
           const float a1 = sub == 0 ? hC[vi][1].x : hC[vi][1].y;                          \
           acc[vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[vi][1][0], 0, 0, 0); \
           acc[vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[vi][1][1], 0, 0, 0); \
@@ -780,51 +764,21 @@ __device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotR
   } while (0)
   FC_FETCH();
   FC_LOADH(hC);
-#ifdef FC_HB_DEPTH3
-  float2 hM[2][2];             // hidden rows two chunks ahead (the re-reads of a tile's rows come from MALL/HBM, not L2)
-  if (NG8 > 1) FC_LOADH(hN);
-#endif
   FC_CONTRACT(0);
   if (NG8 > 1) FC_FETCH();
   __syncthreads();
   int g = 0;
-  for (; g + 2 < NG8; ++g) {   // steady state: straight-line body (with DENSE no branch at all between two barriers)
+  for (; g + 2 < NG8; ++g) {   // steady state
     FC_CONTRACT((g + 1) & 1);
     FC_FETCH();
-#ifdef FC_HB_DEPTH3
-    FC_LOADH(hM);
-#else
     FC_LOADH(hN);
-#endif
     FC_EDGE_GEMM(g & 1);
-#if defined(FC_SCHED) && !defined(DDMI_HIPEMU)
-    if (DENSE) {   // issue order of the block: the loads and LDS traffic ride in the MFMA shadows instead of in bursts between them
-      constexpr int NC = S0 + 3 * SN;
-      _Pragma("unroll") for (int i = 0; i < NC; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // hidden-row fragments of the next chunk
-        if (i >= NC - 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // first B fragments of the edge product
-      }
-      _Pragma("unroll") for (int i = 0; i < 32; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < NC) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // weight fragments two chunks ahead
-        if (i >= FC_SCHED && i < FC_SCHED + 16) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // contracted rows -> LDS
-        if (i % 4 == 1 && i < 24) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-    }
-#endif
     __syncthreads();
     FC_ROLL();
-#ifdef FC_HB_DEPTH3
-    _Pragma("unroll") for (int vi = 0; vi < 2; ++vi)
-      _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) hN[vi][rt] = hM[vi][rt];
-#endif
   }
   if (g + 1 < NG8) {           // last contraction: nothing left to request
     FC_CONTRACT((g + 1) & 1);
-#ifndef FC_HB_DEPTH3
     FC_LOADH(hN);
-#endif
     FC_EDGE_GEMM(g & 1);
     __syncthreads();
     FC_ROLL();
@@ -1221,9 +1175,9 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   if (MODE == 2) { vslot[0] = stab[16 + 2 * wave]; vslot[1] = stab[17 + 2 * wave]; }
   const int H = a.HK - 1;
   const int NG8 = a.NG8;
-  const float* __restrict__ hb_tile = a.Hb + fc_hb_off((a.dbg & 512) ? 0 : v0, 0, 0, 0, fc_ngp(NG8));   // uniform
+  const float* __restrict__ hb_tile = a.Hb + fc_hb_off(v0, 0, 0, 0, fc_ngp(NG8));   // uniform: hidden rows of this tile
   (void)hb_tile;
-  const float* __restrict__ hfrag = a.Hb + fc_hb_off(((a.dbg & 512) ? 0 : v0) + 2 * wave, 0, 0, lane, fc_ngp(NG8));   // + fc_hb_off(vi, rt, g, 0)
+  const float* __restrict__ hfrag = a.Hb + fc_hb_off(v0 + 2 * wave, 0, 0, lane, fc_ngp(NG8));   // + fc_hb_off(vi, rt, g, 0)
   float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
   constexpr int NGR = MODE == 2 ? 2 : 1;   // granules per pass
@@ -1271,19 +1225,15 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.w0, lr, lq);
-#if FC_MANUAL
-      if (MODE == 3) {
+      if (MODE == 3) {   // dense rows: hand-scheduled loop
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
         if (Gd.shape == 1) fc_mainloop_dense<12, 3>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, ywr, yrd);
         else if (Gd.shape == 2) fc_mainloop_dense<3, 3>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, ywr, yrd);
         else fc_mainloop_dense<12, 0>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, ywr, yrd);
-      } else
-#endif
-      if (MODE == 0 || MODE == 3) {
-        constexpr bool DN = MODE == 3;
-        if (Gd.shape == 1) fc_mainloop<12, 3, DN>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
-        else if (Gd.shape == 2) fc_mainloop<3, 3, DN>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
-        else fc_mainloop<12, 0, DN>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+      } else if (MODE == 0) {
+        if (Gd.shape == 1) fc_mainloop<12, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+        else if (Gd.shape == 2) fc_mainloop<3, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+        else fc_mainloop<12, 0>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
       } else {
       FcPre pre;
       const int shape = Gd.shape;
