@@ -212,7 +212,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
       f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.gmap = L.gmap;
       f.ctab = L.ctab; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
-      f.dense = L.H % 16 == 0 && (m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount))) ? 1 : 0;
+      f.dense = (m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount))) ? 1 : 0;
       // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
       int ys_req = m.fused_ysplit;
       if (ys_req <= 0) {

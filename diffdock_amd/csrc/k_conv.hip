@@ -677,129 +677,6 @@ __device__ __forceinline__ void fc_store_rows(const float* __restrict__ stg, int
   }
 }
 
-// Steady-state loop of one granule for the static chain shapes (S0, SN, SN, SN), hidden width a multiple of 8:
-// straight-line code per 8-k group -- the k-invariant x fragments stay in registers, the weight fragments arrive one
-// iteration ahead, and the four slot chains are issued interleaved (a dependent f32 MFMA costs 40 cycles, an independent
-// one 32).
-template <int S0, int SN>
-__device__ __forceinline__ void fc_mainloop(f32x4 (&acc)[2][2][4], const FcSlotRt& s0, const FcSlotRt& s1, const FcSlotRt& s2,
-                                            const FcSlotRt& s3, int KS, int NG8, int wave, const float* __restrict__ hfrag,
-                                            const int (&vne)[2], float* ywr, const float* yrd) {
-  constexpr int M0 = S0 > 0 ? S0 : 1, MN = SN > 0 ? SN : 1;
-  float xa0[M0], xa1[MN], xa2[MN], xa3[MN];
-  float b0[M0], b1[MN], b2[MN], b3[MN];
-#pragma unroll
-  for (int j = 0; j < S0; ++j) xa0[j] = s0.xp[j * s0.xstride];
-#pragma unroll
-  for (int j = 0; j < SN; ++j) { xa1[j] = s1.xp[j * s1.xstride]; xa2[j] = s2.xp[j * s2.xstride]; xa3[j] = s3.xp[j * s3.xstride]; }
-  const float* __restrict__ w0 = s0.wb + (size_t)wave * KS;   // row k = 8g + wave: advance by 8*KS per group
-  const float* __restrict__ w1 = s1.wb + (size_t)wave * KS;
-  const float* __restrict__ w2 = s2.wb + (size_t)wave * KS;
-  const float* __restrict__ w3 = s3.wb + (size_t)wave * KS;
-  const size_t gstep = (size_t)8 * KS;
-#define FC_FETCH()                                                                       \
-  do {                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < S0; ++j) b0[j] = (w0 + j)[s0.loff]; \
-    _Pragma("unroll") for (int j = 0; j < SN; ++j) {                                     \
-      b1[j] = (w1 + j)[s1.loff];                                    \
-      b2[j] = (w2 + j)[s2.loff];                                    \
-      b3[j] = (w3 + j)[s3.loff];                                    \
-    }                                                                                    \
-    w0 += gstep; w1 += gstep; w2 += gstep; w3 += gstep;                                  \
-  } while (0)
-#define FC_CONTRACT(buf)                                                                 \
-  do {                                                                                   \
-    f32x4 r0 = f32x4{0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;                     \
-    _Pragma("unroll") for (int j = 0; j < (S0 > 3 * SN ? S0 : 3 * SN); ++j) {            \
-      if (j < S0) r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0[j], b0[j], r0, 0, 0, 0); \
-      if (j < 3 * SN) {                                                                  \
-        if (j % 3 == 0) r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1[j / 3], b1[j / 3], r1, 0, 0, 0);      \
-        else if (j % 3 == 1) r2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa2[j / 3], b2[j / 3], r2, 0, 0, 0); \
-        else r3 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa3[j / 3], b3[j / 3], r3, 0, 0, 0);                 \
-      }                                                                                  \
-    }                                                                                    \
-    float* yw = ywr + (buf) * FC_YB;                                                     \
-    fc_store(yw, 0, r0); fc_store(yw, 1, r1); fc_store(yw, 2, r2); fc_store(yw, 3, r3);  \
-  } while (0)
-  float2 hC[2][2], hN[2][2];
-  const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
-  const float* __restrict__ hp = hfrag;
-  const size_t rts = (size_t)fc_ngp(NG8) * 256;   // row-tile stride of the hidden rows
-  int hg = 0;
-#define FC_LDH(p) (*reinterpret_cast<const float2*>(p))
-#define FC_LOADH(dst)                                                                    \
-  do {                                                                                   \
-    dst[0][0] = FC_LDH(hp);                                                              \
-    dst[0][1] = two0 ? FC_LDH(hp + rts) : make_float2(0.f, 0.f);                         \
-    dst[1][0] = FC_LDH(hp + 2 * rts);                                                    \
-    dst[1][1] = two1 ? FC_LDH(hp + 3 * rts) : make_float2(0.f, 0.f);                     \
-    hp += (hg & 1) ? 254 : 2; ++hg;   /* second half of the float4, then the next pair of groups */ \
-  } while (0)
-#define FC_EDGE_GEMM(buf)                                                                \
-  do {                                                                                   \
-    const float* __restrict__ yb0 = yrd + (buf) * FC_YB;                                 \
-    _Pragma("unroll") for (int vi = 0; vi < 2; ++vi) {                                   \
-      _Pragma("unroll") for (int sub = 0; sub < 2; ++sub) {                              \
-        const float* __restrict__ yb = yb0 + vi * FC_YVN + sub * FC_YROW;                \
-        const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];                   \
-        const float a0 = sub == 0 ? hC[vi][0].x : hC[vi][0].y;                          \
-        acc[vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[vi][0][0], 0, 0, 0); \
-        acc[vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[vi][0][1], 0, 0, 0); \
-        acc[vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[vi][0][2], 0, 0, 0); \
-        acc[vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[vi][0][3], 0, 0, 0); \
-        if (vi == 0 ? two0 : two1) {                                                     \
-          const float a1 = sub == 0 ? hC[vi][1].x : hC[vi][1].y;                          \
-          acc[vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[vi][1][0], 0, 0, 0); \
-          acc[vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[vi][1][1], 0, 0, 0); \
-          acc[vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[vi][1][2], 0, 0, 0); \
-          acc[vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[vi][1][3], 0, 0, 0); \
-        }                                                                                \
-      }                                                                                  \
-    }                                                                                    \
-  } while (0)
-#define FC_ROLL()                                                                        \
-  do {                                                                                   \
-    _Pragma("unroll") for (int vi = 0; vi < 2; ++vi)                                     \
-      _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];          \
-  } while (0)
-  FC_FETCH();
-  FC_LOADH(hC);
-  FC_CONTRACT(0);
-  if (NG8 > 1) FC_FETCH();
-  __syncthreads();
-  int g = 0;
-  for (; g + 2 < NG8; ++g) {   // steady state
-    FC_CONTRACT((g + 1) & 1);
-    FC_FETCH();
-    FC_LOADH(hN);
-    FC_EDGE_GEMM(g & 1);
-    __syncthreads();
-    FC_ROLL();
-  }
-  if (g + 1 < NG8) {           // last contraction: nothing left to request
-    FC_CONTRACT((g + 1) & 1);
-    FC_LOADH(hN);
-    FC_EDGE_GEMM(g & 1);
-    __syncthreads();
-    FC_ROLL();
-    ++g;
-  }
-  FC_EDGE_GEMM(g & 1);
-  __syncthreads();
-#undef FC_EDGE_GEMM
-#undef FC_LDH
-#undef FC_ROLL
-#undef FC_FETCH
-#undef FC_CONTRACT
-#undef FC_LOADH
-}
-
-// Dense-row main loop with a hand-placed issue order.  Two waves share a SIMD and meet at a barrier every chunk, so they
-// run the same phase at the same time: whatever is not an MFMA has to ride in the 32-cycle shadow of one, not sit in a
-// burst between two MFMA phases.  Per chunk: the NC contraction MFMAs of chunk g+1 (with the four hidden-row fragment
-// requests of chunk g+1 and the first B-fragment reads of chunk g between them), then the 32 edge MFMAs of chunk g with,
-// one per MFMA, the NC weight-fragment requests of chunk g+2 (uniform base + 32-bit lane offset), the 8 paired LDS stores
-// of the rows just contracted and the B-fragment reads of the next (virtual node, k pair).  sched_barrier fences pin it.
 // Uniform-base requests (buffer resource in SGPRs + 32-bit lane offset + SGPR offset): no per-request 64-bit address
 // arithmetic in the vector ALU and no address registers -- the dense main loop issues one such request per MFMA shadow.
 #ifdef DDMI_HIPEMU
@@ -851,10 +728,13 @@ struct FcOrder {   // issue order of the four slot chains: slot 0 alternating wi
   static constexpr int slot(int i) { return find(i, true); }
   static constexpr int step(int i) { return find(i, false); }
 };
-template <int S0, int SN>
+template <int S0, int SN, bool DENSE>
 __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
                                                   int KS, int HK, int NG8, int wave, int lane,
-                                                  const float* __restrict__ hb_tile, float* ywr, const float* yrd) {
+                                                  const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr,
+                                                  const float* yrd) {
+  // sparse rows (!DENSE): the second 16-row tile of a virtual node with <= 16 edges is neither fetched nor multiplied
+  const bool two[2] = {DENSE || vne[0] > 16, DENSE || vne[1] > 16};
   using O = FcOrder<S0, SN>;
   constexpr int NC = O::NC;
   float xa[NC];
@@ -888,12 +768,14 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
     }
   };
   float4 hC[2][2], hN[2][2];   // hidden-row fragments of the current / next PAIR of chunks: [virtual node][row tile]
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) hC[pc >> 1][pc & 1] = hN[pc >> 1][pc & 1] = make_float4(0.f, 0.f, 0.f, 0.f);
   const unsigned rts = (unsigned)(NG8 >> 1) * 1024u;                     // bytes per (virtual node, row tile)
   const FcBuf hbuf = fc_buf(hb_tile, (unsigned)FC_VN * 2u * rts);
   unsigned hoff = (unsigned)(2 * wave) * 2u * rts;                       // uniform: this wave's two virtual nodes, pair 0
   const unsigned hlane = (unsigned)lane * 16u;
   auto loadh = [&](float4 (&dst)[2][2], int piece) __attribute__((always_inline)) {
-    dst[piece >> 1][piece & 1] = fc_buf_ld4(hbuf, hlane, hoff + (unsigned)piece * rts);
+    if (DENSE || !(piece & 1) || two[piece >> 1]) dst[piece >> 1][piece & 1] = fc_buf_ld4(hbuf, hlane, hoff + (unsigned)piece * rts);
   };
   f32x4 r[4];
   // live 16-column blocks of the granule: a (12,-,-,-) granule (one item column) multiplies only block 0 in the edge product
@@ -933,8 +815,10 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
     fc_sfor<0, NE>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       constexpr int grp = m / (2 * NCB), t8 = m % (2 * NCB), vi = grp >> 1, sub = grp & 1, rt = t8 / NCB, c = t8 % NCB;
-      const float av = ODD ? (sub == 0 ? hC[vi][rt].z : hC[vi][rt].w) : (sub == 0 ? hC[vi][rt].x : hC[vi][rt].y);
-      acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
+      if (DENSE || rt == 0 || two[vi]) {
+        const float av = ODD ? (sub == 0 ? hC[vi][rt].z : hC[vi][rt].w) : (sub == 0 ? hC[vi][rt].x : hC[vi][rt].y);
+        acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
+      }
       if constexpr (DO_W) { if constexpr (m % 2 == 0 && m / 2 < NL) loadw(std::integral_constant<int, m / 2>{}); }
       if constexpr (DO_C) { if (m >= 2 && m < 2 + NP) store_piece(cb, m - 2); }
       if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
@@ -1225,15 +1109,12 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.w0, lr, lq);
-      if (MODE == 3) {   // dense rows: hand-scheduled loop
+      if (MODE == 0 || MODE == 3) {   // static chain shapes: hand-scheduled loop, dense (3) or sparse (0) rows
+        constexpr bool DN = MODE == 3;
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
-        if (Gd.shape == 1) fc_mainloop_dense<12, 3>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, ywr, yrd);
-        else if (Gd.shape == 2) fc_mainloop_dense<3, 3>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, ywr, yrd);
-        else fc_mainloop_dense<12, 0>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, ywr, yrd);
-      } else if (MODE == 0) {
-        if (Gd.shape == 1) fc_mainloop<12, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
-        else if (Gd.shape == 2) fc_mainloop<3, 3>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
-        else fc_mainloop<12, 0>(acc, s0, s1, s2, s3, a.KS, NG8, wave, hfrag, vne, ywr, yrd);
+        if (Gd.shape == 1) fc_mainloop_dense<12, 3, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
+        else if (Gd.shape == 2) fc_mainloop_dense<3, 3, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
+        else fc_mainloop_dense<12, 0, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
       } else {
       FcPre pre;
       const int shape = Gd.shape;

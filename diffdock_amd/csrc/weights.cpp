@@ -392,7 +392,7 @@ static void commit_conv(Model& m, ConvW& L) {
     }
     L.fgran_generic = false;
     for (auto& G : fg) if (!G.empty && G.shape == 0) L.fgran_generic = true;
-    if (L.H % 8 != 0) L.fgran_generic = true;   // the static loops assume whole 8-k groups
+    if (L.H % 16 != 0) L.fgran_generic = true;   // the static loops walk whole pairs of 8-k groups
     L.fgran = m.wpool.upload(fg);
     L.n_fgran = (int)fg.size();
     L.HKq = (int)round_up(L.H, 8);   // hidden width padded to the 8-k groups of the fused kernel
