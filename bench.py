@@ -55,11 +55,13 @@ def t_schedule(steps):
     return np.linspace(1, 0, steps + 1)[:-1]      # get_t_schedule('expbeta', alpha=beta=1), diffusion_utils.py:138-142
 
 
-def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr, fused=True):
+def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr, fused=True, fused_lig=True):
     """Algorithmic flops / bytes of every (layer, edge group) launch of the convolution kernels of one forward pass
     (DESIGN.md section 4).  NT = columns of a contracted node row (sum over paths of din*mul_out), K = 3ns + 1.
-    Receptor-gather groups run k_conv_fused (contracted rows stay in LDS: its HBM bytes are the x rows, the hidden rows
-    and the messages); ligand-gather groups run k_node_contract + k_edge_conv with the rows Y in HBM."""
+    Groups that run k_conv_fused keep the contracted rows in LDS: their HBM bytes are the x rows, the hidden rows and the
+    messages, and their node term is counted once per gather NODE (the kernel repeats it per 32-edge virtual node of a
+    ligand atom -- that repetition is not algorithmic work).  With DDMI_FUSED_LIG < 3 the ligand-gather groups run
+    k_node_contract + k_edge_conv with the rows Y in HBM."""
     from diffdock_amd.irreps import parse_irreps, sh_irreps
     from diffdock_amd.o3 import faster_path_table, fctp_path_table
     out = []
@@ -76,7 +78,7 @@ def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr, fused=True):
         for gcount, tcount, E, rec_gather in (groups if l < L - 1 else groups[:2]):
             H = 3 * cfg.ns
             node_flops, edge_flops = 2.0 * gcount * HK * mac_node, 2.0 * E * HK * NT
-            if fused and rec_gather:
+            if fused and (rec_gather or fused_lig):
                 out.append({"k_conv_fused": {"flops": node_flops + edge_flops,
                                              "bytes": gcount * d_in * 4.0 + E * (H * 4.0 + d_out * 4.0)}})
             else:
@@ -190,7 +192,8 @@ def main():
         if dom in ("k_edge_conv", "k_node_contract", "k_conv_fused") and not args.all_atoms:
             ms, n = kern[dom]
             avg_s = ms / max(n, 1) * 1e-3
-            work = [w[dom] for w in conv_work(cfg, B * N_LIG, B * N_RES, e_ll, e_lr, e_rr, fused="k_conv_fused" in kern)
+            work = [w[dom] for w in conv_work(cfg, B * N_LIG, B * N_RES, e_ll, e_lr, e_rr, fused="k_conv_fused" in kern,
+                                              fused_lig="k_edge_conv" not in kern and "k_conv_fused_load" not in kern)
                     if dom in w]
             launches_per_forward = len(work)
             flops = sum(w["flops"] for w in work) / launches_per_forward
@@ -207,12 +210,31 @@ def main():
             roof.update({"avg_launch_ms": avg_s * 1e3, "launches": n, "launches_per_forward": launches_per_forward,
                          "alg_flops_per_launch": flops, "alg_bytes_per_launch": bytes_,
                          "concurrent_streams": 1 if os.environ.get("DDMI_STREAMS") == "1" else 2,
-                         "alg_definition": "mean over the launches of this kernel in one forward (exact f32 on v_mfma_f32_16x16x4_f32, "
+                         "alg_definition": "mean over the launches of this kernel in one forward -- all four edge groups of every "
+                                           "layer, 22 launches (exact f32 on v_mfma_f32_16x16x4_f32, "
                                            "peak = dense f32 MFMA); k_conv_fused: 2*145*sum(mul_in*mul_out*din) flop per gather node "
                                            "+ 2*145*NT flop per edge, bytes = x rows + 576 B hidden row + 624 B message per edge; "
                                            "k_edge_conv: 2*145*NT flop/edge, bytes = contracted rows Y (145*NT*4 B per gather node) + "
                                            "hidden + message rows; k_node_contract: node flops, Y written once.  With 2 streams the "
-                                           "ligand-gather kernels run concurrently, so launch durations include their share of the chip"})
+                                           "ligand-gather launches run concurrently with the receptor-gather ones, so the launch "
+                                           "durations overlap (their sum exceeds the wall time); DDMI_STREAMS=1 serialises them"})
+            if roof["concurrent_streams"] == 2 and dom == "k_conv_fused":
+                # the same kernel timed with the launches serialised on ONE stream (untimed extra pass, second handle):
+                # with two streams the launch durations overlap, so the figures above understate the kernel alone
+                os.environ["DDMI_STREAMS"] = "1"
+                m1 = MIScoreModel(cfg, device=str(dev), lib_path=args.lib)
+                del os.environ["DDMI_STREAMS"]
+                m1.load_state_dict(sd)
+                m1.set_tables(so3_t, tor_t)
+                m1.sample_batch(batch, INFERENCE_STEPS, (sched, sched, sched), seed=7, sample_ids=ids, no_final_step_noise=True, **TEMP)
+                m1.set_kernel_timing(True)
+                m1.sample_batch(batch, INFERENCE_STEPS, (sched, sched, sched), seed=8, sample_ids=ids, no_final_step_noise=True, **TEMP)
+                torch.cuda.synchronize()
+                ms1, n1 = m1.kernel_timings()[dom]
+                ach1 = flops / (ms1 / max(n1, 1) * 1e-3) / 1e12
+                roof["serialised"] = {"avg_launch_ms": ms1 / max(n1, 1), "launches": n1, "achieved": ach1,
+                                      "frac": ach1 / MFMA_F32_PEAK_TFLOPS}
+                del m1
         cpu = None if (args.no_cpu_baseline or args.all_atoms) else cpu_baseline(cfg, sd, so3_t, tor_t, g)
         out = {
             "metric": "poses/sec (20 steps x 40 samples, DiffDock-L score model)" if not args.all_atoms else
