@@ -98,6 +98,42 @@ def test_ddl_synth_forward_matches_oracle(lmax, t):
     assert rel_err(tr2.cpu(), tr) < REL and rel_err(rot2.cpu(), rot) < REL and rel_err(tor2.cpu(), tor) < REL
 
 
+@pytest.fixture(scope="module")
+def width48_case():
+    """Benchmark-width model on a small complex: inputs, oracle scores and the scores of the default kernel route."""
+    cfg = DDL_SYNTH
+    sd = init_state_dict(cfg, seed=1234)
+    batch = synth_batch(cfg, 100, 40, 2, seed=5, t=0.6)     # 40-atom ligand: receptor residues with two virtual nodes
+    so3_t, tor_t = tables()
+    ref = CGModelOracle(cfg, sd, so3_t, tor_t)(batch)[:3]
+    base = [o.cpu() for o in gpu_model(cfg, sd)(to_gpu(batch))[:3]]
+    return cfg, sd, batch, ref, base
+
+
+@pytest.mark.parametrize("env", [{"DDMI_FUSED_LIG": "2"}, {"DDMI_FUSED_LIG": "0"}, {"DDMI_FUSED": "0"}, {"DDMI_FUSED_DENSE": "0"},
+                                 {"DDMI_FUSED_DENSE": "2"}, {"DDMI_FUSED_MM": "0"}, {"DDMI_STREAMS": "1"}, {"DDMI_FUSED_YS": "3"}],
+                         ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
+def test_selectable_kernel_paths_agree_on_the_gpu(env, width48_case, monkeypatch):
+    """Every selectable route of an edge group (load mode, the unfused k_node_contract + k_edge_conv pair, sparse- / dense-row
+    loop, GEMM first layer, one stream, granule-range splits) against the default route and the oracle at the benchmark
+    width: the knobs are read at ddmi_create, so each model handle is built under its own environment."""
+    cfg, sd, batch, ref, base = width48_case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m = gpu_model(cfg, sd)
+    m.set_kernel_timing(True)
+    out = m(to_gpu(batch))[:3]
+    launched = m.kernel_timings()
+    if env.get("DDMI_FUSED") == "0":
+        assert "k_conv_fused" not in launched and "k_edge_conv" in launched
+    if env.get("DDMI_FUSED_LIG") == "2":
+        assert "k_conv_fused_load" in launched
+    if env.get("DDMI_FUSED_LIG") == "0":
+        assert "k_edge_conv" in launched and "k_conv_fused" in launched
+    for o, b, r in zip(out, base, ref):
+        assert rel_err(o.cpu(), r) < REL and rel_err(o.cpu(), b) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1"])
 def test_confidence_mode_matches_reference_fixture(name):
     fx, cfg, data_list = fixture_case(name)
