@@ -172,12 +172,13 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb && lig_ok &&
                       (!load_mode || (c.y_chunk <= 0 && (size_t)g.gcount * L.n_fgran * L.HKp * 256 < 0xf0000000ull));   // 32-bit row offsets in the kernel
     float* Hb = side ? c.Hb_b : c.Hb;
-    const bool fuse_mm = fuse && m.fused_mm && ns % 16 == 0 && ns <= 64;   // first Linear inside the hidden-row kernel
-    if (fuse_mm) {
+    const bool fuse_mm = fuse && m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
+    if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
       PhaseTimer t(m, "conv_fc1_gemms", gs);
-      if (g.sig) { gemm(g.sig, ns, W1, L.n_edge, nullptr, rowbias, H, c.B, H, ns, 0, gs); rb = rowbias; }
-      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + (g.swap_pq ? 2 : 1) * ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
-      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + (g.swap_pq ? 1 : 2) * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
+      const float* W1p = L.W1p[wg];
+      if (g.sig) { gemm(g.sig, ns, W1p, L.n_edge, nullptr, rowbias, H, c.B, H, ns, 0, gs); rb = rowbias; }
+      gemm(Xin + (size_t)g.tbase * XS, XS, W1p + (g.swap_pq ? 2 : 1) * ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
+      gemm(Xin + (size_t)g.gbase * XS, XS, W1p + (g.swap_pq ? 1 : 2) * ns, L.n_edge, L.b1p[wg], Q, H, g.gcount, H, ns, 0, gs);
     } else {
       PhaseTimer t(m, "conv_fc1_gemms", gs);
       if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]
@@ -200,7 +201,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         PhaseTimer t(m, "k_edge_hidden", gs);
         EdgeHiddenArgs h{};
         h.nvn = nvn; h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
-        h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = W1; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
+        h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = L.W1p[wg]; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
         h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb;
         launch_edge_hidden_mm(h, gs);
       } else {

@@ -489,21 +489,21 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
   const int lr = lane & 15, lq = lane >> 4;
   const int nvn = *a.nvn;
   if ((int)blockIdx.x * 4 >= nvn) return;
-  // Output position 4a + i of a 16-block holds hidden unit 8 (i >> 1) + 2a + (i & 1): lane (row, quarter a) then ends with
-  // k = 8g + 2a + {0, 1} of BOTH 8-k groups g = 2nb, 2nb + 1 -- the float4 of fragment lane 16a + row.
+  // a.W1 is the permuted copy of the first layer (weights.cpp): output position 4a + i of a 16-block holds hidden unit
+  // 8 (i >> 1) + 2a + (i & 1), so lane (row, quarter a) ends with k = 8g + 2a + {0, 1} of BOTH 8-k groups g = 2nb, 2nb + 1 --
+  // the float4 of fragment lane 16a + row; P, Q and the sigma rows arrive in the same order.
   for (int idx = tid; idx < H * 4 * KS; idx += 256) {   // k fastest: coalesced reads of the weight rows
     const int k = idx % (4 * KS), n = idx / (4 * KS);
     const int q = k / KS, t = k - q * KS;
-    const int pos = n & 15, unit = (n & ~15) + 8 * ((pos & 3) >> 1) + 2 * (pos >> 2) + (pos & 1);
-    wl[(t * 4 + q) * H + n] = a.W1[(size_t)unit * a.ldw + k];
+    wl[(t * 4 + q) * H + n] = a.W1[(size_t)n * a.ldw + k];
   }
   __syncthreads();
   for (int v = blockIdx.x * 4 + wave; v < nvn; v += gridDim.x * 4) {
     const int d = a.vn_node[v], e0 = a.vn_e0[v];
     const int ne = min(32, a.goff[d + 1] - e0);
-    const float* __restrict__ qrow = a.Q + (size_t)d * H + 2 * lq;
+    const float* __restrict__ qrow = a.Q + (size_t)d * H + 4 * lq;
     const float* __restrict__ rbrow = nullptr;
-    if (a.rowbias && ne > 0) rbrow = a.rowbias + (size_t)a.ridx[a.arow ? a.arow[e0] : e0] * H + 2 * lq;
+    if (a.rowbias && ne > 0) rbrow = a.rowbias + (size_t)a.ridx[a.arow ? a.arow[e0] : e0] * H + 4 * lq;
 #pragma unroll 1
     for (int rt = 0; rt < 2; ++rt) {
       float* __restrict__ hp = a.Hb + fc_hb_off(v, rt, 0, lane, NG8 / 2);   // + 256 per pair of 8-k groups
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
         continue;
       }
       float4 ae[NSQ];
-      const float* __restrict__ prow = a.P + 2 * lq;
+      const float* __restrict__ prow = a.P + 4 * lq;
       if (live) {
         const int e = e0 + el;
         const int ar = a.arow ? a.arow[e] : e;
@@ -529,13 +529,9 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        auto ld22 = [](const float* __restrict__ p) __attribute__((always_inline)) {   // units 2a + {0,1} and 8 + 2a + {0,1}
-          const float2 u = *reinterpret_cast<const float2*>(p), w = *reinterpret_cast<const float2*>(p + 8);
-          return make_float4(u.x, u.y, w.x, w.y);
-        };
-        float4 pq = ld22(qrow + 16 * nb);
-        if (rbrow) { const float4 t = ld22(rbrow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
-        if (live) { const float4 t = ld22(prow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
+        float4 pq = *reinterpret_cast<const float4*>(qrow + 16 * nb);
+        if (rbrow) { const float4 t = *reinterpret_cast<const float4*>(rbrow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
+        if (live) { const float4 t = *reinterpret_cast<const float4*>(prow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
         f32x4 acc = f32x4{pq.x, pq.y, pq.z, pq.w}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: a dependent f32 MFMA waits 40 cycles
         const float* __restrict__ wp = wl + lq * H + 16 * nb + lr;
 #pragma unroll

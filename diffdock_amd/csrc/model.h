@@ -44,6 +44,7 @@ struct ConvW {  // one TensorProductConvLayer
   TPTable table;
   int n_edge = 0, H = 0, HK = 0, HKp = 0, D_in = 0, D_out = 0, NT = 0, NTs = 0, sh_dim = 0, Wn = 0;
   std::vector<float*> W1, b1, W2, b2, wpack;
+  std::vector<float*> W1p, b1p;   // first layer with the hidden units of every block of 16 in the order k_edge_hidden_mm emits them
   NcUnit* nc_units = nullptr; int n_nc = 0, KS = 0;          // node-contraction work list, k-slab size of wpack
   FGran* fgran = nullptr; int n_fgran = 0, HKq = 0; bool fgran_generic = false;          // fused form: granule list, padded hidden-row length
   std::vector<int> fgran_unit;                               // unit id of every granule (split points of the grid)

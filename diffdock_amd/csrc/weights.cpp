@@ -308,6 +308,25 @@ static void commit_conv(Model& m, ConvW& L) {
     const std::string pre = L.G == 1 ? L.name + ".fc" : L.name + ".fc." + std::to_string(g);
     L.W1.push_back(up(m, pre + ".0.weight"));
     L.b1.push_back(up(m, pre + ".0.bias"));
+    {   // position 4a + i of a block of 16 holds hidden unit 8 (i >> 1) + 2a + (i & 1): a lane of the MFMA first layer (row,
+        // quarter a) then ends with k = 8g + 2a + {0, 1} of two 8-k groups -- the float4 of its own fragment lane.  The
+        // per-node terms P, Q and the sigma rows come out of their GEMMs in the same order when they use this copy.
+      const HostTensor &w1 = W(m, pre + ".0.weight"), &bb = W(m, pre + ".0.bias");
+      const int Hh = (int)w1.shape[0], ne = (int)w1.shape[1];
+      if (Hh % 16 == 0) {
+        std::vector<float> wp((size_t)Hh * ne), bp(Hh);
+        for (int pos = 0; pos < Hh; ++pos) {
+          const int q = pos & 15, unit = (pos & ~15) + 8 * ((q & 3) >> 1) + 2 * (q >> 2) + (q & 1);
+          std::copy(w1.data.begin() + (size_t)unit * ne, w1.data.begin() + (size_t)(unit + 1) * ne, wp.begin() + (size_t)pos * ne);
+          bp[pos] = bb.data[unit];
+        }
+        L.W1p.push_back(m.wpool.upload(wp));
+        L.b1p.push_back(m.wpool.upload(bp));
+      } else {
+        L.W1p.push_back(nullptr);
+        L.b1p.push_back(nullptr);
+      }
+    }
     const HostTensor &w2 = W(m, pre + ".3.weight"), &b2 = W(m, pre + ".3.bias");
     if (!L.yform) {
       L.W2.push_back(m.wpool.upload(w2.data));
