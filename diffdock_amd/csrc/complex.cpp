@@ -197,12 +197,15 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         vs.built_goff = g.goff; vs.epoch = c.epoch;
       }
       const int* nvn = vs.voff + g.gcount;
+      // dense-row loop: groups with >= 20 edges per gather node (both row tiles of every virtual node are multiplied)
+      const bool dense_rows = m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount));
       if (fuse_mm) {
         PhaseTimer t(m, "k_edge_hidden", gs);
         EdgeHiddenArgs h{};
         h.nvn = nvn; h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
         h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = L.W1p[wg]; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
         h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb;
+        h.zero_fill = (!L.fgran_generic && !load_mode && dense_rows) ? 1 : 0;
         launch_edge_hidden_mm(h, gs);
       } else {
         PhaseTimer t(m, "k_edge_hidden", gs);
@@ -213,7 +216,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
       f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.gmap = L.gmap;
       f.ctab = L.ctab; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
-      f.dense = (m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount))) ? 1 : 0;
+      f.dense = dense_rows ? 1 : 0;
       // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
       int ys_req = m.fused_ysplit;
       if (ys_req <= 0) {

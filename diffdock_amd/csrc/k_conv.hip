@@ -509,7 +509,8 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
       float* __restrict__ hp = a.Hb + fc_hb_off(v, rt, 0, lane, NG8 / 2);   // + 256 per pair of 8-k groups
       const int el = 16 * rt + lr;
       const bool live = el < ne;
-      if (16 * rt >= ne) {   // empty row tile: zero fragments
+      if (16 * rt >= ne) {   // empty row tile: zero fragments where the consumer multiplies them
+        if (!a.zero_fill) continue;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<float4*>(hp + (size_t)nb * 256) = make_float4(0.f, 0.f, 0.f, 0.f);
         continue;

@@ -101,6 +101,7 @@ struct EdgeHiddenArgs {
   const float* Q;                     // [gcount][H]
   const float* rowbias; const int* ridx;   // optional per-graph term [B][H], graph of attr row
   int H, NG8;
+  int zero_fill;   // write zero fragments for empty row tiles (the dense-row loop multiplies them; the other loops skip them)
   float* Hb;
 };
 void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s);
