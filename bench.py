@@ -218,7 +218,7 @@ def main():
                                            "hidden + message rows; k_node_contract: node flops, Y written once.  With 2 streams the "
                                            "ligand-gather launches run concurrently with the receptor-gather ones, so the launch "
                                            "durations overlap (their sum exceeds the wall time); DDMI_STREAMS=1 serialises them"})
-            if roof["concurrent_streams"] == 2 and dom == "k_conv_fused":
+            if roof["concurrent_streams"] == 2 and dom == "k_conv_fused" and world == 1:
                 # the same kernel timed with the launches serialised on ONE stream (untimed extra pass, second handle):
                 # with two streams the launch durations overlap, so the figures above understate the kernel alone
                 os.environ["DDMI_STREAMS"] = "1"
@@ -235,7 +235,7 @@ def main():
                 roof["serialised"] = {"avg_launch_ms": ms1 / max(n1, 1), "launches": n1, "achieved": ach1,
                                       "frac": ach1 / MFMA_F32_PEAK_TFLOPS}
                 del m1
-        cpu = None if (args.no_cpu_baseline or args.all_atoms) else cpu_baseline(cfg, sd, so3_t, tor_t, g)
+        cpu = None if (args.no_cpu_baseline or args.all_atoms or world > 1) else cpu_baseline(cfg, sd, so3_t, tor_t, g)   # N = 1 only
         out = {
             "metric": "poses/sec (20 steps x 40 samples, DiffDock-L score model)" if not args.all_atoms else
                       "poses/sec (20 steps x 40 samples, all-atom score model -- secondary workload)",
