@@ -116,6 +116,38 @@ def test_no_cross_edges_and_ragged_batch(emu_lib):
         assert rel_err(a, b) < 1e-4
 
 
+@pytest.mark.parametrize("no_torsion", [False, True])
+def test_rigid_ligand_and_no_torsion_early_out(no_torsion, emu_lib):
+    """cg_model.py:404: a ligand without rotatable bonds, or `no_torsion`, returns (tr, rot, empty(0), None); the device loop
+    then runs the rigid-body update only (modify_conformer_batch with zero torsions)."""
+    from diffdock_amd.config import TINY
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = TINY.replace(no_torsion=no_torsion)
+    sd = init_state_dict(cfg, seed=5)
+    g = make_complex(seed=11, n_res=20, n_lig=8)
+    if not no_torsion:
+        g["ligand"].edge_mask = torch.zeros_like(g["ligand"].edge_mask)
+        g["ligand"].mask_rotate = [g["ligand"].mask_rotate[0][:0]]
+    dl = make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=3, no_torsion=no_torsion)
+    b = HeteroBatch.from_data_list(dl)
+    set_time(b, 0.5, 0.5, 0.5, 2)
+    so3_t, tor_t = tables()
+    ref = CGModelOracle(cfg, sd, so3_t, tor_t)(b)
+    m = make_model(cfg, sd, emu_lib)
+    tr, rot, tor, none = m(b)
+    assert none is None and ref[3] is None and tor.shape == (0,) and ref[2].shape == (0,)
+    assert rel_err(tr, ref[0]) < 1e-4 and rel_err(rot, ref[1]) < 1e-4
+    sched = get_t_schedule(3)
+    start = b["ligand"].pos.clone()
+    pos = m.sample_batch(b, 3, (sched, sched, sched), seed=1, no_final_step_noise=True)
+    assert pos.shape == start.shape and torch.isfinite(pos).all()
+    # rigid motion only: the intramolecular distances of every pose are those of the start conformer
+    for k in range(2):
+        a0, a1 = start.reshape(2, -1, 3)[k], pos.reshape(2, -1, 3)[k]
+        assert (torch.cdist(a0, a0) - torch.cdist(a1, a1)).abs().max() < 1e-3
+
+
 def test_errors_are_python_exceptions(emu_lib):
     from diffdock_amd.lib import DdmiError
     fx, cfg, data_list = fixture_case("tiny_l1")
