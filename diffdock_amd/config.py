@@ -65,7 +65,7 @@ class ModelConfig:
     confidence_mode: bool = False
     num_confidence_outputs: int = 1     # len(rmsd_classification_cutoff) + 1 when that is a list
     # get_model(..., old=True) (utils/utils.py:180-219): the legacy class models/old_cg_model.py -- what the released DiffDock-L
-    # confidence checkpoint is (`old_confidence_model: true`).  Built in confidence mode only; always sh_lmax = 2, one output.
+    # confidence checkpoint is (`old_confidence_model: true`).  Score and confidence mode; always sh_lmax = 2, one confidence output.
     old: bool = False
     use_old_atom_encoder: bool = True
 

@@ -30,6 +30,7 @@ struct Model::Cx {
   float* rec_node_base; int rec_base_dim = 0;
   // per forward
   float *temb, *hidB, *rec_sig, *ligsig, *ll_gvec, *cross_gvec, *center_gvec, *tr_sig, *rot_sig, *cutoff, *rr_rowbias;
+  float* rr_sig_old = nullptr;   // legacy classes: sigma term of the receptor edge embedding (old_cg_model.py:411-413)
   float* embsum;
   std::vector<float*> X;
   int *adjrank, *cnt_g, *cnt_t, *goff_ll, *toff_ll, *ll_tgt, *ll_tslot, *ll_featidx, *ll_batch;
@@ -490,6 +491,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.rec_sig = dalloc<float>(m, "rec_sig", {B, ns}); c.ligsig = dalloc<float>(m, nullptr, {B, ns});
   c.ll_gvec = dalloc<float>(m, nullptr, {B, ns}); c.cross_gvec = dalloc<float>(m, nullptr, {B, ns});
   c.center_gvec = dalloc<float>(m, nullptr, {B, ns}); c.tr_sig = dalloc<float>(m, nullptr, {B, ns});
+  c.rr_sig_old = dalloc<float>(m, nullptr, {B, ns});
   c.rot_sig = dalloc<float>(m, nullptr, {B, ns}); c.cutoff = dalloc<float>(m, "cross_cutoff", {B});
   c.rr_rowbias = dalloc<float>(m, nullptr, {B, H});
   c.embsum = dalloc<float>(m, nullptr, {nL, ns});
@@ -722,7 +724,59 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
 // models/old_cg_model.py:203-291 (CGOldModel.forward with confidence_mode): four separate OldTensorProductConvLayers per
 // interaction layer, each = fc + tensor product + its own mean + BatchNorm (tensor_layers.py:338-380), summed onto the
 // zero-padded node features.
-static void forward_old_confidence(Model& m, const float* lig_pos, const float* t_tr, float* conf_out, hipStream_t s) {
+// Score read-outs on the final ligand rows XL (cg_model.py:368-423 = old_cg_model.py:293-352): centre convolution ->
+// translation / rotation heads, torsion-bond convolution -> torsion head.
+static void score_readouts(Model& m, const float* XL, const float* lig_pos, const float* t_tr, const float* t_rot,
+                           const float* t_tor, float* tr_out, float* rot_out, float* tor_out, hipStream_t s) {
+  Cx& c = *m.cx;
+  const ddmi_config& cfg = m.cfg;
+  const int ns = m.ns, sd = m.sd, B = c.B, nL = c.nL;
+  // ---- translation / rotation heads (cg_model.py:368-395)
+  const ConvW& F = m.final_conv;
+  launch_center_edges(lig_pos, c.lig_batch, c.lig_ptr, B, nL, c.c_dist, c.c_nvec, s);
+  launch_edge_mlp(mlp_args(m.center_edge, ns, nL, nullptr, c.c_dist, m.off_center, m.D, m.coeff_center, 0, c.center_gvec,
+                           c.lig_batch, c.c_ea), s);
+  launch_gather_cols(c.c_attr, F.n_edge, 0, c.c_ea, ns, nullptr, nL, ns, nullptr, s);
+  // fixed_center_conv: scalars of the atom; otherwise the reference indexes the ligand table by GRAPH id (cg_model.py:371-374)
+  launch_gather_cols(c.c_attr, F.n_edge, ns, XL, XS, cfg.fixed_center_conv ? c.c_xrow : c.lig_batch, nL, ns, nullptr, s);
+  launch_sh_rows(c.c_nvec, 1.f, nL, cfg.sh_lmax, c.c_sh, F.sh_dim, s);
+  run_direct_conv(m, F, c.c_attr, nL, c.c_hid, c.c_W, c.c_xrow, XL, c.c_sh, nullptr, nullptr, 0, c.c_out, s);
+  launch_segment_mean_bn(c.c_out, F.D_out, c.lig_ptr, nullptr, 0, B, F.D_out, F.has_bn ? F.bn_mean : nullptr,
+                         F.has_bn ? F.bn_scale : nullptr, F.has_bn ? F.bn_bias : nullptr, c.gp, F.D_out, s);
+  {
+    ScoreHeadArgs a{};
+    a.B = B; a.gp = c.gp; a.odd_parity = cfg.odd_parity; a.scale_by_sigma = cfg.scale_by_sigma; a.ns = ns; a.ldw0 = 1 + sd;
+    a.tr_w0n = m.tr_final.W0; a.tr_sig = c.tr_sig; a.tr_w3 = m.tr_final.W3; a.tr_b3 = m.tr_final.b3;
+    a.rot_w0n = m.rot_final.W0; a.rot_sig = c.rot_sig; a.rot_w3 = m.rot_final.W3; a.rot_b3 = m.rot_final.b3;
+    a.t_tr = t_tr; a.t_rot = t_rot; a.tr_smin = cfg.tr_sigma_min; a.tr_smax = cfg.tr_sigma_max;
+    a.rot_smin = cfg.rot_sigma_min; a.rot_smax = cfg.rot_sigma_max; a.so3_table = m.so3_table; a.so3_n = m.so3_n;
+    a.tr_out = tr_out; a.rot_out = rot_out;
+    launch_score_heads(a, s);
+  }
+  // ---- torsion head (cg_model.py:404-423)
+  if (c.nT > 0 && tor_out) {
+    const ConvW& T = m.tor_conv;
+    launch_tor_radius(lig_pos, c.lig_ptr, c.tor_u, c.tor_v, c.tor_batch, c.nT, cfg.lig_max_radius, c.tor_cap,
+                      cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.t_cnt, c.t_atom, c.t_dist, c.t_nvec, c.t_ew, c.t_bond_nvec, s);
+    launch_edge_mlp(mlp_args(m.final_edge, ns, c.Et, nullptr, c.t_dist, m.off_lig, m.D, m.coeff_lig, 0, m.final_edge.b0,
+                             nullptr, c.t_ea), s);
+    launch_gather_cols(c.t_attr, T.n_edge, 0, c.t_ea, ns, nullptr, c.Et, ns, nullptr, s);
+    launch_gather_cols(c.t_attr, T.n_edge, ns, XL, XS, c.t_atom, c.Et, ns, nullptr, s);
+    launch_gather_cols(c.t_attr, T.n_edge, 2 * ns, XL, XS, c.tor_eu, c.Et, ns, c.tor_ev, s);
+    launch_tor_sh(c.t_nvec, c.t_bond_nvec, c.nT, c.tor_cap, cfg.sh_lmax, m.tor_T, m.tor_ds, m.tor_dts, c.t_sh, s);
+    run_direct_conv(m, T, c.t_attr, c.Et, c.t_hid, c.t_W, c.t_atom, XL, c.t_sh, c.t_ew, c.t_cnt, c.tor_cap, c.t_out, s);
+    launch_segment_mean_bn(c.t_out, T.D_out, nullptr, c.t_cnt, c.tor_cap, c.nT, T.D_out, T.has_bn ? T.bn_mean : nullptr,
+                           T.has_bn ? T.bn_scale : nullptr, T.has_bn ? T.bn_bias : nullptr, c.t_feat, T.D_out, s);
+    TorHeadArgs a{};
+    a.nT = c.nT; a.ns = ns; a.in_dim = T.D_out; a.feat = c.t_feat; a.W0 = m.tor_W0; a.W3 = m.tor_W3;
+    a.tor_batch = c.tor_batch; a.t_tor = t_tor; a.smin = cfg.tor_sigma_min; a.smax = cfg.tor_sigma_max;
+    a.scale_by_sigma = cfg.scale_by_sigma; a.torus_table = m.torus_table; a.torus_n = m.torus_n; a.out = tor_out;
+    launch_tor_head(a, s);
+  }
+}
+
+static void forward_old(Model& m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor, float* tr_out,
+                        float* rot_out, float* tor_out, float* conf_out, hipStream_t s) {
   Cx& c = *m.cx;
   const ddmi_config& cfg = m.cfg;
   const int ns = m.ns, sd = m.sd, B = c.B, nL = c.nL, nR = c.nR, Lc = cfg.num_conv_layers;
@@ -736,7 +790,13 @@ static void forward_old_confidence(Model& m, const float* lig_pos, const float* 
   else gemm(c.temb, sd, m.old_rec_lin.W0, sd, m.old_rec_lin.b0, c.rec_sig, ns, B, ns, sd, 0, s);
   gemm(c.temb, sd, m.lig_edge.W0 + m.nf, m.lig_edge.in, m.lig_edge.b0, c.ll_gvec, ns, B, ns, sd, 0, s);
   gemm(c.temb, sd, m.cross_edge.W0, m.cross_edge.in, m.cross_edge.b0, c.cross_gvec, ns, B, ns, sd, 0, s);
-  gemm(c.temb, sd, m.rec_edge.W0, m.rec_edge.in, m.rec_edge.b0, c.center_gvec, ns, B, ns, sd, 0, s);   // receptor-edge sigma term
+  gemm(c.temb, sd, m.rec_edge.W0, m.rec_edge.in, m.rec_edge.b0, c.rr_sig_old, ns, B, ns, sd, 0, s);   // receptor-edge sigma term
+  const bool conf = cfg.confidence_mode != 0;
+  if (!conf) {   // sigma terms of the read-outs (old_cg_model.py:294-296,313-315)
+    gemm(c.temb, sd, m.center_edge.W0 + m.D, m.center_edge.in, m.center_edge.b0, c.center_gvec, ns, B, ns, sd, 0, s);
+    gemm(c.temb, sd, m.tr_final.W0 + 1, 1 + sd, m.tr_final.b0, c.tr_sig, ns, B, ns, sd, 0, s);
+    gemm(c.temb, sd, m.rot_final.W0 + 1, 1 + sd, m.rot_final.b0, c.rot_sig, ns, B, ns, sd, 0, s);
+  }
   float* X0 = c.X[0];
   launch_lig_node_embed(c.lig_x, nL, m.lig_emb, m.lig_emb_off, 16, ns, c.embsum, s);
   launch_add_rowvec(X0, XS, c.embsum, ns, c.ligsig, ns, c.lig_batch, nL, ns, ns, s);
@@ -755,11 +815,12 @@ static void forward_old_confidence(Model& m, const float* lig_pos, const float* 
     a.feat = c.bond_attr; a.featidx = c.ll_featidx; a.nfeat = m.nf; a.W0f = m.lig_edge.W0; a.ldw0f = m.lig_edge.in;
     launch_edge_mlp(a, s);
   }
-  launch_edge_mlp(mlp_args(m.rec_edge, ns, c.Err, nullptr, c.rr_dist, m.off_rec, m.D, m.coeff_rec, sd, c.center_gvec, c.rr_batch,
+  launch_edge_mlp(mlp_args(m.rec_edge, ns, c.Err, nullptr, c.rr_dist, m.off_rec, m.D, m.coeff_rec, sd, c.rr_sig_old, c.rr_batch,
                            c.rec_edge_base), s);
   const float* cut_dev = nullptr;
   if (cfg.dynamic_max_cross) {
-    launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, s, 1);
+    // confidence mode feeds the raw t as sigma (old_cg_model.py:207-210), score mode t_to_sigma(t)
+    launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, s, conf ? 1 : 0);
     cut_dev = c.cutoff;
   }
   launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
@@ -797,6 +858,10 @@ static void forward_old_confidence(Model& m, const float* lig_pos, const float* 
     launch_add3(c.X[l + 1], Xin, L.D_in, Ua, Ub, last ? nL : nL + nR, L.D_out, s);
   }
   PhaseTimer t_read(m, "readouts", s);
+  if (!conf) {
+    score_readouts(m, c.X[Lc], lig_pos, t_tr, t_rot, t_tor, tr_out, rot_out, tor_out, s);
+    return;
+  }
   ConfHeadArgs a{};
   a.B = B; a.X = c.X[Lc]; a.lig_ptr = c.lig_ptr; a.ns = ns;
   a.n_tail = Lc >= 3 ? ns : 0;
@@ -813,9 +878,9 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   DDMI_REQUIRE(m.has_complex, DDMI_ERR_STATE, "ddmi_set_complex must precede ddmi_forward");
   const bool conf = m.cfg.confidence_mode != 0;
   DDMI_REQUIRE(conf == (conf_out != nullptr), DDMI_ERR_STATE, "score models use ddmi_forward, confidence models ddmi_confidence");
-  if (m.cfg.old_model) { forward_old_confidence(m, lig_pos, t_tr, conf_out, s); return; }
   DDMI_REQUIRE(conf || !m.cfg.scale_by_sigma || (m.so3_table && (m.cfg.no_torsion || m.torus_table)), DDMI_ERR_STATE,
                "score-norm tables not set (ddmi_set_table)");
+  if (m.cfg.old_model) { forward_old(m, lig_pos, t_tr, t_rot, t_tor, tr_out, rot_out, tor_out, conf_out, s); return; }
   Cx& c = *m.cx;
   const ddmi_config& cfg = m.cfg;
   const int ns = m.ns, sd = m.sd, B = c.B, nL = c.nL, nR = c.nR;
@@ -971,48 +1036,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     launch_conf_head(a, s);
     return;
   }
-  // ---- translation / rotation heads (cg_model.py:368-395)
-  const ConvW& F = m.final_conv;
-  launch_center_edges(lig_pos, c.lig_batch, c.lig_ptr, B, nL, c.c_dist, c.c_nvec, s);
-  launch_edge_mlp(mlp_args(m.center_edge, ns, nL, nullptr, c.c_dist, m.off_center, m.D, m.coeff_center, 0, c.center_gvec,
-                           c.lig_batch, c.c_ea), s);
-  launch_gather_cols(c.c_attr, F.n_edge, 0, c.c_ea, ns, nullptr, nL, ns, nullptr, s);
-  // fixed_center_conv: scalars of the atom; otherwise the reference indexes the ligand table by GRAPH id (cg_model.py:371-374)
-  launch_gather_cols(c.c_attr, F.n_edge, ns, XL, XS, cfg.fixed_center_conv ? c.c_xrow : c.lig_batch, nL, ns, nullptr, s);
-  launch_sh_rows(c.c_nvec, 1.f, nL, cfg.sh_lmax, c.c_sh, F.sh_dim, s);
-  run_direct_conv(m, F, c.c_attr, nL, c.c_hid, c.c_W, c.c_xrow, XL, c.c_sh, nullptr, nullptr, 0, c.c_out, s);
-  launch_segment_mean_bn(c.c_out, F.D_out, c.lig_ptr, nullptr, 0, B, F.D_out, F.has_bn ? F.bn_mean : nullptr,
-                         F.has_bn ? F.bn_scale : nullptr, F.has_bn ? F.bn_bias : nullptr, c.gp, F.D_out, s);
-  {
-    ScoreHeadArgs a{};
-    a.B = B; a.gp = c.gp; a.odd_parity = cfg.odd_parity; a.scale_by_sigma = cfg.scale_by_sigma; a.ns = ns; a.ldw0 = 1 + sd;
-    a.tr_w0n = m.tr_final.W0; a.tr_sig = c.tr_sig; a.tr_w3 = m.tr_final.W3; a.tr_b3 = m.tr_final.b3;
-    a.rot_w0n = m.rot_final.W0; a.rot_sig = c.rot_sig; a.rot_w3 = m.rot_final.W3; a.rot_b3 = m.rot_final.b3;
-    a.t_tr = t_tr; a.t_rot = t_rot; a.tr_smin = cfg.tr_sigma_min; a.tr_smax = cfg.tr_sigma_max;
-    a.rot_smin = cfg.rot_sigma_min; a.rot_smax = cfg.rot_sigma_max; a.so3_table = m.so3_table; a.so3_n = m.so3_n;
-    a.tr_out = tr_out; a.rot_out = rot_out;
-    launch_score_heads(a, s);
-  }
-  // ---- torsion head (cg_model.py:404-423)
-  if (c.nT > 0 && tor_out) {
-    const ConvW& T = m.tor_conv;
-    launch_tor_radius(lig_pos, c.lig_ptr, c.tor_u, c.tor_v, c.tor_batch, c.nT, cfg.lig_max_radius, c.tor_cap,
-                      cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.t_cnt, c.t_atom, c.t_dist, c.t_nvec, c.t_ew, c.t_bond_nvec, s);
-    launch_edge_mlp(mlp_args(m.final_edge, ns, c.Et, nullptr, c.t_dist, m.off_lig, m.D, m.coeff_lig, 0, m.final_edge.b0,
-                             nullptr, c.t_ea), s);
-    launch_gather_cols(c.t_attr, T.n_edge, 0, c.t_ea, ns, nullptr, c.Et, ns, nullptr, s);
-    launch_gather_cols(c.t_attr, T.n_edge, ns, XL, XS, c.t_atom, c.Et, ns, nullptr, s);
-    launch_gather_cols(c.t_attr, T.n_edge, 2 * ns, XL, XS, c.tor_eu, c.Et, ns, c.tor_ev, s);
-    launch_tor_sh(c.t_nvec, c.t_bond_nvec, c.nT, c.tor_cap, cfg.sh_lmax, m.tor_T, m.tor_ds, m.tor_dts, c.t_sh, s);
-    run_direct_conv(m, T, c.t_attr, c.Et, c.t_hid, c.t_W, c.t_atom, XL, c.t_sh, c.t_ew, c.t_cnt, c.tor_cap, c.t_out, s);
-    launch_segment_mean_bn(c.t_out, T.D_out, nullptr, c.t_cnt, c.tor_cap, c.nT, T.D_out, T.has_bn ? T.bn_mean : nullptr,
-                           T.has_bn ? T.bn_scale : nullptr, T.has_bn ? T.bn_bias : nullptr, c.t_feat, T.D_out, s);
-    TorHeadArgs a{};
-    a.nT = c.nT; a.ns = ns; a.in_dim = T.D_out; a.feat = c.t_feat; a.W0 = m.tor_W0; a.W3 = m.tor_W3;
-    a.tor_batch = c.tor_batch; a.t_tor = t_tor; a.smin = cfg.tor_sigma_min; a.smax = cfg.tor_sigma_max;
-    a.scale_by_sigma = cfg.scale_by_sigma; a.torus_table = m.torus_table; a.torus_n = m.torus_n; a.out = tor_out;
-    launch_tor_head(a, s);
-  }
+  score_readouts(m, XL, lig_pos, t_tr, t_rot, t_tor, tr_out, rot_out, tor_out, s);
 }
 
 // ========================================================================= conformer / sampling

@@ -115,9 +115,29 @@ void build_weight_spec(Model& m) {
   const Irreps sh = sh_irreps(c.sh_lmax);
   const bool faster = c.sh_lmax == 1 && !c.use_second_order_repr;
   const int K = c.num_prot_emb_layers, Lc = c.num_conv_layers;
-  if (c.old_model) {   // models/old_cg_model.py:18-160 (confidence mode), models/layers.py:70-118, models/tensor_layers.py:338-380
-    DDMI_REQUIRE(c.confidence_mode && c.sh_lmax == 2 && !c.all_atoms && K == 0, DDMI_ERR_ARG,
-                 "legacy class: confidence mode, sh_lmax = 2, CG graphs, no embedding layers");
+  // score read-outs (cg_model.py:209-255, old_cg_model.py:156-200: the same modules in both class families)
+  auto readout_spec = [&](const Irreps& last_out) {
+    S.push_back({"center_distance_expansion.offset", {m.D}});
+    mlp("center_edge_embedding", m.D + sd, ns, ns);
+    const Irreps fout = c.odd_parity ? make_irreps({{1, 1, -1}, {1, 1, 1}}) : make_irreps({{2, 1, -1}, {2, 1, 1}});
+    init_conv_meta(c, m.final_conv, "final_conv", last_out, sh, fout, 2 * ns, 1, false, false, false);
+    conv(m.final_conv);
+    mlp("tr_final_layer", 1 + sd, ns, 1);
+    mlp("rot_final_layer", 1 + sd, ns, 1);
+    if (!c.no_torsion) {
+      mlp("final_edge_embedding", m.D, ns, ns);
+      Irreps tor_sh;
+      full_tp_dense(sh, make_irreps({{1, 2, 1}}), &tor_sh);
+      const Irreps tout = c.odd_parity ? make_irreps({{ns, 0, -1}}) : make_irreps({{ns, 0, -1}, {ns, 0, 1}});
+      init_conv_meta(c, m.tor_conv, "tor_bond_conv", last_out, tor_sh, tout, 3 * ns, 1, false, false, false);
+      conv(m.tor_conv);
+      lin("tor_final_layer.0", c.odd_parity ? ns : 2 * ns, ns, false);
+      lin("tor_final_layer.3", ns, 1, false);
+    }
+  };
+  if (c.old_model) {   // models/old_cg_model.py:18-200, models/layers.py:70-118, models/tensor_layers.py:338-380
+    DDMI_REQUIRE(c.sh_lmax == 2 && !c.all_atoms && K == 0, DDMI_ERR_ARG,
+                 "legacy class: sh_lmax = 2, CG graphs, no embedding layers");
     auto old_encoder = [&](const std::string& n, const int* dims, int nd, bool lm) {
       for (int i = 0; i < nd; ++i) S.push_back({n + ".atom_embedding_list." + std::to_string(i) + ".weight", {dims[i], ns}});
       lin(n + ".linear", sd, ns);
@@ -143,6 +163,10 @@ void build_weight_spec(Model& m) {
                        false, false, true);
         conv((*fams[f])[l]);
       }
+    }
+    if (!c.confidence_mode) {   // score mode of the legacy class: the read-outs of old_cg_model.py:156-200
+      readout_spec(layer_irreps(co, Lc));
+      return;
     }
     lin("confidence_predictor.0", Lc >= 3 ? 2 * ns : ns, ns);
     lin("confidence_predictor.4", ns, ns);
@@ -203,23 +227,7 @@ void build_weight_spec(Model& m) {
         S.push_back({"confidence_predictor." + std::to_string(i) + k, {ns}});
     return;
   }
-  S.push_back({"center_distance_expansion.offset", {m.D}});
-  mlp("center_edge_embedding", m.D + sd, ns, ns);
-  const Irreps fout = c.odd_parity ? make_irreps({{1, 1, -1}, {1, 1, 1}}) : make_irreps({{2, 1, -1}, {2, 1, 1}});
-  init_conv_meta(c, m.final_conv, "final_conv", last_out, sh, fout, 2 * ns, 1, false, false, false);
-  conv(m.final_conv);
-  mlp("tr_final_layer", 1 + sd, ns, 1);
-  mlp("rot_final_layer", 1 + sd, ns, 1);
-  if (!c.no_torsion) {
-    mlp("final_edge_embedding", m.D, ns, ns);
-    Irreps tor_sh;
-    full_tp_dense(sh, make_irreps({{1, 2, 1}}), &tor_sh);
-    const Irreps tout = c.odd_parity ? make_irreps({{ns, 0, -1}}) : make_irreps({{ns, 0, -1}, {ns, 0, 1}});
-    init_conv_meta(c, m.tor_conv, "tor_bond_conv", last_out, tor_sh, tout, 3 * ns, 1, false, false, false);
-    conv(m.tor_conv);
-    lin("tor_final_layer.0", c.odd_parity ? ns : 2 * ns, ns, false);
-    lin("tor_final_layer.3", ns, 1, false);
-  }
+  readout_spec(last_out);
 }
 
 // ------------------------------------------------------------------------------ commit
@@ -458,6 +466,27 @@ static void commit_conv(Model& m, ConvW& L) {
   }
 }
 
+// score read-outs of both class families: centre convolution, translation / rotation heads, torsion convolution + head
+static void commit_readouts(Model& m) {
+  const ddmi_config& c = m.cfg;
+  m.center_edge = up_mlp(m, "center_edge_embedding");
+  m.tr_final = up_mlp(m, "tr_final_layer");
+  m.rot_final = up_mlp(m, "rot_final_layer");
+  commit_conv(m, m.final_conv);
+  if (!c.no_torsion) {
+    m.final_edge = up_mlp(m, "final_edge_embedding");
+    commit_conv(m, m.tor_conv);
+    m.tor_W0 = up(m, "tor_final_layer.0.weight");
+    m.tor_W3 = up(m, "tor_final_layer.3.weight");
+    Irreps tsh;
+    std::vector<double> T = full_tp_dense(sh_irreps(c.sh_lmax), make_irreps({{1, 2, 1}}), &tsh);
+    std::vector<float> Tf(T.begin(), T.end());
+    m.tor_T = m.wpool.upload(Tf);
+    m.tor_ds = (c.sh_lmax + 1) * (c.sh_lmax + 1);
+    m.tor_dts = irreps_dim(tsh);
+  }
+}
+
 void commit_weights(Model& m) {
   for (auto& kv : m.spec) {
     auto it = m.host_w.find(kv.first);
@@ -492,16 +521,18 @@ void commit_weights(Model& m) {
     m.lig_edge = up_mlp(m, "lig_edge_embedding");
     m.rec_edge = up_mlp(m, "rec_edge_embedding");
     m.cross_edge = up_mlp(m, "cross_edge_embedding");
-    for (int i = 0; i < 3; ++i) {
-      m.conf_W[i] = up(m, "confidence_predictor." + std::to_string(4 * i) + ".weight");
-      m.conf_b[i] = up(m, "confidence_predictor." + std::to_string(4 * i) + ".bias");
-    }
-    for (int i = 0; i < 2; ++i) {
-      const std::string n = "confidence_predictor." + std::to_string(4 * i + 1);
-      const HostTensor &w = W(m, n + ".weight"), &b = W(m, n + ".bias"), &rm = W(m, n + ".running_mean"), &rv = W(m, n + ".running_var");
-      std::vector<float> sc(m.ns), sh(m.ns);
-      for (int k = 0; k < m.ns; ++k) { sc[k] = w.data[k] / std::sqrt(rv.data[k] + 1e-5f); sh[k] = b.data[k] - rm.data[k] * sc[k]; }
-      m.conf_bn_scale[i] = m.wpool.upload(sc); m.conf_bn_shift[i] = m.wpool.upload(sh);
+    if (c.confidence_mode) {
+      for (int i = 0; i < 3; ++i) {
+        m.conf_W[i] = up(m, "confidence_predictor." + std::to_string(4 * i) + ".weight");
+        m.conf_b[i] = up(m, "confidence_predictor." + std::to_string(4 * i) + ".bias");
+      }
+      for (int i = 0; i < 2; ++i) {
+        const std::string n = "confidence_predictor." + std::to_string(4 * i + 1);
+        const HostTensor &w = W(m, n + ".weight"), &b = W(m, n + ".bias"), &rm = W(m, n + ".running_mean"), &rv = W(m, n + ".running_var");
+        std::vector<float> sc(m.ns), sh(m.ns);
+        for (int k = 0; k < m.ns; ++k) { sc[k] = w.data[k] / std::sqrt(rv.data[k] + 1e-5f); sh[k] = b.data[k] - rm.data[k] * sc[k]; }
+        m.conf_bn_scale[i] = m.wpool.upload(sc); m.conf_bn_shift[i] = m.wpool.upload(sh);
+      }
     }
     auto offs_old = [&](const std::string& k, float*& dev, float& coeff) {
       const HostTensor& t = W(m, k);
@@ -515,6 +546,10 @@ void commit_weights(Model& m) {
     offs_old("cross_distance_expansion.offset", m.off_cross, m.coeff_cross);
     for (auto* fam : {&m.old_lig, &m.old_rec, &m.old_l2r, &m.old_r2l})
       for (auto& L : *fam) commit_conv(m, L);
+    if (!c.confidence_mode) {
+      offs_old("center_distance_expansion.offset", m.off_center, m.coeff_center);
+      commit_readouts(m);
+    }
     const int half = m.sd / 2;
     if ((int)m.time_freq_host.size() != half) {
       m.time_freq_host.resize(half);
@@ -564,10 +599,6 @@ void commit_weights(Model& m) {
       }
       m.conf_bn_scale[i] = m.wpool.upload(sc); m.conf_bn_shift[i] = m.wpool.upload(sh);
     }
-  } else {
-    m.center_edge = up_mlp(m, "center_edge_embedding");
-    m.tr_final = up_mlp(m, "tr_final_layer");
-    m.rot_final = up_mlp(m, "rot_final_layer");
   }
   auto offs = [&](const std::string& k, float*& dev, float& coeff) {
     const HostTensor& t = W(m, k);
@@ -583,19 +614,7 @@ void commit_weights(Model& m) {
   for (auto& L : m.rec_emb_layers) commit_conv(m, L);
   for (auto& L : m.lig_emb_layers) commit_conv(m, L);
   for (auto& L : m.conv_layers) commit_conv(m, L);
-  if (!c.confidence_mode) commit_conv(m, m.final_conv);
-  if (!c.no_torsion && !c.confidence_mode) {
-    m.final_edge = up_mlp(m, "final_edge_embedding");
-    commit_conv(m, m.tor_conv);
-    m.tor_W0 = up(m, "tor_final_layer.0.weight");
-    m.tor_W3 = up(m, "tor_final_layer.3.weight");
-    Irreps tsh;
-    std::vector<double> T = full_tp_dense(sh_irreps(c.sh_lmax), make_irreps({{1, 2, 1}}), &tsh);
-    std::vector<float> Tf(T.begin(), T.end());
-    m.tor_T = m.wpool.upload(Tf);
-    m.tor_ds = (c.sh_lmax + 1) * (c.sh_lmax + 1);
-    m.tor_dts = irreps_dim(tsh);
-  }
+  if (!c.confidence_mode) commit_readouts(m);
   // sinusoidal embedding frequencies (utils/diffusion_utils.py:101-103) unless supplied by the caller
   const int half = m.sd / 2;
   if ((int)m.time_freq_host.size() != half) {

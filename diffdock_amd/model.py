@@ -183,6 +183,8 @@ class MIScoreModel:
         tor = torch.empty(0 if no_tor else self._n_tor, device=dev)
         _lib.check(self.lib, self.lib.ddmi_forward(self._h, _ptr(pos), _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(tr),
                                                    _ptr(rot), None if no_tor else _ptr(tor), self._stream()))
+        if self.cfg.old:   # the legacy class returns a 3-tuple (old_cg_model.py:329,352)
+            return tr, rot, tor
         return tr, rot, tor, None
 
     forward = __call__
@@ -261,10 +263,10 @@ def get_model(args, device, t_to_sigma=None, no_parallel=True, confidence_mode=F
     in-library from the sigma bounds in `args`."""
     cfg = args if isinstance(args, ModelConfig) else config_from_args(args)
     if old:   # utils/utils.py:180-219: CGOldModel; no sh_lmax / embedding-layer / pseudoscalar arguments reach it
-        if not confidence_mode or cfg.all_atoms:
-            raise NotImplementedError("the legacy classes are built in confidence mode on CG graphs only (models/old_cg_model.py)")
-        cfg = cfg.replace(old=True, confidence_mode=True, sh_lmax=2, num_prot_emb_layers=0, reduce_pseudoscalars=False,
-                          num_confidence_outputs=1,
+        if cfg.all_atoms:
+            raise NotImplementedError("the legacy classes are built on CG graphs only (models/old_cg_model.py)")
+        cfg = cfg.replace(old=True, confidence_mode=bool(confidence_mode), sh_lmax=2, num_prot_emb_layers=0,
+                          reduce_pseudoscalars=False, num_confidence_outputs=1,
                           use_old_atom_encoder=getattr(args, "use_old_atom_encoder", True) if not isinstance(args, ModelConfig)
                           else cfg.use_old_atom_encoder)
         if not cfg.use_old_atom_encoder:

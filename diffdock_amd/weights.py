@@ -69,7 +69,7 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
             bn(f"{name}.batch_norm", out_irr)
 
     if cfg.old:
-        return _old_confidence_spec(cfg, spec, lin, mlp, bn)
+        return _old_spec(cfg, spec, lin, mlp, bn, conv)
     sh = sh_irreps(cfg.sh_lmax)
     encoder("lig_node_embedding", LIG_FEATURE_DIMS, sd)
     mlp("lig_edge_embedding", cfg.in_lig_edge_features + sd + cfg.distance_embed_dim, ns, ns)
@@ -114,6 +114,13 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
             spec[f"confidence_predictor.{i}.running_mean"] = ((ns,), "bn_mean")
             spec[f"confidence_predictor.{i}.running_var"] = ((ns,), "bn_var")
         return spec
+    _readout_spec(cfg, spec, lin, mlp, conv, last_out, sh)
+    return spec
+
+
+def _readout_spec(cfg, spec, lin, mlp, conv, last_out, sh):
+    """Score read-outs, the same modules in both class families (cg_model.py:209-255, old_cg_model.py:156-200)."""
+    ns, sd = cfg.ns, cfg.sigma_embed_dim
     spec["center_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:center")
     mlp("center_edge_embedding", cfg.distance_embed_dim + sd, ns, ns)
     conv("final_conv", last_out, sh, final_conv_out(cfg), 2 * ns, 2 * ns, 1, False)
@@ -124,13 +131,12 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
         conv("tor_bond_conv", last_out, tor_sh_irreps(cfg), tor_conv_out(cfg), 3 * ns, 3 * ns, 1, False)
         lin("tor_final_layer.0", 2 * ns if not cfg.odd_parity else ns, ns, bias=False)
         lin("tor_final_layer.3", ns, 1, bias=False)
-    return spec
 
 
-def _old_confidence_spec(cfg, spec, lin, mlp, bn):
-    """models/old_cg_model.py:18-160 in confidence mode (CGOldModel + OldAtomEncoder + OldTensorProductConvLayer)."""
-    assert cfg.confidence_mode and cfg.use_old_atom_encoder and cfg.sh_lmax == 2 and not cfg.all_atoms, \
-        "legacy class: confidence mode, OldAtomEncoder, sh_lmax = 2 (get_model(old=True) passes no sh_lmax), CG graphs"
+def _old_spec(cfg, spec, lin, mlp, bn, conv):
+    """models/old_cg_model.py:18-200 (CGOldModel + OldAtomEncoder + OldTensorProductConvLayer), score or confidence mode."""
+    assert cfg.use_old_atom_encoder and cfg.sh_lmax == 2 and not cfg.all_atoms, \
+        "legacy class: OldAtomEncoder, sh_lmax = 2 (get_model(old=True) passes no sh_lmax), CG graphs"
     ns, sd = cfg.ns, cfg.sigma_embed_dim
 
     def old_encoder(name, dims, lm):
@@ -157,6 +163,9 @@ def _old_confidence_spec(cfg, spec, lin, mlp, bn):
             lin(f"{fam}.{l}.fc.3", 3 * ns, W)
             if cfg.batch_norm:
                 bn(f"{fam}.{l}.batch_norm", b)
+    if not cfg.confidence_mode:
+        _readout_spec(old_cfg, spec, lin, mlp, conv, old_cfg.layer_irreps(cfg.num_conv_layers - 1)[1], sh)
+        return spec
     lin("confidence_predictor.0", 2 * ns if cfg.num_conv_layers >= 3 else ns, ns)
     lin("confidence_predictor.4", ns, ns)
     lin("confidence_predictor.8", ns, 1)

@@ -1,5 +1,5 @@
-"""Oracle restatement of the LEGACY score-model class in confidence mode: models/old_cg_model.py CGOldModel.forward
-:203-291 (with OldAtomEncoder models/layers.py:70-118 and OldTensorProductConvLayer models/tensor_layers.py:338-380) --
+"""Oracle restatement of the LEGACY score-model class: models/old_cg_model.py CGOldModel.forward :203-352, in
+confidence mode (:203-291) and in score mode (read-outs :293-352, the same modules as the new classes) (with OldAtomEncoder models/layers.py:70-118 and OldTensorProductConvLayer models/tensor_layers.py:338-380) --
 the class `get_model(..., old=True, confidence_mode=True)` builds, i.e. what `old_confidence_model: true` in
 default_inference_args.yaml selects for the released DiffDock-L confidence checkpoint.
 
@@ -17,14 +17,15 @@ Differences from the new classes that the restatement keeps literally:
 import torch
 
 from .cg_model import CGModelOracle
-from .e3nn_lite import Irreps
+from .e3nn_lite import FullTensorProduct, Irreps
 from .layers import TPConv, linear, mlp2
 
 
-class CGOldConfidenceOracle(CGModelOracle):
+class CGOldOracle(CGModelOracle):
     def __init__(self, cfg, state_dict, so3_table=None, torus_table=None, dtype=torch.float32):
-        assert cfg.old and cfg.confidence_mode and cfg.sh_lmax == 2
+        assert cfg.old and cfg.sh_lmax == 2
         self.cfg, self.dtype = cfg, dtype
+        self.so3_table, self.torus_table = so3_table, torus_table
         self.sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in state_dict.items()}
         self.sh_irreps = Irreps.spherical_harmonics(2)
         seq_cfg = cfg.replace(reduce_pseudoscalars=False)
@@ -35,6 +36,15 @@ class CGOldConfidenceOracle(CGModelOracle):
         self.rec_conv = [mk("rec_conv_layers", l) for l in range(L)]
         self.l2r_conv = [mk("lig_to_rec_conv_layers", l) for l in range(L)]
         self.r2l_conv = [mk("rec_to_lig_conv_layers", l) for l in range(L)]
+        if not cfg.confidence_mode:   # old_cg_model.py:156-200
+            last_out = seq_cfg.layer_irreps(L - 1)[1]
+            self.final_conv = TPConv(self.sd, "final_conv", last_out, self.sh_irreps,
+                                     "2x1o + 2x1e" if not cfg.odd_parity else "1x1o + 1x1e", residual=False, batch_norm=cfg.batch_norm)
+            if not cfg.no_torsion:
+                self.final_tp_tor = FullTensorProduct(self.sh_irreps, "2e")
+                self.tor_bond_conv = TPConv(self.sd, "tor_bond_conv", last_out, self.final_tp_tor.irreps_out,
+                                            f"{cfg.ns}x0o + {cfg.ns}x0e" if not cfg.odd_parity else f"{cfg.ns}x0o",
+                                            residual=False, batch_norm=cfg.batch_norm)
 
     def old_atom_encoder(self, name, x, n_cat, lm_dim):
         sd, c = self.sd, self.cfg
@@ -60,14 +70,14 @@ class CGOldConfidenceOracle(CGModelOracle):
 
     def __call__(self, data, return_intermediates=False):
         c, sd, ns = self.cfg, self.sd, self.cfg.ns
-        tr_t = data.complex_t["tr"]
+        tr_sigma, rot_sigma, tor_sigma = self._sigmas(data)     # raw t in confidence mode, t_to_sigma(t) in score mode (:207-210)
         lig_node_attr, lig_ei, lig_edge_attr, lig_sh, lig_ew = self.build_lig_conv_graph(data)
         lig_node_attr = self.old_atom_encoder("lig_node_embedding", lig_node_attr, 16, 0)
         lig_edge_attr = mlp2(sd, "lig_edge_embedding", lig_edge_attr)
         rec_node_attr, rec_ei, rec_edge_attr, rec_sh, rec_ew = self.build_rec_conv_graph_old(data)
         rec_node_attr = self.old_atom_encoder("rec_node_embedding", rec_node_attr, 1, c.lm_embedding_dim)
         rec_edge_attr = mlp2(sd, "rec_edge_embedding", rec_edge_attr)
-        cutoff = (tr_t * 3 + 20).unsqueeze(1).to(self.dtype) if c.dynamic_max_cross else c.cross_max_distance
+        cutoff = (tr_sigma * 3 + 20).unsqueeze(1).to(self.dtype) if c.dynamic_max_cross else c.cross_max_distance
         lr_ei, lr_edge_attr, lr_sh, _, lr_ew = self.build_cross_conv_graph(data, cutoff)
         lr_edge_attr = mlp2(sd, "cross_edge_embedding", lr_edge_attr)
         cross_lig, cross_rec = lr_ei
@@ -90,6 +100,9 @@ class CGOldConfidenceOracle(CGModelOracle):
                 rec_node_attr = pad(rec_node_attr, rec_intra.shape[-1]) + rec_intra + rl
             if inter is not None:
                 inter[f"lig{l + 1}"], inter[f"rec{l + 1}"] = lig_node_attr.clone(), rec_node_attr.clone()
+        if not c.confidence_mode:   # the legacy class returns a 3-tuple (:329,352)
+            out = self._readouts(data, lig_node_attr, tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates)
+            return out[:3] + (out[4:] if return_intermediates else ())
         x = torch.cat([lig_node_attr[:, :ns], lig_node_attr[:, -ns:]], 1) if L >= 3 else lig_node_attr[:, :ns]
         batch = data["ligand"].batch
         x = torch.zeros(data.num_graphs, x.shape[1], dtype=x.dtype).index_add_(0, batch, x) / \
@@ -103,3 +116,6 @@ class CGOldConfidenceOracle(CGModelOracle):
         x = torch.relu(bn1d(5, lin(4, x)))
         out = lin(8, x).squeeze(dim=-1)
         return (out, inter) if return_intermediates else out
+
+
+CGOldConfidenceOracle = CGOldOracle   # earlier name (confidence mode only)

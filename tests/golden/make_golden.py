@@ -157,6 +157,9 @@ def main():
     cases["tiny_oldconf_2l"] = dict(cfg=TINY.replace(old=True, confidence_mode=True, sh_lmax=2, num_conv_layers=2,
                                                       lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=25.0),
                                     n_res=22, n_lig=9, n_samples=2, seed=11, t=0.3)
+    # the same legacy class in score mode (get_model(old=True, confidence_mode=False)): read-outs old_cg_model.py:293-352
+    cases["tiny_oldscore"] = dict(cfg=TINY.replace(old=True, confidence_mode=False, sh_lmax=2, num_conv_layers=3), n_res=26, n_lig=10,
+                                  n_samples=3, seed=12, t=0.45)
     if len(sys.argv) > 1:
         cases = {k: v for k, v in cases.items() if k in sys.argv[1:]}
     for name, c in cases.items():
@@ -196,7 +199,7 @@ def main():
             torch.save(fixture, os.path.join(HERE, f"{name}.pt"))
             print(name, "confidence", fixture["forward"]["confidence"].tolist())
             continue
-        tr, rot, tor, _ = out
+        tr, rot, tor = out[:3]   # the legacy class returns a 3-tuple
         fixture["forward"] = {"tr": tr, "rot": rot, "tor": tor, "conv_out": layer_out}
 
         # ---- reference sampling() with recorded Gaussian draws

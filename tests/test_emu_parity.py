@@ -252,6 +252,27 @@ def test_legacy_confidence_class_matches_reference_fixture(name, emu_lib, monkey
         assert rel_err(conf, fx["forward"]["confidence"]) < 1e-4
 
 
+def test_legacy_class_score_mode_matches_reference_fixture(emu_lib, monkeypatch):
+    """models/old_cg_model.py in score mode (get_model(old=True, confidence_mode=False)): 3-tuple scores and the device loop
+    against the reference-executed fixture; fused and unfused kernels."""
+    fx, cfg, data_list = fixture_case("tiny_oldscore")
+    s = fx["sampling"]
+    B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DDMI_FUSED", fused)
+        m = make_model(cfg, fx["state_dict"], emu_lib)
+        batch = HeteroBatch.from_data_list(data_list)
+        set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+        out = m(batch)
+        assert len(out) == 3
+        for mine, key in zip(out, ("tr", "rot", "tor")):
+            assert mine.shape == fx["forward"][key].shape and rel_err(mine, fx["forward"][key]) < 1e-4, key
+        sched = get_t_schedule(s["steps"])
+        pos = m.sample_batch(HeteroBatch.from_data_list(data_list), s["steps"], (sched, sched, sched),
+                             noise=split_draws(s["draws"], s["steps"], B, R), no_final_step_noise=True, **s["temp"])
+        assert (pos.reshape(B, -1, 3) - s["final_pos"]).abs().max() < 2e-3
+
+
 def test_sampling_calls_confidence_model(emu_lib):
     """sampling(..., confidence_model=...) (utils/sampling.py:208-231): confidences of the final poses, both with separate
     confidence graphs (t = 0) and on the sampling batch itself (last step's t), against the oracle on the returned poses."""

@@ -156,6 +156,24 @@ def test_legacy_confidence_class_matches_reference_fixture(name):
     assert conf.is_cuda and rel_err(conf.cpu(), fx["forward"]["confidence"]) < REL
 
 
+def test_legacy_class_score_mode_matches_reference_fixture():
+    """get_model(old=True) in score mode (old_cg_model.py:293-352): forward 3-tuple and the device loop."""
+    fx, cfg, data_list = fixture_case("tiny_oldscore")
+    m = gpu_model(cfg, fx["state_dict"])
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    out = m(to_gpu(batch))
+    assert len(out) == 3
+    for mine, key in zip(out, ("tr", "rot", "tor")):
+        assert rel_err(mine.cpu(), fx["forward"][key]) < REL, key
+    s = fx["sampling"]
+    B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
+    sched = get_t_schedule(s["steps"])
+    pos = m.sample_batch(to_gpu(HeteroBatch.from_data_list(data_list)), s["steps"], (sched, sched, sched),
+                         noise=split_draws(s["draws"], s["steps"], B, R), no_final_step_noise=True, **s["temp"])
+    assert (pos.cpu().reshape(B, -1, 3) - s["final_pos"]).abs().max() < 2e-3
+
+
 def test_legacy_confidence_class_full_width_matches_oracle():
     """The legacy confidence class at DiffDock-L-like widths (ns=24, nv=6, 5 layers, sh_lmax=2) on a 200-residue / 28-atom
     complex, 3 poses, t = 0 (cross cutoff 20 A) -- static-shape and generic fused kernels, load mode, against the oracle."""

@@ -59,6 +59,26 @@ def test_legacy_confidence_matches_reference(name):
     assert conf.shape == fx["forward"]["confidence"].shape and rel_err(conf, fx["forward"]["confidence"]) < 2e-5
 
 
+def test_legacy_score_mode_matches_reference():
+    """get_model(..., old=True) in score mode executed by the reference: the legacy encoder / four-layer interaction blocks
+    followed by the read-outs of old_cg_model.py:293-352; forward scores and the reference sampling() trajectory."""
+    fx, cfg, data_list = fixture_case("tiny_oldscore")
+    so3_t, tor_t = tables()
+    model = oracle_model(cfg, fx["state_dict"], so3_t, tor_t)
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    out = model(batch)
+    assert len(out) == 3
+    for mine, key in zip(out, ("tr", "rot", "tor")):
+        assert mine.shape == fx["forward"][key].shape and rel_err(mine, fx["forward"][key]) < 2e-5, key
+    s = fx["sampling"]
+    B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
+    noise = split_draws(s["draws"], s["steps"], B, R)
+    res = sampling(data_list, model, s["steps"], cfg, noise, batch_size=B, no_final_step_noise=True, **s["temp"])
+    final = torch.stack([d["ligand"].pos for d in res])
+    assert (final - s["final_pos"]).abs().max() < 2e-3
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_sampling_matches_reference(name):
     fx, cfg, data_list = fixture_case(name)
