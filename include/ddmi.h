@@ -57,7 +57,8 @@ typedef struct ddmi_config {
    * 353-366); the model is evaluated with ddmi_confidence instead of ddmi_forward */
   int32_t confidence_mode, num_confidence_outputs;
   /* get_model(..., old=True) (utils/utils.py:180-219): legacy class models/old_cg_model.py (the released DiffDock-L
-   * confidence checkpoint, `old_confidence_model: true`).  Built in confidence mode, OldAtomEncoder, sh_lmax = 2. */
+   * confidence checkpoint, `old_confidence_model: true`).  Score mode (ddmi_forward, old_cg_model.py:293-352) and confidence
+   * mode (ddmi_confidence), OldAtomEncoder, sh_lmax = 2. */
   int32_t old_model;
 } ddmi_config;
 
