@@ -64,6 +64,11 @@ class ModelConfig:
     # layers, read-out = confidence_predictor on the graph-mean scalar ligand features; t is used raw (no t_to_sigma)
     confidence_mode: bool = False
     num_confidence_outputs: int = 1     # len(rmsd_classification_cutoff) + 1 when that is a list
+    # per-atom predictor in front of the graph mean (atom_confidence_loss_weight > 0; utils/utils.py:273) and the extra
+    # affinity output of confidence_predictor (affinity_prediction, parallel = 1)
+    atom_confidence: bool = False
+    atom_num_confidence_outputs: int = 1
+    affinity_prediction: bool = False
     # get_model(..., old=True) (utils/utils.py:180-219): the legacy class models/old_cg_model.py -- what the released DiffDock-L
     # confidence checkpoint is (`old_confidence_model: true`).  Score and confidence mode; always sh_lmax = 2, one confidence output.
     old: bool = False
@@ -116,10 +121,14 @@ class ModelConfig:
                  esm_embeddings_path="precomputed" if self.lm_embedding_type else None)
         for k in ('fixed_center_conv', 'lm_embedding_type', 'batch_norm', 'differentiate_convolutions',
                   'lig_max_radius', 'rec_max_radius', 'center_max_distance', 'in_lig_edge_features', 'confidence_mode',
-                  'num_confidence_outputs', 'old'):
+                  'num_confidence_outputs', 'old', 'atom_confidence', 'atom_num_confidence_outputs'):
             d.pop(k)
         if self.num_confidence_outputs > 1:
             d["rmsd_classification_cutoff"] = [2.0 + i for i in range(self.num_confidence_outputs - 1)]
+        if self.atom_confidence:
+            d["atom_confidence_loss_weight"] = 1.0
+            if self.atom_num_confidence_outputs > 1:
+                d["atom_rmsd_classification_cutoff"] = [1.0 + i for i in range(self.atom_num_confidence_outputs - 1)]
         return argparse.Namespace(**d)
 
     def replace(self, **kw) -> "ModelConfig":
@@ -141,9 +150,13 @@ def config_from_args(args) -> ModelConfig:
         if get(k, None) is not None:
             lm = "precomputed"
     cut = get("rmsd_classification_cutoff", None)
+    acut = get("atom_rmsd_classification_cutoff", None)
     return ModelConfig(
         all_atoms=bool(get("all_atoms", False)),
         num_confidence_outputs=len(cut) + 1 if isinstance(cut, list) else 1,
+        atom_confidence=get("atom_confidence_loss_weight", 0.0) > 0.0,
+        atom_num_confidence_outputs=len(acut) + 1 if isinstance(acut, list) else 1,
+        affinity_prediction=bool(get("affinity_prediction", False)),
         ns=args.ns, nv=args.nv, num_conv_layers=args.num_conv_layers,
         num_prot_emb_layers=get("num_prot_emb_layers", 0), sh_lmax=get("sh_lmax", 2),
         sigma_embed_dim=args.sigma_embed_dim, distance_embed_dim=args.distance_embed_dim,

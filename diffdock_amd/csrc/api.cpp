@@ -118,12 +118,13 @@ int ddmi_forward(ddmi_model* h, const float* lig_pos, const float* t_tr, const f
 }
 
 int ddmi_confidence(ddmi_model* h, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor,
-                    float* conf_out, ddmi_stream s) {
+                    float* conf_out, float* atom_conf_out, ddmi_stream s) {
   return guard([&] {
     DDMI_REQUIRE(h && lig_pos && t_tr && t_rot && t_tor && conf_out, DDMI_ERR_ARG, "null argument");
     DDMI_REQUIRE(h->m.cfg.confidence_mode, DDMI_ERR_STATE, "ddmi_confidence needs a model created with confidence_mode");
+    DDMI_REQUIRE(!h->m.cfg.atom_confidence || atom_conf_out, DDMI_ERR_ARG, "atom_confidence models need atom_conf_out");
     DDMI_CHECK_HIP(hipSetDevice(h->m.device));
-    forward(h->m, lig_pos, t_tr, t_rot, t_tor, nullptr, nullptr, nullptr, (hipStream_t)s, conf_out);
+    forward(h->m, lig_pos, t_tr, t_rot, t_tor, nullptr, nullptr, nullptr, (hipStream_t)s, conf_out, atom_conf_out);
   });
 }
 

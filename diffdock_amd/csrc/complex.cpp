@@ -30,6 +30,7 @@ struct Model::Cx {
   float* rec_node_base; int rec_base_dim = 0;
   // per forward
   float *temb, *hidB, *rec_sig, *ligsig, *ll_gvec, *cross_gvec, *center_gvec, *tr_sig, *rot_sig, *cutoff, *rr_rowbias;
+  float *ac_in = nullptr, *ac_h0 = nullptr, *ac_h1 = nullptr, *ac_out = nullptr;   // atom_confidence_predictor activations [nL, .]
   float* rr_sig_old = nullptr;   // legacy classes: sigma term of the receptor edge embedding (old_cg_model.py:411-413)
   float* embsum;
   std::vector<float*> X;
@@ -492,6 +493,10 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.ll_gvec = dalloc<float>(m, nullptr, {B, ns}); c.cross_gvec = dalloc<float>(m, nullptr, {B, ns});
   c.center_gvec = dalloc<float>(m, nullptr, {B, ns}); c.tr_sig = dalloc<float>(m, nullptr, {B, ns});
   c.rr_sig_old = dalloc<float>(m, nullptr, {B, ns});
+  if (cfg.atom_confidence && cfg.confidence_mode) {
+    c.ac_in = dalloc<float>(m, nullptr, {nL, 2 * ns}); c.ac_h0 = dalloc<float>(m, nullptr, {nL, ns});
+    c.ac_h1 = dalloc<float>(m, nullptr, {nL, ns}); c.ac_out = dalloc<float>(m, nullptr, {nL, cfg.atom_num_confidence_outputs + ns});
+  }
   c.rot_sig = dalloc<float>(m, nullptr, {B, ns}); c.cutoff = dalloc<float>(m, "cross_cutoff", {B});
   c.rr_rowbias = dalloc<float>(m, nullptr, {B, H});
   c.embsum = dalloc<float>(m, nullptr, {nL, ns});
@@ -863,18 +868,18 @@ static void forward_old(Model& m, const float* lig_pos, const float* t_tr, const
     return;
   }
   ConfHeadArgs a{};
-  a.B = B; a.X = c.X[Lc]; a.lig_ptr = c.lig_ptr; a.ns = ns;
+  a.B = B; a.X = c.X[Lc]; a.ldx = XS; a.col0 = 0; a.lig_ptr = c.lig_ptr; a.ns = ns;
   a.n_tail = Lc >= 3 ? ns : 0;
   a.tail_off = m.old_lig[Lc - 1].D_out - a.n_tail;
   a.W0 = m.conf_W[0]; a.b0 = m.conf_b[0]; a.sc0 = m.conf_bn_scale[0]; a.sh0 = m.conf_bn_shift[0];
   a.W1 = m.conf_W[1]; a.b1 = m.conf_b[1]; a.sc1 = m.conf_bn_scale[1]; a.sh1 = m.conf_bn_shift[1];
-  a.W2 = m.conf_W[2]; a.b2 = m.conf_b[2]; a.n_out = 1; a.out = conf_out;
+  a.W2 = m.conf_W[2]; a.b2 = m.conf_b[2]; a.n_out = cfg.affinity_prediction ? 2 : 1; a.out = conf_out;   // old_cg_model.py:154
   launch_conf_head(a, s);
 }
 
 // =================================================================================== forward
 void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor, float* tr_out,
-             float* rot_out, float* tor_out, hipStream_t s, float* conf_out) {
+             float* rot_out, float* tor_out, hipStream_t s, float* conf_out, float* atom_conf_out) {
   DDMI_REQUIRE(m.has_complex, DDMI_ERR_STATE, "ddmi_set_complex must precede ddmi_forward");
   const bool conf = m.cfg.confidence_mode != 0;
   DDMI_REQUIRE(conf == (conf_out != nullptr), DDMI_ERR_STATE, "score models use ddmi_forward, confidence models ddmi_confidence");
@@ -1027,12 +1032,23 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     const int total = cfg.num_conv_layers + cfg.num_prot_emb_layers;
     const ConvW& Ll = m.conv_layers.back();
     ConfHeadArgs a{};
-    a.B = B; a.X = XL; a.lig_ptr = c.lig_ptr; a.ns = ns;
+    a.B = B; a.X = XL; a.ldx = XS; a.col0 = 0; a.lig_ptr = c.lig_ptr; a.ns = ns;
     a.n_tail = total >= 3 ? (cfg.reduce_pseudoscalars ? cfg.nv : ns) : 0;
     a.tail_off = Ll.D_out - a.n_tail;
+    if (cfg.atom_confidence) {   // cg_model.py:357-360: per-atom predictor; columns [0, n_atom_out) are the atom outputs, the
+                                 // remaining ns columns replace the scalar features in the graph mean
+      const int n_in = ns + a.n_tail, na = cfg.atom_num_confidence_outputs, wo = na + ns;
+      launch_gather_cols(c.ac_in, n_in, 0, XL, XS, nullptr, nL, ns, nullptr, s);
+      if (a.n_tail > 0) launch_gather_cols(c.ac_in, n_in, ns, XL + a.tail_off, XS, nullptr, nL, a.n_tail, nullptr, s);
+      gemm(c.ac_in, n_in, m.aconf_W[0], n_in, m.aconf_b[0], c.ac_h0, ns, nL, ns, n_in, 1, s);
+      gemm(c.ac_h0, ns, m.aconf_W[1], ns, m.aconf_b[1], c.ac_h1, ns, nL, ns, ns, 1, s);
+      gemm(c.ac_h1, ns, m.aconf_W[2], ns, m.aconf_b[2], c.ac_out, wo, nL, wo, ns, 0, s);
+      launch_gather_cols(atom_conf_out, na, 0, c.ac_out, wo, nullptr, nL, na, nullptr, s);
+      a.X = c.ac_out; a.ldx = wo; a.col0 = na; a.n_tail = 0; a.tail_off = 0;
+    }
     a.W0 = m.conf_W[0]; a.b0 = m.conf_b[0]; a.sc0 = m.conf_bn_scale[0]; a.sh0 = m.conf_bn_shift[0];
     a.W1 = m.conf_W[1]; a.b1 = m.conf_b[1]; a.sc1 = m.conf_bn_scale[1]; a.sh1 = m.conf_bn_shift[1];
-    a.W2 = m.conf_W[2]; a.b2 = m.conf_b[2]; a.n_out = cfg.num_confidence_outputs; a.out = conf_out;
+    a.W2 = m.conf_W[2]; a.b2 = m.conf_b[2]; a.n_out = cfg.num_confidence_outputs + (cfg.affinity_prediction ? 1 : 0); a.out = conf_out;
     launch_conf_head(a, s);
     return;
   }

@@ -215,9 +215,9 @@ __global__ __launch_bounds__(64) void k_conf_head(ConfHeadArgs a) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int lo = a.lig_ptr[b], hi = a.lig_ptr[b + 1], n_in = a.ns + a.n_tail;
   for (int c = lane; c < n_in; c += 64) {
-    const int col = c < a.ns ? c : a.tail_off + (c - a.ns);
+    const int col = c < a.ns ? a.col0 + c : a.tail_off + (c - a.ns);
     float s = 0.f;
-    for (int i = lo; i < hi; ++i) s += a.X[(size_t)i * XS + col];
+    for (int i = lo; i < hi; ++i) s += a.X[(size_t)i * a.ldx + col];
     feat[c] = s / (float)max(hi - lo, 1);
   }
   __syncthreads();

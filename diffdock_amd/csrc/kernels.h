@@ -220,7 +220,8 @@ void launch_score_heads(const ScoreHeadArgs& a, hipStream_t s);
 // confidence = confidence_predictor(scatter_mean(cat[x[:, :ns], x[:, tail_off : tail_off + n_tail]], batch)) -- cg_model.py:353-366;
 // BatchNorm1d folded to scale / shift.  One workgroup per graph.
 struct ConfHeadArgs {
-  int B; const float* X; const int* lig_ptr;   // ligand rows of the last node table (stride XS)
+  int B; const float* X; const int* lig_ptr;   // ligand rows: the last node table (ldx = XS) or the atom predictor's output
+  int ldx, col0;                               // row stride, first column of the leading ns-block
   int ns, tail_off, n_tail;                    // n_tail = 0: scalars only (fewer than 3 layers)
   const float *W0, *b0, *sc0, *sh0, *W1, *b1, *sc1, *sh1, *W2, *b2;
   int n_out; float* out;                       // [B][n_out]

@@ -72,6 +72,7 @@ struct Model {
   Mlp2W atom_edge, ar_edge, la_edge;            // all_atoms (cross_edge then holds lr_edge_embedding)
   float* atom_emb = nullptr; int* atom_emb_off = nullptr;
   float *conf_W[3] = {}, *conf_b[3] = {}, *conf_bn_scale[2] = {}, *conf_bn_shift[2] = {};   // confidence_predictor
+  float *aconf_W[3] = {}, *aconf_b[3] = {};   // atom_confidence_predictor, BatchNorm1d folded into the two hidden Linears
   float* rec_emb = nullptr; float *rec_enc_W = nullptr, *rec_enc_b = nullptr;
   float *off_lig = nullptr, *off_rec = nullptr, *off_cross = nullptr, *off_center = nullptr;
   float coeff_lig = 0, coeff_rec = 0, coeff_cross = 0, coeff_center = 0;
@@ -126,7 +127,7 @@ void commit_weights(Model& m);
 void set_complex(Model& m, const ddmi_complex& c, hipStream_t s);
 // score mode: tr_out / rot_out / tor_out; confidence mode (cfg.confidence_mode): conf_out [B, num_confidence_outputs] only
 void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor, float* tr_out,
-             float* rot_out, float* tor_out, hipStream_t s, float* conf_out = nullptr);
+             float* rot_out, float* tor_out, hipStream_t s, float* conf_out = nullptr, float* atom_conf_out = nullptr);
 void modify_conformer(Model& m, float* lig_pos, const float* tr, const float* rot, const float* tor, hipStream_t s);
 void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s);
 

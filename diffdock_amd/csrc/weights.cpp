@@ -170,7 +170,7 @@ void build_weight_spec(Model& m) {
     }
     lin("confidence_predictor.0", Lc >= 3 ? 2 * ns : ns, ns);
     lin("confidence_predictor.4", ns, ns);
-    lin("confidence_predictor.8", ns, 1);
+    lin("confidence_predictor.8", ns, c.affinity_prediction ? 2 : 1);
     for (int i : {1, 5})
       for (const char* k : {".weight", ".bias", ".running_mean", ".running_var"})
         S.push_back({"confidence_predictor." + std::to_string(i) + k, {ns}});
@@ -218,13 +218,21 @@ void build_weight_spec(Model& m) {
   const Irreps last_out = layer_irreps(c, K + Lc);
   if (c.confidence_mode) {   // cg_model.py:181-207: Linear, BatchNorm1d, ReLU, Dropout, Linear, BatchNorm1d, ReLU, Dropout, Linear
     DDMI_REQUIRE(c.num_confidence_outputs >= 1, DDMI_ERR_ARG, "num_confidence_outputs must be >= 1");
-    const int n_in = K + Lc >= 3 ? ns + (c.reduce_pseudoscalars ? c.nv : ns) : ns;
-    lin("confidence_predictor.0", n_in, ns);
-    lin("confidence_predictor.4", ns, ns);
-    lin("confidence_predictor.8", ns, c.num_confidence_outputs);
-    for (int i : {1, 5})
-      for (const char* k : {".weight", ".bias", ".running_mean", ".running_var"})
-        S.push_back({"confidence_predictor." + std::to_string(i) + k, {ns}});
+    int n_in = K + Lc >= 3 ? ns + (c.reduce_pseudoscalars ? c.nv : ns) : ns;
+    auto predictor = [&](const std::string& name, int n_in_, int n_out) {
+      lin(name + ".0", n_in_, ns);
+      lin(name + ".4", ns, ns);
+      lin(name + ".8", ns, n_out);
+      for (int i : {1, 5})
+        for (const char* k : {".weight", ".bias", ".running_mean", ".running_var"})
+          S.push_back({name + "." + std::to_string(i) + k, {ns}});
+    };
+    if (c.atom_confidence) {   // cg_model.py:184-196: per-atom predictor; its last ns outputs feed the graph mean
+      DDMI_REQUIRE(c.atom_num_confidence_outputs >= 1, DDMI_ERR_ARG, "atom_num_confidence_outputs must be >= 1");
+      predictor("atom_confidence_predictor", n_in, c.atom_num_confidence_outputs + ns);
+      n_in = ns;
+    }
+    predictor("confidence_predictor", n_in, c.num_confidence_outputs + (c.affinity_prediction ? 1 : 0));
     return;
   }
   readout_spec(last_out);
@@ -598,6 +606,24 @@ void commit_weights(Model& m) {
         sh[k] = b.data[k] - rm.data[k] * sc[k];
       }
       m.conf_bn_scale[i] = m.wpool.upload(sc); m.conf_bn_shift[i] = m.wpool.upload(sh);
+    }
+    if (c.atom_confidence) {   // Linear + BatchNorm1d(eval) folded: W' = diag(s) W, b' = s b + shift
+      for (int i = 0; i < 3; ++i) {
+        const std::string n = "atom_confidence_predictor." + std::to_string(4 * i);
+        const HostTensor &w = W(m, n + ".weight"), &b = W(m, n + ".bias");
+        std::vector<float> wf = w.data, bf = b.data;
+        if (i < 2) {
+          const std::string nb = "atom_confidence_predictor." + std::to_string(4 * i + 1);
+          const HostTensor &g = W(m, nb + ".weight"), &be = W(m, nb + ".bias"), &rm = W(m, nb + ".running_mean"), &rv = W(m, nb + ".running_var");
+          const int cols = (int)w.shape[1];
+          for (int r = 0; r < m.ns; ++r) {
+            const float sc = g.data[r] / std::sqrt(rv.data[r] + 1e-5f);
+            for (int k = 0; k < cols; ++k) wf[(size_t)r * cols + k] *= sc;
+            bf[r] = bf[r] * sc + (be.data[r] - rm.data[r] * sc);
+          }
+        }
+        m.aconf_W[i] = m.wpool.upload(wf); m.aconf_b[i] = m.wpool.upload(bf);
+      }
     }
   }
   auto offs = [&](const std::string& k, float*& dev, float& coeff) {

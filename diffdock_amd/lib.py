@@ -32,7 +32,8 @@ class Config(C.Structure):
                [(n, C.c_float) for n in ("embedding_scale", "tr_sigma_min", "tr_sigma_max", "rot_sigma_min",
                                          "rot_sigma_max", "tor_sigma_min", "tor_sigma_max")] + \
                [("all_atoms", C.c_int32), ("confidence_mode", C.c_int32), ("num_confidence_outputs", C.c_int32),
-                ("old_model", C.c_int32)]
+                ("old_model", C.c_int32), ("atom_confidence", C.c_int32), ("atom_num_confidence_outputs", C.c_int32),
+                ("affinity_prediction", C.c_int32)]
 
 
 class Complex(C.Structure):
@@ -76,7 +77,7 @@ _DECLS = {
     "ddmi_set_time_frequencies": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "ddmi_set_complex": (C.c_int, [C.c_void_p, C.POINTER(Complex), C.c_void_p]),
     "ddmi_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
-    "ddmi_confidence": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
+    "ddmi_confidence": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p]),
     "ddmi_set_crop_cutoff": (C.c_int, [C.c_void_p, C.c_float]),
     "ddmi_modify_conformer": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "ddmi_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SampleCfg), C.c_void_p]),

@@ -170,13 +170,14 @@ class MIScoreModel:
         pos = data["ligand"].pos.to(dev, torch.float32).contiguous()
         t = [data.complex_t[k].to(dev, torch.float32).contiguous() for k in ("tr", "rot", "tor")]
         if self.cfg.confidence_mode:   # (confidence, atom_confidence) -- models/cg_model.py:353-366
-            n_out = self.cfg.num_confidence_outputs
+            n_out = self.cfg.num_confidence_outputs + (1 if self.cfg.affinity_prediction else 0)
             conf = torch.empty(self._B, n_out, device=dev)
+            atom = torch.empty(self._n_lig, self.cfg.atom_num_confidence_outputs, device=dev) if self.cfg.atom_confidence else None
             _lib.check(self.lib, self.lib.ddmi_confidence(self._h, _ptr(pos), _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(conf),
-                                                          self._stream()))
+                                                          None if atom is None else _ptr(atom), self._stream()))
             if self.cfg.old:   # the legacy class returns the bare tensor (old_cg_model.py:287-291)
                 return conf.squeeze(-1)
-            return conf.squeeze(-1), torch.zeros(self._n_lig, device=dev)
+            return conf.squeeze(-1), (atom if atom is not None else torch.zeros(self._n_lig, device=dev))
         tr = torch.empty(self._B, 3, device=dev)
         rot = torch.empty(self._B, 3, device=dev)
         no_tor = self.cfg.no_torsion or self._n_tor == 0

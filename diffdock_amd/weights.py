@@ -105,14 +105,20 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
     last_out = cfg.layer_irreps(K + L - 1)[1]
     if cfg.confidence_mode:   # cg_model.py:181-207: Linear, BatchNorm1d, ReLU, Dropout, Linear, BatchNorm1d, ReLU, Dropout, Linear
         n_in = ns + (cfg.nv if cfg.reduce_pseudoscalars else ns) if K + L >= 3 else ns
-        lin("confidence_predictor.0", n_in, ns)
-        lin("confidence_predictor.4", ns, ns)
-        lin("confidence_predictor.8", ns, cfg.num_confidence_outputs)
-        for i in (1, 5):   # get_model never passes confidence_no_batchnorm: BatchNorm1d is always there
-            spec[f"confidence_predictor.{i}.weight"] = ((ns,), "bn_w")
-            spec[f"confidence_predictor.{i}.bias"] = ((ns,), "bn_b")
-            spec[f"confidence_predictor.{i}.running_mean"] = ((ns,), "bn_mean")
-            spec[f"confidence_predictor.{i}.running_var"] = ((ns,), "bn_var")
+
+        def predictor(name, n_in_, n_out):   # get_model never passes confidence_no_batchnorm: BatchNorm1d is always there
+            lin(f"{name}.0", n_in_, ns)
+            lin(f"{name}.4", ns, ns)
+            lin(f"{name}.8", ns, n_out)
+            for i in (1, 5):
+                spec[f"{name}.{i}.weight"] = ((ns,), "bn_w")
+                spec[f"{name}.{i}.bias"] = ((ns,), "bn_b")
+                spec[f"{name}.{i}.running_mean"] = ((ns,), "bn_mean")
+                spec[f"{name}.{i}.running_var"] = ((ns,), "bn_var")
+        if cfg.atom_confidence:   # cg_model.py:184-196: per-atom predictor, its last ns outputs feed the graph mean
+            predictor("atom_confidence_predictor", n_in, cfg.atom_num_confidence_outputs + ns)
+            n_in = ns
+        predictor("confidence_predictor", n_in, cfg.num_confidence_outputs + (1 if cfg.affinity_prediction else 0))
         return spec
     _readout_spec(cfg, spec, lin, mlp, conv, last_out, sh)
     return spec
@@ -168,7 +174,7 @@ def _old_spec(cfg, spec, lin, mlp, bn, conv):
         return spec
     lin("confidence_predictor.0", 2 * ns if cfg.num_conv_layers >= 3 else ns, ns)
     lin("confidence_predictor.4", ns, ns)
-    lin("confidence_predictor.8", ns, 1)
+    lin("confidence_predictor.8", ns, 2 if cfg.affinity_prediction else 1)
     for i in (1, 5):
         spec[f"confidence_predictor.{i}.weight"] = ((ns,), "bn_w")
         spec[f"confidence_predictor.{i}.bias"] = ((ns,), "bn_b")

@@ -60,6 +60,10 @@ typedef struct ddmi_config {
    * confidence checkpoint, `old_confidence_model: true`).  Score mode (ddmi_forward, old_cg_model.py:293-352) and confidence
    * mode (ddmi_confidence), OldAtomEncoder, sh_lmax = 2. */
   int32_t old_model;
+  /* confidence-mode options of the new classes (cg_model.py:184-207, aa_model.py:177-211): per-atom predictor in front of the
+   * graph mean (`atom_confidence_loss_weight > 0`, atom_num_confidence_outputs = len(atom_rmsd_classification_cutoff) + 1)
+   * and one extra affinity output of confidence_predictor (`affinity_prediction`, parallel = 1) */
+  int32_t atom_confidence, atom_num_confidence_outputs, affinity_prediction;
 } ddmi_config;
 
 /* Static description of one collated batch of complexes = the fields of the PyG Batch the
@@ -140,10 +144,11 @@ int ddmi_forward(ddmi_model* m, const float* lig_pos, const float* t_tr, const f
                  float* tr_out, float* rot_out, float* tor_out, ddmi_stream stream);
 
 /* confidence, atom_confidence = confidence_model(batch) -- utils/sampling.py:221, models/cg_model.py:353-366 /
- * models/aa_model.py:431-452 (atom_confidence is identically zero unless atom_confidence_loss_weight > 0: not built).
- * Requires ddmi_config.confidence_mode.  t_* are used raw (sampling() passes 0).  conf_out [B, num_confidence_outputs]. */
+ * models/aa_model.py:431-452.  Requires ddmi_config.confidence_mode.  t_* are used raw (sampling() passes 0).
+ * conf_out [B, num_confidence_outputs (+ 1 with affinity_prediction)]; atom_conf_out [n_lig, atom_num_confidence_outputs]
+ * with ddmi_config.atom_confidence, else NULL (the reference returns zeros there). */
 int ddmi_confidence(ddmi_model* m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor,
-                    float* conf_out, ddmi_stream stream);
+                    float* conf_out, float* atom_conf_out, ddmi_stream stream);
 
 /* crop_beyond(graph, cutoff) -- utils/utils.py:388-413 as applied by sampling() before each model call
  * (utils/sampling.py:104-109): subsequent ddmi_forward calls drop the residues farther than `cutoff` from every

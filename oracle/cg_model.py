@@ -178,23 +178,31 @@ class CGModelOracle:
         return tuple(ts) if self.cfg.confidence_mode else t_to_sigma(self.cfg, *ts)
 
     def _confidence(self, data, lig_node_attr):
-        """cg_model.py:353-366 (atom_confidence=False): (confidence, atom_confidence)."""
+        """cg_model.py:353-366: (confidence, atom_confidence); with atom_confidence a per-atom predictor runs first and its
+        trailing ns outputs replace the scalar features in the graph mean."""
         c, sd, ns = self.cfg, self.sd, self.cfg.ns
         if c.num_conv_layers + c.num_prot_emb_layers >= 3:
             x = torch.cat([lig_node_attr[:, :ns], lig_node_attr[:, -(c.nv if c.reduce_pseudoscalars else ns):]], 1)
         else:
             x = lig_node_attr[:, :ns]
+
+        def predictor(name, v):   # Linear, BatchNorm1d(eval), ReLU, Dropout, Linear, BatchNorm1d, ReLU, Dropout, Linear
+            def bn1d(i, u):
+                p = f"{name}.{i}"
+                return (u - sd[p + ".running_mean"]) / torch.sqrt(sd[p + ".running_var"] + 1e-5) * sd[p + ".weight"] + sd[p + ".bias"]
+            lin = lambda i, u: torch.nn.functional.linear(u, sd[f"{name}.{i}.weight"], sd[f"{name}.{i}.bias"])
+            u = torch.relu(bn1d(1, lin(0, v)))
+            u = torch.relu(bn1d(5, lin(4, u)))
+            return lin(8, u)
+        if c.atom_confidence:
+            x = predictor("atom_confidence_predictor", x)
+            atom_confidence, x = x[:, :c.atom_num_confidence_outputs], x[:, c.atom_num_confidence_outputs:]
+        else:
+            atom_confidence = torch.zeros(len(lig_node_attr), dtype=x.dtype)
         batch = data["ligand"].batch
         x = torch.zeros(data.num_graphs, x.shape[1], dtype=x.dtype).index_add_(0, batch, x) / \
             torch.bincount(batch, minlength=data.num_graphs).clamp(min=1).unsqueeze(1).to(x.dtype)
-
-        def bn1d(i, v):
-            p = f"confidence_predictor.{i}"
-            return (v - sd[p + ".running_mean"]) / torch.sqrt(sd[p + ".running_var"] + 1e-5) * sd[p + ".weight"] + sd[p + ".bias"]
-        lin = lambda i, v: torch.nn.functional.linear(v, sd[f"confidence_predictor.{i}.weight"], sd[f"confidence_predictor.{i}.bias"])
-        x = torch.relu(bn1d(1, lin(0, x)))
-        x = torch.relu(bn1d(5, lin(4, x)))
-        return lin(8, x).squeeze(dim=-1), torch.zeros(len(lig_node_attr), dtype=x.dtype)
+        return predictor("confidence_predictor", x).squeeze(dim=-1), atom_confidence
 
     def __call__(self, data, return_intermediates=False):
         c, sd, ns = self.cfg, self.sd, self.cfg.ns

@@ -157,6 +157,10 @@ def main():
     cases["tiny_oldconf_2l"] = dict(cfg=TINY.replace(old=True, confidence_mode=True, sh_lmax=2, num_conv_layers=2,
                                                       lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=25.0),
                                     n_res=22, n_lig=9, n_samples=2, seed=11, t=0.3)
+    # per-atom confidence predictor + affinity output (atom_confidence_loss_weight > 0, affinity_prediction; cg_model.py:184-207)
+    cases["tiny_conf_atom"] = dict(cfg=TINY.replace(confidence_mode=True, sh_lmax=2, num_conv_layers=3, atom_confidence=True,
+                                                     atom_num_confidence_outputs=2, affinity_prediction=True,
+                                                     num_confidence_outputs=2), n_res=24, n_lig=9, n_samples=3, seed=13, t=0.0)
     # the same legacy class in score mode (get_model(old=True, confidence_mode=False)): read-outs old_cg_model.py:293-352
     cases["tiny_oldscore"] = dict(cfg=TINY.replace(old=True, confidence_mode=False, sh_lmax=2, num_conv_layers=3), n_res=26, n_lig=10,
                                   n_samples=3, seed=12, t=0.45)

@@ -222,7 +222,7 @@ def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
         assert rel_err(a_, b_) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1"])
+@pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1", "tiny_conf_atom"])
 def test_confidence_mode_matches_reference_fixture(name, emu_lib):
     """get_model(..., confidence_mode=True) for CGModel / AAModel (cg_model.py:353-366), fixture from the reference."""
     fx, cfg, data_list = fixture_case(name)
@@ -233,7 +233,11 @@ def test_confidence_mode_matches_reference_fixture(name, emu_lib):
     conf, atom_conf = m(batch)
     ref = fx["forward"]
     assert conf.shape == ref["confidence"].shape and rel_err(conf, ref["confidence"]) < 1e-4
-    assert atom_conf.shape == ref["atom_confidence"].shape and not atom_conf.any()
+    assert atom_conf.shape == ref["atom_confidence"].shape
+    if cfg.atom_confidence:   # per-atom predictor in front of the graph mean (+ the affinity column of the graph predictor)
+        assert rel_err(atom_conf, ref["atom_confidence"]) < 1e-4
+    else:
+        assert not atom_conf.any()
 
 
 @pytest.mark.parametrize("name", ["tiny_oldconf", "tiny_oldconf_2l"])

@@ -134,7 +134,7 @@ def test_selectable_kernel_paths_agree_on_the_gpu(env, width48_case, monkeypatch
         assert rel_err(o.cpu(), r) < REL and rel_err(o.cpu(), b) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1"])
+@pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1", "tiny_conf_atom"])
 def test_confidence_mode_matches_reference_fixture(name):
     fx, cfg, data_list = fixture_case(name)
     m = MIScoreModel(cfg, device="cuda:0")
@@ -142,7 +142,11 @@ def test_confidence_mode_matches_reference_fixture(name):
     batch = HeteroBatch.from_data_list(data_list)
     set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
     conf, atom_conf = m(to_gpu(batch))
-    assert conf.is_cuda and rel_err(conf.cpu(), fx["forward"]["confidence"]) < REL and not atom_conf.any()
+    assert conf.is_cuda and rel_err(conf.cpu(), fx["forward"]["confidence"]) < REL
+    if cfg.atom_confidence:
+        assert rel_err(atom_conf.cpu(), fx["forward"]["atom_confidence"]) < REL
+    else:
+        assert not atom_conf.any()
 
 
 @pytest.mark.parametrize("name", ["tiny_oldconf", "tiny_oldconf_2l"])

@@ -33,7 +33,7 @@ def test_forward_matches_reference(name):
     assert rel_err(tor, ref["tor"]) < 2e-5
 
 
-@pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1"])
+@pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1", "tiny_conf_atom"])
 def test_confidence_matches_reference(name):
     """get_model(..., confidence_mode=True) executed by the reference (CGModel / AAModel, cg_model.py:353-366)."""
     fx, cfg, data_list = fixture_case(name)
@@ -45,7 +45,11 @@ def test_confidence_matches_reference(name):
     for l, ref_nodes in enumerate(ref["conv_out"]):
         assert rel_err(inter[f"node_attr{l + 1}"], ref_nodes) < 2e-5, l
     assert conf.shape == ref["confidence"].shape and rel_err(conf, ref["confidence"]) < 2e-5
-    assert torch.equal(atom_conf, ref["atom_confidence"])
+    if cfg.atom_confidence:   # per-atom predictor (+ affinity column), cg_model.py:184-207,357-360
+        assert atom_conf.shape == ref["atom_confidence"].shape == (batch["ligand"].pos.shape[0], cfg.atom_num_confidence_outputs)
+        assert rel_err(atom_conf, ref["atom_confidence"]) < 2e-5
+    else:
+        assert torch.equal(atom_conf, ref["atom_confidence"])
 
 
 @pytest.mark.parametrize("name", ["tiny_oldconf", "tiny_oldconf_2l"])
