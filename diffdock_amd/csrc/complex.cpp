@@ -558,8 +558,8 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
       vmax = std::max(vmax, vs.vcap);
       if (lig_v[i]) vmax_b = std::max(vmax_b, vs.vcap);
     }
-    c.Hb = HKq > 0 ? dalloc<float>(m, nullptr, {vmax, 32, round_up(HKq, 16)}) : nullptr;   // whole pairs of 8-k groups
-    c.Hb_b = HKq > 0 ? dalloc<float>(m, nullptr, {vmax_b, 32, round_up(HKq, 16)}) : nullptr;
+    c.Hb = HKq > 0 ? dalloc<float>(m, nullptr, {round_up(vmax, 16), 32, round_up(HKq, 16)}) : nullptr;   // whole 16-node tiles, whole pairs of 8-k groups
+    c.Hb_b = HKq > 0 ? dalloc<float>(m, nullptr, {round_up(vmax_b, 16), 32, round_up(HKq, 16)}) : nullptr;
   }
   const int ecap[4] = {c.Ell_cap, c.Elr_cap, c.Err, c.Elr_cap};
   for (int g = 0; g < 4; ++g) c.msg[g] = dalloc<float>(m, nullptr, {ecap[g], XS});
