@@ -69,6 +69,8 @@ class ModelConfig:
     atom_confidence: bool = False
     atom_num_confidence_outputs: int = 1
     affinity_prediction: bool = False
+    # receptor features multiplied by 0 at the top of forward (cg_model.py:309-310; needs lm_embedding_type None)
+    no_aminoacid_identities: bool = False
     # get_model(..., old=True) (utils/utils.py:180-219): the legacy class models/old_cg_model.py -- what the released DiffDock-L
     # confidence checkpoint is (`old_confidence_model: true`).  Score and confidence mode; always sh_lmax = 2, one confidence output.
     old: bool = False
@@ -157,6 +159,7 @@ def config_from_args(args) -> ModelConfig:
         atom_confidence=get("atom_confidence_loss_weight", 0.0) > 0.0,
         atom_num_confidence_outputs=len(acut) + 1 if isinstance(acut, list) else 1,
         affinity_prediction=bool(get("affinity_prediction", False)),
+        no_aminoacid_identities=bool(get("no_aminoacid_identities", False)),
         ns=args.ns, nv=args.nv, num_conv_layers=args.num_conv_layers,
         num_prot_emb_layers=get("num_prot_emb_layers", 0), sh_lmax=get("sh_lmax", 2),
         sigma_embed_dim=args.sigma_embed_dim, distance_embed_dim=args.distance_embed_dim,

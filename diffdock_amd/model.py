@@ -144,7 +144,8 @@ class MIScoreModel:
             if mr.size and mr.shape[0] * B == n_tor and mr.shape[1] * B == lig.pos.shape[0]:
                 mask_rotate = torch.from_numpy(np.ascontiguousarray(mr.astype(np.uint8))).to(dev)
         keep = dict(lig_ptr=lig_ptr, rec_ptr=rec_ptr, lig_x=i32(lig.x[:, :16]), bond_index=i32(bond.edge_index),
-                    bond_attr=f32(bond.edge_attr), edge_mask=edge_mask, rec_x=f32(rec.x), rec_pos=f32(rec.pos),
+                    bond_attr=f32(bond.edge_attr), edge_mask=edge_mask,
+                    rec_x=f32(rec.x * 0 if self.cfg.no_aminoacid_identities else rec.x), rec_pos=f32(rec.pos),   # cg_model.py:309-310
                     rec_edge_index=i32(rr.edge_index), mask_rotate=mask_rotate)
         c = _lib.Complex()
         c.num_graphs, c.n_lig, c.n_rec = B, lig.pos.shape[0], rec.pos.shape[0]

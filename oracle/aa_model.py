@@ -110,6 +110,8 @@ class AAModelOracle(CGModelOracle):
     # ------------------------------------------------------------------ forward (aa_model.py:364-436)
     def __call__(self, data, return_intermediates=False):
         c, sd, ns = self.cfg, self.sd, self.cfg.ns
+        if c.no_aminoacid_identities:   # cg_model.py:309-310 / aa_model.py:377-378
+            data["receptor"].x = data["receptor"].x * 0
         tr_sigma, rot_sigma, tor_sigma = self._sigmas(data)
         (lig_node_attr, lig_ei, lig_edge_attr, lig_edge_sh, lig_ew,
          rec_node_attr, rec_ei, rec_edge_attr, rec_edge_sh, rec_ew,

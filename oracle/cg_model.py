@@ -206,6 +206,8 @@ class CGModelOracle:
 
     def __call__(self, data, return_intermediates=False):
         c, sd, ns = self.cfg, self.sd, self.cfg.ns
+        if c.no_aminoacid_identities:   # cg_model.py:309-310 / aa_model.py:377-378
+            data["receptor"].x = data["receptor"].x * 0
         lig = data["ligand"]
         tr_sigma, rot_sigma, tor_sigma = self._sigmas(data)
         (lig_node_attr, lig_edge_index, lig_edge_attr, lig_edge_sh, lig_ew,

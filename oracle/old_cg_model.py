@@ -70,6 +70,8 @@ class CGOldOracle(CGModelOracle):
 
     def __call__(self, data, return_intermediates=False):
         c, sd, ns = self.cfg, self.sd, self.cfg.ns
+        if c.no_aminoacid_identities:   # old_cg_model.py:204-205
+            data["receptor"].x = data["receptor"].x * 0
         tr_sigma, rot_sigma, tor_sigma = self._sigmas(data)     # raw t in confidence mode, t_to_sigma(t) in score mode (:207-210)
         lig_node_attr, lig_ei, lig_edge_attr, lig_sh, lig_ew = self.build_lig_conv_graph(data)
         lig_node_attr = self.old_atom_encoder("lig_node_embedding", lig_node_attr, 16, 0)

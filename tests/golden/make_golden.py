@@ -157,6 +157,9 @@ def main():
     cases["tiny_oldconf_2l"] = dict(cfg=TINY.replace(old=True, confidence_mode=True, sh_lmax=2, num_conv_layers=2,
                                                       lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=25.0),
                                     n_res=22, n_lig=9, n_samples=2, seed=11, t=0.3)
+    # receptor identities switched off (no_aminoacid_identities: rec.x * 0 at the top of forward; needs no language model)
+    cases["tiny_noaa"] = dict(cfg=TINY.replace(no_aminoacid_identities=True, lm_embedding_type=None, sh_lmax=1), n_res=22, n_lig=9,
+                              n_samples=2, seed=14, t=0.5)
     # per-atom confidence predictor + affinity output (atom_confidence_loss_weight > 0, affinity_prediction; cg_model.py:184-207)
     cases["tiny_conf_atom"] = dict(cfg=TINY.replace(confidence_mode=True, sh_lmax=2, num_conv_layers=3, atom_confidence=True,
                                                      atom_num_confidence_outputs=2, affinity_prediction=True,

@@ -17,7 +17,8 @@ from util import fixture_case, graph_from_dict, load_fixture, oracle_model, rel_
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "hipemu", "libddmi_emu.so")
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb"]   # tiny_aa_*: AAModel
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb",   # tiny_aa_*: AAModel
+         "tiny_noaa"]
 
 
 @pytest.fixture(scope="session")

@@ -18,7 +18,8 @@ from util import fixture_case, graph_from_dict, load_fixture, oracle_model, rel_
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb"]
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb",
+         "tiny_noaa"]
 
 
 def gpu_model(cfg, sd):

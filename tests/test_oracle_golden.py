@@ -13,7 +13,8 @@ from oracle.layers import faster_tensor_product, gaussian_smearing
 from oracle.sampling import sampling
 from util import fixture_case, load_fixture, oracle_model, rel_err, split_draws, tables, graph_from_dict
 
-CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb"]
+CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb",
+         "tiny_noaa"]
 
 
 @pytest.mark.parametrize("name", CASES)
