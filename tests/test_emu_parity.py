@@ -223,6 +223,32 @@ def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
         assert rel_err(a_, b_) < 1e-5
 
 
+def test_ligand_atoms_with_many_receptor_neighbours(emu_lib):
+    """Ligand-gather groups through the fused kernel with several virtual nodes per ligand atom (70 receptor neighbours ->
+    32 + 32 + 6 edges: the node term is repeated per virtual node, the last one is a sparse tile) at a width the MFMA first
+    layer and the dense-row loop accept (ns = 16), against the oracle."""
+    from diffdock_amd.config import TINY
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = TINY.replace(ns=16, nv=4, sh_lmax=1, num_conv_layers=3, dynamic_max_cross=False, cross_max_distance=200.0,
+                       lm_embedding_type=None)
+    sd = init_state_dict(cfg, seed=9)
+    g = make_complex(seed=21, n_res=70, n_lig=5, lm_dim=0)
+    b = HeteroBatch.from_data_list(make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=4))
+    set_time(b, 0.5, 0.5, 0.5, 2)
+    so3_t, tor_t = tables()
+    ref = CGModelOracle(cfg, sd, so3_t, tor_t)(b)[:3]
+    m = make_model(cfg, sd, emu_lib)
+    m.set_kernel_timing(True)
+    out = m(b)[:3]
+    launched = m.kernel_timings()
+    assert "k_conv_fused" in launched and "k_edge_conv" not in launched and "k_conv_fused_load" not in launched
+    assert int(m.debug_buffer("vn_off_rl")[-1]) == 3 * b["ligand"].pos.shape[0]     # ceil(70 / 32) virtual nodes per ligand atom
+    assert int(m.debug_buffer("vn_off_cross")[-1]) == b["receptor"].pos.shape[0]    # 5 ligand neighbours: one sparse tile each
+    for o, r in zip(out, ref):
+        assert rel_err(o, r) < 1e-4
+
+
 @pytest.mark.parametrize("name", ["tiny_conf_l2", "tiny_conf_aa_l1", "tiny_conf_atom"])
 def test_confidence_mode_matches_reference_fixture(name, emu_lib):
     """get_model(..., confidence_mode=True) for CGModel / AAModel (cg_model.py:353-366), fixture from the reference."""
