@@ -149,6 +149,29 @@ def test_rigid_ligand_and_no_torsion_early_out(no_torsion, emu_lib):
         assert (torch.cdist(a0, a0) - torch.cdist(a1, a1)).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("n_res,n_lig,B", [(20, 8, 1), (3, 4, 2), (40, 2, 3)])
+def test_degenerate_sizes(n_res, n_lig, B, emu_lib):
+    """A batch of one pose, a 3-residue receptor (fewer neighbours than the 24-nearest graph asks for), a 2-atom ligand:
+    forward against the oracle, and the device loop stays finite."""
+    from diffdock_amd.config import TINY
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = TINY
+    sd = init_state_dict(cfg, seed=5)
+    g = make_complex(seed=11, n_res=n_res, n_lig=n_lig)
+    b = HeteroBatch.from_data_list(make_pose_list(g, B, tr_sigma_max=cfg.tr_sigma_max, seed=3))
+    set_time(b, 0.5, 0.5, 0.5, B)
+    so3_t, tor_t = tables()
+    ref = CGModelOracle(cfg, sd, so3_t, tor_t)(b)
+    m = make_model(cfg, sd, emu_lib)
+    out = m(b)
+    for o, r in zip(out[:3], ref[:3]):
+        assert o.shape == r.shape and (r.numel() == 0 or rel_err(o, r) < 1e-4)
+    sched = get_t_schedule(3)
+    pos = m.sample_batch(b, 3, (sched, sched, sched), seed=1, no_final_step_noise=True)
+    assert pos.shape == b["ligand"].pos.shape and torch.isfinite(pos).all()
+
+
 def test_errors_are_python_exceptions(emu_lib):
     from diffdock_amd.lib import DdmiError
     fx, cfg, data_list = fixture_case("tiny_l1")
