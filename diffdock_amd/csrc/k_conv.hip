@@ -7,10 +7,13 @@
 // which is tri-linear in (h_e = relu(..) (+) 1, x_d, sh_e).  Contracting x_d with W2 FIRST
 // (per gather node, shared by all of its edges) cuts the multiply-adds per edge from
 // K*weight_numel (~1.0 M at ns=48) to K*NT (~76 k), K = 3ns+1, NT = sum_paths din*mul_out:
-//   k_node_contract : Y[d][k][n]  = sum_u x_d[u,i] * W2[k][slot(u,w)]          (n = (path,i,w))
-//   k_edge_conv     : T[e][n]     = sum_k h_e[k] * Y[d(e)][k][n]               (MFMA 16x16x4 f32)
-//                     m_e[o,w,k'] = sum_{paths,i,j} C[i][j][k'] sh_e[j] T[e][path,i,w]
-//   k_reduce_bn     : deterministic segmented mean over the target-CSR, BatchNorm, residual
+//   Y[d][k][n]  = sum_u x_d[u,i] * W2[k][slot(u,w)]          (n = (path,i,w))            node contraction
+//   T[e][n]     = sum_k h_e[k] * Y[d(e)][k][n]               (MFMA 16x16x4 f32)           edge product
+//   m_e[o,w,k'] = sum_{paths,i,j} C[i][j][k'] sh_e[j] T[e][path,i,w]                       coupling with sh_e
+//   k_reduce_bn : deterministic segmented mean over the target-CSR, BatchNorm, residual
+// k_conv_fused does the first three per tile of 16 virtual nodes with Y never leaving LDS (default for every edge group);
+// k_node_contract + k_edge_conv are the same steps with Y in HBM (DDMI_FUSED=0 / DDMI_FUSED_LIG=0), and k_node_contract
+// also feeds the load mode of k_conv_fused.  k_edge_hidden(_mm) produces h_e in the fused kernel's A-fragment order.
 // Results equal the reference up to fp32 re-association.
 #include <algorithm>
 #include <cstdlib>
@@ -967,13 +970,16 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const
 }
 
 // Workgroup = 16 virtual nodes x the granules [gsplit[y], gsplit[y+1]), 8 waves: wave w owns virtual nodes 2w, 2w+1 in the
-// edge GEMM and row w (k = 8g + w) of every 8-row k group g in the node contraction.  A lane's two A values of the edge GEMM
-// over a group (k = 8g + 2q + sub) are one 8-B load of the fragment-ordered hidden rows.  The contracted group is
-// double-buffered in LDS; per iteration a wave contracts row w of group g+1 (weights requested one iteration earlier),
-// requests the weights of group g+2 and the hidden fragments of g+1, and multiplies group g into its edge accumulators:
-// one barrier per 8 k.  The bias row of the packed second layer (h = 1) is added outside the MFMA loop.
-// MODE 0: static chain shapes, 1: generic (predicated) contraction, 2: load mode (rows from k_node_contract),
-// 3: static shapes, dense rows (both 16-edge row tiles of every virtual node are multiplied: branch-free main loop)
+// edge GEMM and row w (k = 8g + w) of every 8-row k group g in the node contraction.  A lane's A values of the edge GEMM over
+// a PAIR of groups (k = 8g + 2q + sub, g = 2p, 2p + 1) are one 16-B request of the fragment-ordered hidden rows.  The
+// contracted group is double-buffered in LDS; per iteration a wave contracts row w of group g+1 (weights requested one
+// iteration earlier), requests the weights of group g+2 and -- every second iteration -- the hidden fragments of the next
+// pair, and multiplies group g into its edge accumulators: one barrier per 8 k (fc_mainloop_dense).  The bias row of the
+// packed second layer (h = 1) is added outside the MFMA loop; the epilogue of a granule couples the accumulators with sh_e
+// and streams the message columns out through an LDS staging area (wave-local).
+// MODE 0: static chain shapes, sparse rows (the second 16-edge tile of a virtual node with <= 16 edges is skipped),
+// 1: generic (predicated, compiler-scheduled) contraction, 2: load mode (rows from k_node_contract, two granules per pass),
+// 3: static shapes, dense rows (both row tiles of every virtual node are multiplied: straight-line chunk body)
 template <int MAXD, int SHD, int MODE>
 __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
