@@ -151,6 +151,29 @@ def config_from_args(args) -> ModelConfig:
               "pdbsidechain_esm_embeddings_path", "esm_embeddings_path"):
         if get(k, None) is not None:
             lm = "precomputed"
+    # Arguments the reference's get_model acts on (utils/utils.py:174-276) that the built path does not implement: raise
+    # instead of silently computing a different function (most of them leave the weight shapes unchanged).
+    unsupported = []
+    if has("embedding_type") and args.embedding_type != "sinusoidal":
+        unsupported.append(f"embedding_type={args.embedding_type!r} (only 'sinusoidal', utils/diffusion_utils.py:99-110)")
+    if get("esm_embeddings_model", None) is not None:
+        unsupported.append("esm_embeddings_model (on-the-fly language-model embeddings)")
+    if get("parallel", 1) not in (1, None):
+        unsupported.append("parallel > 1")
+    if get("depthwise_convolution", False):
+        unsupported.append("depthwise_convolution")
+    if get("sidechain_loss_weight", 0) or get("backbone_loss_weight", 0):
+        unsupported.append("sidechain_pred (sidechain_loss_weight / backbone_loss_weight > 0)")
+    if get("include_miscellaneous_atoms", False):
+        unsupported.append("include_miscellaneous_atoms")
+    if get("tp_weights_layers", 2) != 2:
+        unsupported.append("tp_weights_layers != 2")
+    if unsupported:
+        raise NotImplementedError("get_model arguments outside the built path: " + "; ".join(unsupported))
+    # norm_by_sigma is stored by the reference classes and never read in forward (cg_model.py:44): accepted, no effect
+    if get("num_prot_emb_layers", 0) > 0 and not get("embed_also_ligand", False):
+        # the reference asserts the same in embedding() (models/cg_model.py:263 "otherwise reimplement padding")
+        raise NotImplementedError("num_prot_emb_layers > 0 requires embed_also_ligand (models/cg_model.py:263 asserts it)")
     cut = get("rmsd_classification_cutoff", None)
     acut = get("atom_rmsd_classification_cutoff", None)
     return ModelConfig(

@@ -150,6 +150,14 @@ int ddmi_sample(ddmi_model* h, float* lig_pos, const ddmi_sample_cfg* cfg, ddmi_
   });
 }
 
+int ddmi_perturb(ddmi_model* h, float* tr, float* rot, float* tor, const ddmi_sample_cfg* cfg, int step, ddmi_stream s) {
+  return guard([&] {
+    DDMI_REQUIRE(h && tr && rot && cfg, DDMI_ERR_ARG, "null argument");
+    DDMI_CHECK_HIP(hipSetDevice(h->m.device));
+    perturb(h->m, tr, rot, tor, *cfg, step, (hipStream_t)s);
+  });
+}
+
 int ddmi_debug_shape(ddmi_model* h, const char* name, int64_t shape[4], int* ndim, int* is_int) {
   return guard([&] {
     DDMI_REQUIRE(h && name, DDMI_ERR_ARG, "null argument");

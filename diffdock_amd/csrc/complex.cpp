@@ -67,7 +67,9 @@ struct Model::Cx {
   int* c_xrow;
   int *t_cnt, *t_atom; float *t_dist, *t_nvec, *t_ew, *t_bond_nvec, *t_ea, *t_attr, *t_hid, *t_W, *t_sh, *t_out, *t_feat;
   // sampler
-  float *s_tr, *s_rot, *s_tor, *s_t = nullptr; long long* s_ids = nullptr; size_t s_t_cap = 0;
+  float *s_tr, *s_rot, *s_tor, *s_t = nullptr; long long* s_ids = nullptr;
+  long long* s_ids_host = nullptr; hipEvent_t s_ids_ev = nullptr;   // pinned staging of the sample ids
+  ~Cx() { if (s_ids_host) (void)hipHostFree(s_ids_host); if (s_ids_ev) (void)hipEventDestroy(s_ids_ev); }
 };
 
 static hipEvent_t get_event(Model& m) {
@@ -1067,75 +1069,105 @@ void modify_conformer(Model& m, float* lig_pos, const float* tr, const float* ro
                           torsion ? tor : nullptr, s);
 }
 
+// Sample ids of the batch (keys of the counter-based generator) on the device: staged through a pinned host buffer, so
+// the caller's array is consumed before this returns and nothing waits for the stream (the event only guards the reuse of
+// the staging buffer by a later call).
+static const long long* upload_sample_ids(Model& m, const int64_t* ids, hipStream_t s) {
+  Cx& c = *m.cx;
+  if (!ids) return nullptr;
+  if (!c.s_ids) {
+    c.s_ids = m.cpool.alloc<long long>(c.B);
+    DDMI_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.s_ids_host), (size_t)c.B * 8));
+    DDMI_CHECK_HIP(hipEventCreate(&c.s_ids_ev));
+  } else {
+    DDMI_CHECK_HIP(hipEventSynchronize(c.s_ids_ev));
+  }
+  for (int b = 0; b < c.B; ++b) c.s_ids_host[b] = ids[b];
+  DDMI_CHECK_HIP(hipMemcpyAsync(c.s_ids, c.s_ids_host, (size_t)c.B * 8, hipMemcpyHostToDevice, s));
+  DDMI_CHECK_HIP(hipEventRecord(c.s_ids_ev, s));
+  return c.s_ids;
+}
+
+// Step k of utils/sampling.py:117-186 on score arrays (in place): NaN guard, then score and noise coefficients evaluated on
+// the host in float64 exactly as the reference's 0-dim float64 tensors are.
+static void perturb_step(Model& m, float* tr, float* rot, float* tor, const ddmi_sample_cfg& sc, int k,
+                         const long long* ids_dev, hipStream_t s) {
+  Cx& c = *m.cx;
+  const ddmi_config& cfg = m.cfg;
+  const int steps = sc.inference_steps, B = c.B;
+  const bool torsion = tor != nullptr && !cfg.no_torsion && c.nT > 0;
+  const bool last = k == steps - 1;
+  const double t_tr = sc.tr_schedule[k], t_rot = sc.rot_schedule[k], t_tor = sc.tor_schedule[k];
+  const double dt_tr = last ? t_tr : t_tr - sc.tr_schedule[k + 1];
+  const double dt_rot = last ? t_rot : t_rot - sc.rot_schedule[k + 1];
+  const double dt_tor = last ? t_tor : t_tor - sc.tor_schedule[k + 1];
+  const double s_tr = std::pow((double)cfg.tr_sigma_min, 1 - t_tr) * std::pow((double)cfg.tr_sigma_max, t_tr);
+  const double s_rot = std::pow((double)cfg.rot_sigma_min, 1 - t_rot) * std::pow((double)cfg.rot_sigma_max, t_rot);
+  const double s_tor = std::pow((double)cfg.tor_sigma_min, 1 - t_tor) * std::pow((double)cfg.tor_sigma_max, t_tor);
+  const bool zero_noise = sc.no_random || (sc.no_final_step_noise && last) || sc.ode;
+  auto coeffs = [&](double sigma, double smin, double smax, double dt, int i, float& cs, float& cz) {
+    const double g = sigma * std::sqrt(2.0 * std::log(smax / smin));
+    double a = sc.ode ? 0.5 * g * g * dt : g * g * dt;
+    double z = g * std::sqrt(dt);
+    if (sc.temp_sampling[i] != 1.0) {
+      const double T = sc.temp_sampling[i], psi = sc.temp_psi[i], sdat = sc.temp_sigma_data[i];
+      const double sigma_data = std::exp(sdat * std::log(smax) + (1 - sdat) * std::log(smin));
+      const double lambda = (sigma_data + sigma) / (sigma_data + sigma / T);
+      a = g * g * dt * (lambda + T * psi / 2);
+      z = g * std::sqrt(dt * (1 + psi));
+    }
+    cs = (float)a;
+    cz = zero_noise ? 0.f : (float)z;
+  };
+  PerturbArgs p{};
+  p.B = B; p.R = torsion ? c.nT / B : 0; p.tr = tr; p.rot = rot; p.tor = tor;
+  coeffs(s_tr, cfg.tr_sigma_min, cfg.tr_sigma_max, dt_tr, 0, p.c_tr_s, p.c_tr_z);
+  coeffs(s_rot, cfg.rot_sigma_min, cfg.rot_sigma_max, dt_rot, 1, p.c_rot_s, p.c_rot_z);
+  coeffs(s_tor, cfg.tor_sigma_min, cfg.tor_sigma_max, dt_tor, 2, p.c_tor_s, p.c_tor_z);
+  if (!zero_noise) {
+    p.z_tr = sc.z_tr ? sc.z_tr + (size_t)k * B * 3 : nullptr;
+    p.z_rot = sc.z_rot ? sc.z_rot + (size_t)k * B * 3 : nullptr;
+    p.z_tor = sc.z_tor ? sc.z_tor + (size_t)k * c.nT : nullptr;
+    p.use_rng = 1;
+  }
+  p.seed = sc.seed; p.sample_ids = ids_dev; p.step = k;
+  launch_perturb(p, s);
+}
+
+static void check_sample_cfg(Model& m, const ddmi_sample_cfg& sc) {
+  DDMI_REQUIRE(sc.inference_steps > 0 && sc.tr_schedule && sc.rot_schedule && sc.tor_schedule, DDMI_ERR_ARG, "bad schedule");
+  DDMI_REQUIRE(m.cx->uniform, DDMI_ERR_STATE, "the step loop needs a batch of copies of one complex");
+}
+
+void perturb(Model& m, float* tr, float* rot, float* tor, const ddmi_sample_cfg& sc, int k, hipStream_t s) {
+  DDMI_REQUIRE(m.has_complex, DDMI_ERR_STATE, "ddmi_set_complex must precede ddmi_perturb");
+  check_sample_cfg(m, sc);
+  DDMI_REQUIRE(k >= 0 && k < sc.inference_steps, DDMI_ERR_ARG, "step index out of range");
+  perturb_step(m, tr, rot, tor, sc, k, upload_sample_ids(m, sc.sample_ids, s), s);
+}
+
 void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) {
   DDMI_REQUIRE(m.has_complex, DDMI_ERR_STATE, "ddmi_set_complex must precede ddmi_sample");
-  DDMI_REQUIRE(sc.inference_steps > 0 && sc.tr_schedule && sc.rot_schedule && sc.tor_schedule, DDMI_ERR_ARG, "bad schedule");
+  check_sample_cfg(m, sc);
   Cx& c = *m.cx;
   const ddmi_config& cfg = m.cfg;
   const int steps = sc.inference_steps, B = c.B;
   const bool torsion = !cfg.no_torsion && c.nT > 0;
-  const double saved_crop = m.crop_cutoff;
-  // per-step time values for all graphs, uploaded once
-  std::vector<float> tvals((size_t)steps * 3 * B);
-  for (int k = 0; k < steps; ++k)
-    for (int b = 0; b < B; ++b) {
-      tvals[((size_t)k * 3 + 0) * B + b] = (float)sc.tr_schedule[k];
-      tvals[((size_t)k * 3 + 1) * B + b] = (float)sc.rot_schedule[k];
-      tvals[((size_t)k * 3 + 2) * B + b] = (float)sc.tor_schedule[k];
-    }
-  if (c.s_t_cap < tvals.size()) { c.s_t = m.cpool.alloc<float>(tvals.size()); c.s_t_cap = tvals.size(); }
-  float* t_dev = c.s_t;
-  DDMI_CHECK_HIP(hipMemcpyAsync(t_dev, tvals.data(), tvals.size() * 4, hipMemcpyHostToDevice, s));
-  long long* ids_dev = nullptr;
-  if (sc.sample_ids) {
-    if (!c.s_ids) c.s_ids = m.cpool.alloc<long long>(B);
-    DDMI_CHECK_HIP(hipMemcpyAsync(c.s_ids, sc.sample_ids, (size_t)B * 8, hipMemcpyHostToDevice, s));
-    ids_dev = c.s_ids;
-  }
-  DDMI_CHECK_HIP(hipStreamSynchronize(s));  // tvals is a stack-lifetime host buffer
+  struct CropGuard {   // the per-step crop must not outlive the loop, also when a step throws
+    Model& m; double saved;
+    ~CropGuard() { m.crop_cutoff = saved; }
+  } crop_guard{m, m.crop_cutoff};
+  if (!c.s_t) c.s_t = m.cpool.alloc<float>((size_t)3 * B);
+  const long long* ids_dev = upload_sample_ids(m, sc.sample_ids, s);
   for (int k = 0; k < steps; ++k) {
-    const bool last = k == steps - 1;
     const double t_tr = sc.tr_schedule[k], t_rot = sc.rot_schedule[k], t_tor = sc.tor_schedule[k];
-    const double dt_tr = last ? t_tr : t_tr - sc.tr_schedule[k + 1];
-    const double dt_rot = last ? t_rot : t_rot - sc.rot_schedule[k + 1];
-    const double dt_tor = last ? t_tor : t_tor - sc.tor_schedule[k + 1];
     const double s_tr = std::pow((double)cfg.tr_sigma_min, 1 - t_tr) * std::pow((double)cfg.tr_sigma_max, t_tr);
-    const double s_rot = std::pow((double)cfg.rot_sigma_min, 1 - t_rot) * std::pow((double)cfg.rot_sigma_max, t_rot);
-    const double s_tor = std::pow((double)cfg.tor_sigma_min, 1 - t_tor) * std::pow((double)cfg.tor_sigma_max, t_tor);
-    const float* tk = t_dev + (size_t)k * 3 * B;
+    launch_fill_times(c.s_t, B, (float)t_tr, (float)t_rot, (float)t_tor, s);   // set_time for this step
     m.crop_cutoff = sc.use_crop ? s_tr * 3.0 + sc.crop_beyond : 0.0;   // sampling.py:107
-    forward(m, lig_pos, tk, tk + B, tk + 2 * B, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
-    const bool zero_noise = sc.no_random || (sc.no_final_step_noise && last) || sc.ode;
-    auto coeffs = [&](double sigma, double smin, double smax, double dt, int i, float& cs, float& cz) {
-      const double g = sigma * std::sqrt(2.0 * std::log(smax / smin));
-      double a = sc.ode ? 0.5 * g * g * dt : g * g * dt;
-      double z = g * std::sqrt(dt);
-      if (sc.temp_sampling[i] != 1.0) {
-        const double T = sc.temp_sampling[i], psi = sc.temp_psi[i], sdat = sc.temp_sigma_data[i];
-        const double sigma_data = std::exp(sdat * std::log(smax) + (1 - sdat) * std::log(smin));
-        const double lambda = (sigma_data + sigma) / (sigma_data + sigma / T);
-        a = g * g * dt * (lambda + T * psi / 2);
-        z = g * std::sqrt(dt * (1 + psi));
-      }
-      cs = (float)a;
-      cz = zero_noise ? 0.f : (float)z;
-    };
-    PerturbArgs p{};
-    p.B = B; p.R = torsion ? c.nT / B : 0; p.tr = c.s_tr; p.rot = c.s_rot; p.tor = c.s_tor;
-    coeffs(s_tr, cfg.tr_sigma_min, cfg.tr_sigma_max, dt_tr, 0, p.c_tr_s, p.c_tr_z);
-    coeffs(s_rot, cfg.rot_sigma_min, cfg.rot_sigma_max, dt_rot, 1, p.c_rot_s, p.c_rot_z);
-    coeffs(s_tor, cfg.tor_sigma_min, cfg.tor_sigma_max, dt_tor, 2, p.c_tor_s, p.c_tor_z);
-    if (!zero_noise) {
-      p.z_tr = sc.z_tr ? sc.z_tr + (size_t)k * B * 3 : nullptr;
-      p.z_rot = sc.z_rot ? sc.z_rot + (size_t)k * B * 3 : nullptr;
-      p.z_tor = sc.z_tor ? sc.z_tor + (size_t)k * c.nT : nullptr;
-      p.use_rng = 1;
-    }
-    p.seed = sc.seed; p.sample_ids = ids_dev; p.step = k;
-    launch_perturb(p, s);
+    forward(m, lig_pos, c.s_t, c.s_t + B, c.s_t + 2 * B, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
+    perturb_step(m, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, sc, k, ids_dev, s);
     modify_conformer(m, lig_pos, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
   }
-  m.crop_cutoff = saved_crop;
 }
 
 }  // namespace ddmi

@@ -101,6 +101,15 @@ void launch_perturb(const PerturbArgs& a, hipStream_t s) {
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
+__global__ void k_fill_times(float* __restrict__ t, int B, float t_tr, float t_rot, float t_tor) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) { t[i] = t_tr; t[B + i] = t_rot; t[2 * B + i] = t_tor; }
+}
+void launch_fill_times(float* t, int B, float t_tr, float t_rot, float t_tor, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill_times, dim3(cdiv(B, 256)), dim3(256), 0, s, t, B, t_tr, t_rot, t_tor);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------ conformer update
 __device__ __forceinline__ void axis_angle_to_matrix(float ax, float ay, float az, float* R) {
   const float angle = sqrtf(ax * ax + ay * ay + az * az);

@@ -130,5 +130,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
              float* rot_out, float* tor_out, hipStream_t s, float* conf_out = nullptr, float* atom_conf_out = nullptr);
 void modify_conformer(Model& m, float* lig_pos, const float* tr, const float* rot, const float* tor, hipStream_t s);
 void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s);
+// NaN guard + score / noise combination of step k (utils/sampling.py:117-186) on score arrays, in place
+void perturb(Model& m, float* tr, float* rot, float* tor, const ddmi_sample_cfg& sc, int k, hipStream_t s);
 
 }  // namespace ddmi

@@ -81,6 +81,7 @@ _DECLS = {
     "ddmi_set_crop_cutoff": (C.c_int, [C.c_void_p, C.c_float]),
     "ddmi_modify_conformer": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "ddmi_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SampleCfg), C.c_void_p]),
+    "ddmi_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SampleCfg), C.c_int, C.c_void_p]),
     "ddmi_debug_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ddmi_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddmi_wigner_3j": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 from typing import Dict, Optional
 
 import numpy as np
@@ -43,6 +44,7 @@ class MIScoreModel:
         dev_index = self.device.index or 0 if self.device.type == "cuda" else 0
         _lib.check(self.lib, self.lib.ddmi_create(C.byref(_lib.make_config(cfg)), dev_index, C.byref(self._h)))
         self._complex_key = None
+        self._complex_ref = None
         self._keep = None
         self._state: Dict[str, torch.Tensor] = {}
         self._tables_set = False
@@ -73,8 +75,10 @@ class MIScoreModel:
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         expected = self.expected_keys()
-        # e3nn keeps constant buffers under *.tp.* / final_tp_tor.* in real checkpoints; they are not weights
-        given = {k: v for k, v in sd.items() if ".tp." not in k and not k.startswith("final_tp_tor.")}
+        # e3nn keeps constant buffers under *.tp.* / final_tp_tor.* in real checkpoints, and nn.BatchNorm1d (confidence
+        # predictors, cg_model.py:184-207) its `num_batches_tracked` step counter: neither is a weight
+        given = {k: v for k, v in sd.items() if ".tp." not in k and not k.startswith("final_tp_tor.")
+                 and not k.endswith("num_batches_tracked")}
         missing = [k for k in expected if k not in given]
         unexpected = [k for k in given if k not in expected]
         if strict and (missing or unexpected):
@@ -89,8 +93,13 @@ class MIScoreModel:
             _lib.check(self.lib, self.lib.ddmi_set_weight(self._h, k.encode(), _ptr(t), shape, t.dim()))
             self._state[k] = t
         _lib.check(self.lib, self.lib.ddmi_commit_weights(self._h))
-        self._complex_key = None
+        self.invalidate_complex()
         return self
+
+    def invalidate_complex(self):
+        """Forget the cached ddmi_set_complex: the next model(batch) rebuilds the static part of the batch."""
+        self._complex_key = None
+        self._complex_ref = None
 
     def set_tables(self, so3_exp_score_norms: np.ndarray, torus_score_norm: np.ndarray):
         """Score-norm tables (utils/so3.py:59, utils/torus.py:72-76); see diffdock_amd/tables.py."""
@@ -113,13 +122,33 @@ class MIScoreModel:
             return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         return None
 
-    def _ensure_complex(self, data):
+    def _static_tensors(self, data):
         lig, rec = data["ligand"], data["receptor"]
         bond, rr = data["ligand", "ligand"], data["receptor", "receptor"]
-        key = (rec.x.data_ptr(), rec.pos.data_ptr(), lig.x.data_ptr(), bond.edge_index.data_ptr(),
-               rr.edge_index.data_ptr(), int(data.num_graphs), tuple(lig.pos.shape), tuple(rec.pos.shape))
-        if key == self._complex_key:
+        ts = [rec.x, rec.pos, lig.x, lig.batch, rec.batch, lig.edge_mask, bond.edge_index, bond.edge_attr, rr.edge_index]
+        if self.cfg.all_atoms:
+            ts += [data["atom"].x, data["atom"].pos, data["atom", "atom"].edge_index, data["atom", "receptor"].edge_index]
+        return ts
+
+    def _ensure_complex(self, data):
+        """ddmi_set_complex once per batch OBJECT.  One model is reused over many complexes (inference.py:224-303) and the
+        caching allocator hands a freed batch's addresses to the next one, so addresses and shapes cannot identify a
+        batch: the cache is keyed on the identity of the live batch object (weak reference) plus the in-place version
+        counters of its static tensors; a batch type that cannot be weakly referenced is fingerprinted by content."""
+        lig, rec = data["ligand"], data["receptor"]
+        bond, rr = data["ligand", "ligand"], data["receptor", "receptor"]
+        static = self._static_tensors(data)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in static) + (int(data.num_graphs),)
+        same_obj = self._complex_ref is not None and self._complex_ref() is data
+        if same_obj and key == self._complex_key:
             return
+        try:
+            ref = weakref.ref(data)
+        except TypeError:    # no weak references: content fingerprint of the static tensors (one host read-back per call)
+            ref = None
+            key = key + tuple(float(t.double().sum()) + float((t.double() * t.double()).sum()) for t in static)
+            if key == self._complex_key:
+                return
         if not self._tables_set:
             from .tables import default_tables
             self.set_tables(*default_tables())
@@ -161,7 +190,7 @@ class MIScoreModel:
         for name in names:
             setattr(c, name, keep[name].data_ptr() if keep[name] is not None else None)
         _lib.check(self.lib, self.lib.ddmi_set_complex(self._h, C.byref(c), self._stream()))
-        self._keep, self._complex_key = keep, key
+        self._keep, self._complex_key, self._complex_ref = keep, key, ref
         self._B, self._n_tor, self._n_lig = B, n_tor, lig.pos.shape[0]
 
     # ------------------------------------------------------------------ model(batch)
@@ -206,13 +235,10 @@ class MIScoreModel:
                                                             self._stream()))
         return out
 
-    def sample_batch(self, data, inference_steps, schedules, noise=None, seed=0, sample_ids=None, ode=False,
-                     no_random=False, no_final_step_noise=False, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5,
-                     crop_beyond=None):
-        """The whole step loop of sampling() (utils/sampling.py:96-191) for one collated batch, on the device."""
-        self._ensure_complex(data)
+    def _sample_cfg(self, inference_steps, schedules, noise, seed, sample_ids, ode, no_random, no_final_step_noise,
+                    temp_sampling, temp_psi, temp_sigma_data, crop_beyond):
+        """ddmi_sample_cfg + the host / device arrays it points into (returned so that they outlive the call)."""
         dev = self.device
-        pos = data["ligand"].pos.to(dev, torch.float32).contiguous().clone()
         sc = _lib.SampleCfg()
         sched = [np.ascontiguousarray(np.asarray(s, dtype=np.float64)) for s in schedules]
         sc.inference_steps = inference_steps
@@ -228,13 +254,47 @@ class MIScoreModel:
         ids = None
         if sample_ids is not None:
             ids = np.ascontiguousarray(np.asarray(sample_ids, dtype=np.int64))
+            assert ids.size == self._B, "one sample id per graph of the batch"
             sc.sample_ids = ids.ctypes.data
         zs = [None, None, None]
         if noise is not None:
             zs = [None if z is None else z.to(dev, torch.float32).contiguous() for z in noise]
             sc.z_tr, sc.z_rot, sc.z_tor = (None if z is None else z.data_ptr() for z in zs)
+        return sc, (sched, ids, zs)
+
+    def sample_batch(self, data, inference_steps, schedules, noise=None, seed=0, sample_ids=None, ode=False,
+                     no_random=False, no_final_step_noise=False, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5,
+                     crop_beyond=None):
+        """The whole step loop of sampling() (utils/sampling.py:96-191) for one collated batch, on the device."""
+        self._ensure_complex(data)
+        pos = data["ligand"].pos.to(self.device, torch.float32).contiguous().clone()
+        sc, keep = self._sample_cfg(inference_steps, schedules, noise, seed, sample_ids, ode, no_random, no_final_step_noise,
+                                    temp_sampling, temp_psi, temp_sigma_data, crop_beyond)
         _lib.check(self.lib, self.lib.ddmi_sample(self._h, _ptr(pos), C.byref(sc), self._stream()))
+        if noise is not None and self.device.type == "cuda":   # the injected draws must outlive the enqueued steps
+            for z in keep[2]:
+                if z is not None:
+                    z.record_stream(torch.cuda.current_stream(self.device))
         return pos
+
+    def perturb(self, data, tr_score, rot_score, tor_score, t_idx, inference_steps, schedules, noise=None, seed=0,
+                sample_ids=None, ode=False, no_random=False, no_final_step_noise=False, temp_sampling=1.0, temp_psi=0.0,
+                temp_sigma_data=0.5):
+        """Scores of step t_idx -> (tr_perturb, rot_perturb, tor_perturb): NaN guard + update formulas of
+        utils/sampling.py:117-186 on the device (ddmi_perturb).  `noise` = (z_tr [steps,B,3], z_rot [steps,B,3], z_tor [steps,n_tor])."""
+        self._ensure_complex(data)
+        dev = self.device
+        f = lambda x: x.to(dev, torch.float32).contiguous().clone()
+        tr, rot = f(tr_score), f(rot_score)
+        tor = f(tor_score) if (tor_score is not None and tor_score.numel()) else None
+        sc, keep = self._sample_cfg(inference_steps, schedules, noise, seed, sample_ids, ode, no_random, no_final_step_noise,
+                                    temp_sampling, temp_psi, temp_sigma_data, None)
+        _lib.check(self.lib, self.lib.ddmi_perturb(self._h, _ptr(tr), _ptr(rot), _ptr(tor), C.byref(sc), int(t_idx), self._stream()))
+        if noise is not None and self.device.type == "cuda":
+            for z in keep[2]:
+                if z is not None:
+                    z.record_stream(torch.cuda.current_stream(self.device))
+        return tr, rot, tor
 
     # ------------------------------------------------------------------ introspection
     def set_kernel_timing(self, enabled: bool):
@@ -274,6 +334,9 @@ def get_model(args, device, t_to_sigma=None, no_parallel=True, confidence_mode=F
         if not cfg.use_old_atom_encoder:
             raise NotImplementedError("CGOldModel with the new AtomEncoder cannot be constructed by the reference either "
                                       "(AtomEncoder has no lm_embedding_type argument)")
+    elif not cfg.embed_also_ligand:
+        # CGModel / AAModel.ligand_embedding asserts it on every forward (models/cg_model.py:263, "otherwise reimplement padding")
+        raise AssertionError("embed_also_ligand must be set for the CGModel / AAModel classes (models/cg_model.py:263)")
     if confidence_mode != cfg.confidence_mode:
         cfg = cfg.replace(confidence_mode=bool(confidence_mode))
     return MIScoreModel(cfg, device=device, lib_path=lib_path)

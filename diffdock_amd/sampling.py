@@ -93,26 +93,24 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                                          temp_sampling=temp_sampling, temp_psi=temp_psi, temp_sigma_data=temp_sigma_data,
                                          crop_beyond=crop)
             else:   # step-wise: model(batch) per step, exactly the reference's loop structure
-                assert z is not None or no_random, "the step-wise loop needs injected noise (or no_random)"
                 pos = batch["ligand"].pos
-                for t_idx in range(inference_steps):
-                    set_time(batch, schedules[0][t_idx], schedules[1][t_idx], schedules[2][t_idx], b, device=pos.device)
-                    batch["ligand"].pos = pos
-                    if crop is not None:     # sampling.py:104-109: crop at 3*tr_sigma + crop_beyond, applied on the device
-                        t = float(schedules[0][t_idx])
-                        model.set_crop_cutoff(cfg.tr_sigma_min ** (1 - t) * cfg.tr_sigma_max ** t * 3 + crop)
-                    tr, rot, tor = model(batch)[:3]
-                    (a_tr, z_tr), (a_rot, z_rot), (a_tor, z_tor) = step_coefficients(
-                        cfg, t_idx, inference_steps, schedules, ode, no_random, no_final_step_noise, temp_sampling,
-                        temp_psi, temp_sigma_data)
-                    zz = [torch.zeros_like(tr), torch.zeros_like(rot), torch.zeros_like(tor)] if z is None else \
-                        [z[0][t_idx].to(tr.device), z[1][t_idx].to(tr.device), z[2][t_idx].to(tr.device)]
-                    trp = np.float32(a_tr) * tr + np.float32(z_tr) * zz[0]
-                    rotp = np.float32(a_rot) * rot + np.float32(z_rot) * zz[1]
-                    torp = (np.float32(a_tor) * tor + np.float32(z_tor) * zz[2]) if tor.numel() else None
-                    pos = model.modify_conformer_batch(pos, batch, trp, rotp, torp)
-                if crop is not None:
-                    model.set_crop_cutoff(None)
+                try:
+                    for t_idx in range(inference_steps):
+                        set_time(batch, schedules[0][t_idx], schedules[1][t_idx], schedules[2][t_idx], b, device=pos.device)
+                        batch["ligand"].pos = pos
+                        if crop is not None:     # sampling.py:104-109: crop at 3*tr_sigma + crop_beyond, applied on the device
+                            t = float(schedules[0][t_idx])
+                            model.set_crop_cutoff(cfg.tr_sigma_min ** (1 - t) * cfg.tr_sigma_max ** t * 3 + crop)
+                        tr, rot, tor = model(batch)[:3]
+                        # NaN guard + update formulas (sampling.py:117-186) on the device, same kernel as the native loop
+                        trp, rotp, torp = model.perturb(batch, tr, rot, tor, t_idx, inference_steps, schedules, noise=z, seed=seed,
+                                                        sample_ids=ids, ode=ode, no_random=no_random,
+                                                        no_final_step_noise=no_final_step_noise, temp_sampling=temp_sampling,
+                                                        temp_psi=temp_psi, temp_sigma_data=temp_sigma_data)
+                        pos = model.modify_conformer_batch(pos, batch, trp, rotp, torp)
+                finally:
+                    if crop is not None:
+                        model.set_crop_cutoff(None)
             pos = pos.reshape(b, n, 3)
             for i in range(b):
                 data_list[lo + i]["ligand"].pos = pos[i]

@@ -246,31 +246,39 @@ def _torsion_update_numpy(pos, rot_edges, mask_rotate, updates):
     return pos
 
 
-def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, initial_noise_std_proportion=-1.0, seed=0):
-    """utils/sampling.py:16-58 with an explicit seeded generator (the reference uses the
-    global numpy / scipy / torch RNGs)."""
+def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, initial_noise_std_proportion=-1.0, seed=0, draws=None):
+    """utils/sampling.py:16-58 with an explicit seeded generator (the reference uses the global numpy / scipy / torch
+    RNGs).  `draws` = dict(torsion=[per complex: R angles], rotation=[per complex: 3x3 matrix], tr=[per complex: (1,3)
+    translation, already scaled]) replaces the generator -- that is how the function is pinned to the reference-executed
+    fixture tests/golden/randpos.pt, which records the reference's own draws."""
     rng = np.random.default_rng(seed)
     center_pocket = data_list[0]["receptor"].pos.mean(dim=0)
-    for g in data_list:
+    for i, g in enumerate(data_list):
         pos = g["ligand"].pos.double().numpy()
         if not no_torsion:
             ei = g["ligand", "ligand"].edge_index.T.numpy()[g["ligand"].edge_mask.numpy()]
-            upd = rng.uniform(-np.pi, np.pi, size=len(ei))
+            upd = rng.uniform(-np.pi, np.pi, size=len(ei)) if draws is None else np.asarray(draws["torsion"][i], dtype=np.float64)
             pos = _torsion_update_numpy(pos, ei, g["ligand"].mask_rotate[0], upd)
-        q = rng.normal(size=4)
-        q /= np.linalg.norm(q)
-        w, x, y, z = q
-        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        if draws is None:
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            w, x, y, z = q
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                          [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        else:
+            R = np.asarray(draws["rotation"][i], dtype=np.float64)
         pos = (pos - pos.mean(0, keepdims=True)) @ R.T + center_pocket.double().numpy()
         if not no_random:
-            if initial_noise_std_proportion >= 0.0:
-                std_rec = float(torch.sqrt(torch.mean(torch.sum(g["receptor"].pos ** 2, dim=1))))
-                std = std_rec * initial_noise_std_proportion / 1.73
+            if draws is not None:
+                pos = pos + np.asarray(draws["tr"][i], dtype=np.float64).reshape(1, 3)
             else:
-                std = -initial_noise_std_proportion * tr_sigma_max
-            pos = pos + rng.normal(size=(1, 3)) * std
+                if initial_noise_std_proportion >= 0.0:
+                    std_rec = float(torch.sqrt(torch.mean(torch.sum(g["receptor"].pos ** 2, dim=1))))
+                    std = std_rec * initial_noise_std_proportion / 1.73
+                else:
+                    std = -initial_noise_std_proportion * tr_sigma_max
+                pos = pos + rng.normal(size=(1, 3)) * std
         g["ligand"].pos = torch.from_numpy(pos.astype(np.float32))
     return data_list
 

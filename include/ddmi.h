@@ -161,8 +161,17 @@ int ddmi_modify_conformer(ddmi_model* m, float* lig_pos, const float* tr_update,
                           const float* tor_update, ddmi_stream stream);
 
 /* The hot loop of sampling() -- utils/sampling.py:96-191 -- for one collated batch, entirely
- * on the device (no host synchronisation).  lig_pos [n_lig,3] is updated in place. */
+ * on the device (no host synchronisation: the call returns once the steps are enqueued).  lig_pos [n_lig,3] is updated
+ * in place. */
 int ddmi_sample(ddmi_model* m, float* lig_pos, const ddmi_sample_cfg* cfg, ddmi_stream stream);
+
+/* One step of the score -> perturbation arithmetic of sampling() -- utils/sampling.py:117-186 -- on caller-owned score
+ * arrays, in place: the NaN guard (:117-131: if any pose's mean translation score is NaN, NaN -> 0.01 * nanmean|x|,
+ * +-inf -> +-that value, per score tensor) followed by  g^2 dt (lambda + T psi / 2) * score + g sqrt(dt (1 + psi)) * z
+ * with the coefficients of step `step` of cfg's schedules.  tr [B,3], rot [B,3], tor [n_tor] or NULL.  This is what
+ * ddmi_sample applies between ddmi_forward and ddmi_modify_conformer. */
+int ddmi_perturb(ddmi_model* m, float* tr, float* rot, float* tor, const ddmi_sample_cfg* cfg, int step,
+                 ddmi_stream stream);
 
 /* Introspection for tests and profiling: copy a named internal buffer to the host.
  * ddmi_debug_shape returns the element count and up to 4 dims; names are listed in DESIGN.md. */

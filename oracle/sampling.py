@@ -144,9 +144,10 @@ def sampling(data_list, model, inference_steps, cfg, noise, schedules=None, batc
                 if record is not None:
                     record.append(dict(t_idx=t_idx, lo=lo, pos_in=batch["ligand"].pos.clone(), tr=tr_score.clone(),
                                        rot=rot_score.clone(), tor=tor_score.clone()))
+                dt = batch["ligand"].pos.dtype      # float32 as in the reference; float64 for the sensitivity runs of the fixtures
                 batch["ligand"].pos = modify_conformer_batch(
-                    batch["ligand"].pos, b, rot_edges, mask_rotate, trp.float(), rotp.float(),
-                    torp.float() if (torp is not None and R > 0) else None).float()
+                    batch["ligand"].pos, b, rot_edges, mask_rotate, trp.to(dt), rotp.to(dt),
+                    torp.to(dt) if (torp is not None and R > 0) else None).to(dt)
             for i in range(b):
                 data_list[lo + i]["ligand"].pos = batch["ligand"].pos[i * n:(i + 1) * n]
     return data_list

@@ -1,0 +1,110 @@
+"""Boundary behaviour of the drop-in objects on the CPU emulation build (no GPU): batch caching across complexes,
+state_dict loading, unsupported arguments, the NaN guard of the step loop, neighbour caps, randomize_position and the
+score-norm tables against what the reference modules hold."""
+import argparse
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from diffdock_amd.config import TINY, config_from_args
+from diffdock_amd.model import MIScoreModel, get_model
+from diffdock_amd.synth import randomize_position
+from diffdock_amd.weights import init_state_dict
+import cases
+from util import graph_from_dict, load_fixture, tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "hipemu", "libddmi_emu.so")
+
+
+@pytest.fixture(scope="module")
+def make():
+    r = subprocess.run(["make", "-j8", "-C", os.path.join(ROOT, "diffdock_amd", "csrc"), "emu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+    def factory(cfg, sd):
+        m = MIScoreModel(cfg, device="cpu", lib_path=EMU)
+        m.load_state_dict(sd)
+        m.set_tables(*tables())
+        return m
+    return factory
+
+
+def test_same_shaped_complexes_do_not_share_a_cached_complex(make):
+    cases.same_shape_complexes_case(make, lambda b: b)
+
+
+def test_nan_guard_matches_reference_semantics(make):
+    cases.nan_guard_case(make, lambda b: b)
+
+
+def test_neighbour_caps_bind_and_match_the_oracle(make):
+    cases.neighbour_cap_case(make, lambda b: b)
+
+
+def test_load_state_dict_accepts_the_reference_modules_unfiltered_keys(make):
+    """A reference confidence checkpoint carries nn.BatchNorm1d's num_batches_tracked counters and e3nn's constant buffers
+    (confidence_predictor.{1,5}.num_batches_tracked, *.tp.*): strict loading must ignore exactly those."""
+    cfg = TINY.replace(confidence_mode=True, sh_lmax=2, num_conv_layers=3, atom_confidence=True, atom_num_confidence_outputs=2)
+    sd = init_state_dict(cfg, seed=2)
+    full = dict(sd)
+    for k in ("confidence_predictor.1.num_batches_tracked", "confidence_predictor.5.num_batches_tracked",
+              "atom_confidence_predictor.1.num_batches_tracked", "atom_confidence_predictor.5.num_batches_tracked"):
+        full[k] = torch.tensor(123)
+    full["conv_layers.0.tp.output_mask"] = torch.ones(4)
+    full["final_tp_tor.w3j_0_1_2"] = torch.ones(3)
+    m = MIScoreModel(cfg, device="cpu", lib_path=EMU)
+    m.load_state_dict(full, strict=True)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({**full, "not_a_weight": torch.zeros(1)}, strict=True)
+    missing = dict(sd)
+    missing.pop(next(iter(sd)))
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(missing, strict=True)
+
+
+def test_get_model_rejects_arguments_outside_the_built_path():
+    base = TINY.to_namespace()
+    assert config_from_args(base).ns == TINY.ns
+    for key, val in (("embedding_type", "fourier"), ("esm_embeddings_model", "esm2_t33"), ("parallel", 2),
+                     ("depthwise_convolution", True), ("sidechain_loss_weight", 0.5), ("tp_weights_layers", 3)):
+        ns = argparse.Namespace(**vars(base))
+        setattr(ns, key, val)
+        with pytest.raises(NotImplementedError):
+            config_from_args(ns)
+    ns = argparse.Namespace(**vars(base))
+    ns.embed_also_ligand = False
+    with pytest.raises(AssertionError):          # the reference asserts it in ligand_embedding (cg_model.py:263)
+        get_model(ns, "cpu", lib_path=EMU)
+    ns.num_prot_emb_layers = 1
+    with pytest.raises(NotImplementedError):
+        config_from_args(ns)
+
+
+def test_randomize_position_matches_reference_execution():
+    """utils/sampling.py:16-58 run by the reference itself with its scipy / numpy / torch draws recorded
+    (tests/golden/make_golden_fullsize.py randpos); the host restatement consumes the same draws."""
+    fx = load_fixture("randpos")
+    stds = {}
+    for tag, c in fx["cases"].items():
+        dl = [graph_from_dict(fx["graph"]) for _ in range(3)]
+        out = randomize_position(dl, False, False, fx["tr_sigma_max"], initial_noise_std_proportion=c["prop"], draws=c["draws"])
+        pos = torch.stack([g["ligand"].pos for g in out])
+        assert (pos - c["pos"]).abs().max() < 1e-5
+        rec = dl[0]["receptor"].pos
+        stds[tag] = float(torch.sqrt(torch.mean(torch.sum(rec ** 2, dim=1)))) * c["prop"] / 1.73 if c["prop"] >= 0 else \
+            -c["prop"] * fx["tr_sigma_max"]
+    # both cases were drawn from the same torch seed: the recorded translations differ exactly by the ratio of the stds
+    a, b = fx["cases"]["prop"]["draws"]["tr"][0], fx["cases"]["sigma"]["draws"]["tr"][0]
+    assert torch.allclose(a / b, torch.full_like(a, stds["prop"] / stds["sigma"]), rtol=1e-5)
+
+
+def test_shipped_score_norm_tables_equal_the_reference_modules():
+    from diffdock_amd.tables import default_tables
+    so3, tor = default_tables()
+    g_so3, g_tor = tables()
+    assert np.array_equal(so3, g_so3, equal_nan=True)        # every index, unconverged small-eps entries and NaNs included
+    assert np.array_equal(tor, g_tor)
