@@ -3,12 +3,21 @@
 
 Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched through
 torch.distributed.run, one rank per GPU.  A "step" = one complete pass of the hot path over one batch:
-all 20 reverse-diffusion steps of the rank's 40 poses of one synthetic 300-residue / 30-atom complex
-(BASELINE.json configs[2]), i.e. 20 score-model forwards + 20 pose updates, entirely on the device
-(ddmi_sample).  Inputs (graph, weights, tables, initial poses) are resident in HBM before the timed
-region.  Each rank owns 40 independent poses (weak scaling: N GPUs sample 40*N poses); the only
-collective is one RCCL all_gather of the final coordinates per step, as the reference's sampler would
-hand them to the confidence model.
+all 20 reverse-diffusion steps of the rank's poses of every complex of the workload, i.e. 20 score-model
+forwards + 20 pose updates per complex, entirely on the device (ddmi_sample).  Inputs (graphs, weights, tables,
+initial poses) are resident in HBM before the timed region.
+
+Workloads (--config; BASELINE.json `configs`, default = the one `metric` is quoted on):
+  configs2 (default)  20 steps x 40 poses of one synthetic 300-residue / 30-atom complex
+  configs1            20 steps x 10 poses of the same complex
+  mix                 SURVEY 8d's PDBBind-test-like mix: the nine complexes Nr in {150,300,500} x Nl in {20,30,45},
+                      40 poses each, sampled one complex after the other (one model handle per complex, all resident)
+  configs4            large-pocket stress: 1500 residues / 80 atoms, 40 poses, 4.8 M cross edges per direction
+
+Multi-GPU (--scaling): "weak" (default; the driver's contract) = every rank samples its own 40 poses of the complex;
+"strong" = BASELINE configs[3] / north_star: the SAME 40 poses sharded in contiguous blocks over the ranks (5 per GPU at 8).
+Either way the only collective is one RCCL all_gather of the final coordinates per step, as the reference's sampler
+would hand them to the confidence model.
 
 Cross graph: the untrained (random-weight) score model cannot keep the ligand in the pocket, and with the
 reference's dynamic cutoff 3*sigma_tr+20 A the ligand would drift out of range and the cross graph would
@@ -18,8 +27,9 @@ edge, as SURVEY.md 8 assumes: 1.02 M edges per interaction layer at 40 poses) an
 edge count in `config`.
 
 Extra objects on the JSON line: `roofline` (dominant kernel, HIP-event timed inside the timed region) and
-`cpu_baseline` (the oracle = pure-torch restatement of the reference, timed on this host's cores on a
-bounded sample: 2 poses x the first 3 of the 20 steps of the same complex, extrapolated linearly).
+`cpu_baseline` (bounded CPU sample of the same workload: the reference's own sampling() + CGModel executed under the
+third-party stand-ins of tests/golden/make_golden.py when /root/reference is present -- kind "reference-executed" --
+else the oracle = pure-torch restatement, kind "port", which is what the GPU box can run).
 """
 import argparse
 import json
@@ -34,17 +44,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from diffdock_amd.config import DDL_SYNTH  # noqa: E402
-from diffdock_amd.hetero import HeteroBatch, set_time  # noqa: E402
+from diffdock_amd.dist import shard_bounds  # noqa: E402
+from diffdock_amd.hetero import HeteroBatch  # noqa: E402
 from diffdock_amd.model import MIScoreModel  # noqa: E402
 from diffdock_amd.synth import make_complex, make_pose_list  # noqa: E402
 from diffdock_amd.tables import default_tables  # noqa: E402
 from diffdock_amd.weights import init_state_dict  # noqa: E402
 
-INFERENCE_STEPS, SAMPLES, N_RES, N_LIG = 20, 40, 300, 30
+INFERENCE_STEPS, SAMPLES = 20, 40
 HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS = 8000.0, 157.3     # /opt/skills/guides/MI355X_MICROARCH.md
 TEMP = dict(temp_sampling=[1.170050527854316, 2.06391612594481, 7.044261621607846],       # default_inference_args.yaml
             temp_psi=[0.727287304570729, 0.9022615585677628, 0.5946212391366862],
             temp_sigma_data=[0.9299802531572672, 0.7464326999906034, 0.6943254174849822])
+# (n_res, n_lig, complex seed) of every complex of a workload
+WORKLOADS = {
+    "configs2": dict(complexes=[(300, 30, 0)], samples=40, label="BASELINE configs[2]"),
+    "configs1": dict(complexes=[(300, 30, 0)], samples=10, label="BASELINE configs[1]"),
+    "mix": dict(complexes=[(nr, nl, 10 + 3 * i + j) for i, nr in enumerate((150, 300, 500)) for j, nl in enumerate((20, 30, 45))],
+                samples=40, label="SURVEY 8d PDBBind-test-like mix (9 complexes, Nr in {150,300,500} x Nl in {20,30,45})"),
+    "configs4": dict(complexes=[(1500, 80, 8)], samples=40, label="BASELINE configs[4] large-pocket stress"),
+}
+# last committed PMC pass for the dominant kernel (tools/round_profile.sh, separate --pmc passes, gfx950 corrections applied)
+TRAFFIC_RECORD = os.path.join(ROOT, "profiles", "traffic_latest.json")
 
 
 def bench_cfg():
@@ -61,7 +82,9 @@ def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr, fused=True, fused_lig=True):
     Groups that run k_conv_fused keep the contracted rows in LDS: their HBM bytes are the x rows, the hidden rows and the
     messages, and their node term is counted once per gather NODE (the kernel repeats it per 32-edge virtual node of a
     ligand atom -- that repetition is not algorithmic work).  With DDMI_FUSED_LIG < 3 the ligand-gather groups run
-    k_node_contract + k_edge_conv with the rows Y in HBM."""
+    k_node_contract + k_edge_conv with the rows Y in HBM.  `ref_flops` = the same launch priced by SURVEY 8(d)'s formula
+    for the REFERENCE's association (per edge 2*(3ns*3ns + 3ns*W) + 6W, W = weight_numel): the re-association removes
+    13x of it, so a fraction of peak computed with it would exceed 1."""
     from diffdock_amd.irreps import parse_irreps, sh_irreps
     from diffdock_amd.o3 import faster_path_table, fctp_path_table
     out = []
@@ -72,44 +95,82 @@ def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr, fused=True, fused_lig=True):
         table, _ = faster_path_table(a, b) if cfg.faster else fctp_path_table(a, sh_irreps(cfg.sh_lmax), b)
         NT = sum(p.di * p.mul_out for p in table)
         mac_node = sum(p.mul_in * p.mul_out * p.di for p in table)
+        W = sum(p.mul_in * p.mul_out for p in table)             # weight_numel of the layer
         d_in, d_out = sum(x.dim for x in parse_irreps(a)), sum(x.dim for x in parse_irreps(b))
         # (gather nodes, target nodes, edges, gather side is receptor)
         groups = [(nL, nL, e_ll, False), (nR, nL, e_lr, True), (nR, nR, e_rr, True), (nL, nR, e_lr, False)]
         for gcount, tcount, E, rec_gather in (groups if l < L - 1 else groups[:2]):
             H = 3 * cfg.ns
             node_flops, edge_flops = 2.0 * gcount * HK * mac_node, 2.0 * E * HK * NT
+            ref_flops = E * (2.0 * (H * H + H * W) + 6.0 * W)
             if fused and (rec_gather or fused_lig):
-                out.append({"k_conv_fused": {"flops": node_flops + edge_flops,
+                out.append({"k_conv_fused": {"flops": node_flops + edge_flops, "ref_flops": ref_flops,
                                              "bytes": gcount * d_in * 4.0 + E * (H * 4.0 + d_out * 4.0)}})
             else:
-                out.append({"k_edge_conv": {"flops": edge_flops,
+                out.append({"k_edge_conv": {"flops": edge_flops, "ref_flops": ref_flops,
                                             "bytes": gcount * HK * NT * 4.0 + E * (H * 4.0 + d_out * 4.0) + (gcount + tcount) * H * 4.0},
-                            "k_node_contract": {"flops": node_flops, "bytes": gcount * (HK * NT * 4.0 + d_in * 4.0)}})
+                            "k_node_contract": {"flops": node_flops, "ref_flops": 0.0, "bytes": gcount * (HK * NT * 4.0 + d_in * 4.0)}})
     return out
 
 
-def cpu_baseline(cfg, sd, so3_t, tor_t, g):
-    """Oracle (restated reference, pure torch fp32, all host cores) on a bounded sample of the same workload."""
-    from oracle.cg_model import CGModelOracle
-    from oracle.sampling import sampling as oracle_sampling
-    threads = min(os.cpu_count(), 64)     # the oracle's small einsums do not scale past a few dozen threads
+def cpu_baseline(cfg, sd, so3_t, tor_t, g, full=False):
+    """Bounded CPU sample of the same workload on this host's cores: the first steps of the 20-step schedule (largest cross
+    cutoffs = the same all-pairs graph as the GPU run) for a few poses, extrapolated linearly to 20 steps."""
+    threads = min(os.cpu_count(), 64)     # the small einsums of the per-edge tensor product do not scale past a few dozen threads
     torch.set_num_threads(threads)
-    n_s, n_steps = 2, 3
-    dl = make_pose_list(g, n_s, tr_sigma_max=cfg.tr_sigma_max, seed=77, initial_noise_std_proportion=0.3)
-    model = CGModelOracle(cfg, sd, so3_t, tor_t)
-    R = int(dl[0]["ligand"].edge_mask.sum())
-    gen = torch.Generator().manual_seed(0)
-    noise = (torch.randn(INFERENCE_STEPS, n_s, 3, generator=gen), torch.randn(INFERENCE_STEPS, n_s, 3, generator=gen),
-             torch.randn(INFERENCE_STEPS, n_s * R, generator=gen))
     s = t_schedule(INFERENCE_STEPS)
-    t0 = time.time()
-    # first n_steps of the 20-step schedule (largest cross cutoffs = the same all-pairs graph as the GPU run)
-    oracle_sampling(dl, model, n_steps, cfg, noise, schedules=(s, s, s), batch_size=n_s, **TEMP)
-    dt = time.time() - t0
+    big = g["receptor"].pos.shape[0] * g["ligand"].pos.shape[0] > 50000
+    if os.path.isdir("/root/reference") and os.path.exists(os.path.join(ROOT, "tests", "golden", "make_golden.py")):
+        # the reference's own python: utils/sampling.sampling + models/cg_model.CGModel (FasterTensorProduct conv layers)
+        import copy
+        from functools import partial
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        from make_golden import install_stubs
+        cwd = os.getcwd()
+        scratch = os.path.join(ROOT, ".scratch", "tables")
+        os.makedirs(scratch, exist_ok=True)
+        os.chdir(scratch)                  # utils/so3.py / utils/torus.py cache their tables in the working directory
+        try:
+            install_stubs()
+            from models import tensor_layers
+            tensor_layers.FasterTensorProduct.irreps_out = property(lambda self: self.out_irreps)   # reference defect, make_golden.py
+            from utils.utils import get_model
+            from utils.diffusion_utils import t_to_sigma as t_to_sigma_compl
+            from utils import sampling as ref_sampling
+            args = cfg.to_namespace()
+            t_to_sigma = partial(t_to_sigma_compl, args=args)
+            model = get_model(args, torch.device("cpu"), t_to_sigma=t_to_sigma, no_parallel=True)
+            model.load_state_dict(sd, strict=False)
+            model.eval()
+            n_s, n_steps = (1, 2) if big else (4, 5)
+            dl = make_pose_list(g, n_s, tr_sigma_max=cfg.tr_sigma_max, seed=77, initial_noise_std_proportion=0.3)
+            torch.manual_seed(0)
+            t0 = time.time()
+            ref_sampling.sampling(copy.deepcopy(dl), model, n_steps, s, s, s, torch.device("cpu"), t_to_sigma, args,
+                                  batch_size=n_s, no_final_step_noise=False, **TEMP)
+            dt = time.time() - t0
+        finally:
+            os.chdir(cwd)
+        kind = "reference-executed"
+    else:
+        from oracle.cg_model import CGModelOracle
+        from oracle.sampling import sampling as oracle_sampling
+        n_s, n_steps = (1, 2) if big else (2, 3)
+        dl = make_pose_list(g, n_s, tr_sigma_max=cfg.tr_sigma_max, seed=77, initial_noise_std_proportion=0.3)
+        model = CGModelOracle(cfg, sd, so3_t, tor_t)
+        R = int(dl[0]["ligand"].edge_mask.sum())
+        gen = torch.Generator().manual_seed(0)
+        noise = (torch.randn(INFERENCE_STEPS, n_s, 3, generator=gen), torch.randn(INFERENCE_STEPS, n_s, 3, generator=gen),
+                 torch.randn(INFERENCE_STEPS, n_s * R, generator=gen))
+        t0 = time.time()
+        oracle_sampling(dl, model, n_steps, cfg, noise, schedules=(s, s, s), batch_size=n_s, **TEMP)
+        dt = time.time() - t0
+        kind = "port"
     poses_per_s = n_s / (dt / n_steps * INFERENCE_STEPS)
-    return {"value": poses_per_s, "unit": "poses/s", "cores": threads, "kind": "port",
-            "sample": f"{n_s} poses x {n_steps} of {INFERENCE_STEPS} steps, same complex and weights, "
-                      f"extrapolated linearly; torch {torch.__version__}, {dt:.1f} s wall"}
+    return {"value": poses_per_s, "unit": "poses/s", "cores": threads, "kind": kind,
+            "sample": f"{n_s} poses x the first {n_steps} of {INFERENCE_STEPS} steps of the "
+                      f"{g['receptor'].pos.shape[0]}-residue / {g['ligand'].pos.shape[0]}-atom complex, same weights, extrapolated "
+                      f"linearly to {INFERENCE_STEPS} steps; torch {torch.__version__}, {threads} threads, {dt:.1f} s wall"}
 
 
 def main():
@@ -117,7 +178,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=SAMPLES, help="poses per GPU")
+    ap.add_argument("--config", default="configs2", choices=sorted(WORKLOADS))
+    ap.add_argument("--samples", type=int, default=None, help="poses per complex (per GPU with weak scaling); default: the workload's")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="multi-GPU: weak = 40 poses per GPU; strong = the same 40 poses sharded over the GPUs (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lib", default=None, help="path of an alternative libddmi build (kernel A/B experiments)")
     ap.add_argument("--all-atoms", action="store_true",
@@ -134,32 +198,53 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
+    wl = WORKLOADS[args.config]
     cfg = bench_cfg()
     if args.all_atoms:
         cfg = cfg.replace(all_atoms=True)
     sd = init_state_dict(cfg, seed=1234)
     so3_t, tor_t = default_tables()
-    model = MIScoreModel(cfg, device=str(dev), lib_path=args.lib)
-    model.load_state_dict(sd)
-    model.set_tables(so3_t, tor_t)
-    g = make_complex(seed=0, n_res=N_RES, n_lig=N_LIG, all_atoms=args.all_atoms)
-    B = args.samples
-    dl = make_pose_list(g, B, tr_sigma_max=cfg.tr_sigma_max, seed=1000 + rank, initial_noise_std_proportion=0.3)
-    batch = HeteroBatch.from_data_list(dl).to(dev)
+    S = args.samples or wl["samples"]              # poses per complex
+    strong = args.scaling == "strong" and world > 1
+    lo, hi = shard_bounds(S, rank, world) if strong else (0, S)
+    B = hi - lo                                    # poses of each complex on this rank
     sched = t_schedule(INFERENCE_STEPS)
-    ids = list(range(rank * B, (rank + 1) * B))
-    gathered = [torch.empty(B * N_LIG, 3, device=dev) for _ in range(world)] if world > 1 else None
+    jobs = []
+    for (n_res, n_lig, cseed) in wl["complexes"]:
+        model = MIScoreModel(cfg, device=str(dev), lib_path=args.lib)
+        model.load_state_dict(sd)
+        model.set_tables(so3_t, tor_t)
+        g = make_complex(seed=cseed, n_res=n_res, n_lig=n_lig, all_atoms=args.all_atoms)
+        # strong: all ranks draw the same S initial poses and keep their block; weak: every rank its own S poses
+        dl = make_pose_list(g, S, tr_sigma_max=cfg.tr_sigma_max, seed=1000 + (0 if strong else rank), initial_noise_std_proportion=0.3)
+        dl = dl[lo:hi]
+        batch = HeteroBatch.from_data_list(dl).to(dev) if B > 0 else None
+        ids = list(range(lo, hi)) if strong else list(range(rank * S, (rank + 1) * S))
+        cap = max(shard_bounds(S, r, world)[1] - shard_bounds(S, r, world)[0] for r in range(world)) if strong else S
+        gathered = [torch.empty(cap * n_lig, 3, device=dev) for _ in range(world)] if world > 1 else None
+        jobs.append(dict(model=model, g=g, batch=batch, ids=ids, n_res=n_res, n_lig=n_lig, gathered=gathered, cap=cap))
 
     def one_step(seed):
-        pos = model.sample_batch(batch, INFERENCE_STEPS, (sched, sched, sched), seed=seed, sample_ids=ids,
-                                 no_final_step_noise=True, **TEMP)
-        if world > 1:
-            dist.all_gather(gathered, pos)
-        return pos
+        last = None
+        for j in jobs:
+            if j["batch"] is not None:
+                pos = j["model"].sample_batch(j["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=seed, sample_ids=j["ids"],
+                                              no_final_step_noise=True, **TEMP)
+            else:
+                pos = torch.zeros(0, 3, device=dev)
+            if world > 1:     # one all_gather per complex: the final coordinates of every pose on every rank
+                buf = pos
+                if pos.shape[0] != j["cap"] * j["n_lig"]:
+                    buf = torch.zeros(j["cap"] * j["n_lig"], 3, device=dev)
+                    buf[:pos.shape[0]] = pos
+                dist.all_gather(j["gathered"], buf)
+            last = pos
+        return last
 
     for w in range(args.warmup):
         one_step(w)
-    model.set_kernel_timing(True)
+    for j in jobs:
+        j["model"].set_kernel_timing(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -174,17 +259,29 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    timings = model.kernel_timings()
-    model.set_kernel_timing(False)
+    timings = {}
+    for j in jobs:
+        for k, (ms, n) in j["model"].kernel_timings().items():
+            a = timings.get(k, (0.0, 0))
+            timings[k] = (a[0] + ms, a[1] + n)
+        j["model"].set_kernel_timing(False)
     assert os.environ.get("DDMI_BENCH_NOCHECK") or torch.isfinite(pos).all()   # NOCHECK: timing-only ablation builds
 
     if rank == 0:
-        # edges actually processed by the last forward of the run
-        e_ll = int(model.debug_buffer("goff_ll")[-1])
-        e_lr = int(model.debug_buffer("offs_l")[-1])
-        e_rr = int(model.debug_buffer("rr_goff")[-1])
-        L = cfg.num_conv_layers
-        edges_per_layer = e_ll + 2 * e_lr + e_rr
+        # edges actually processed by the last forward of the run, per complex
+        edges, work = [], []
+        fused = "k_conv_fused" in timings
+        fused_lig = "k_edge_conv" not in timings and "k_conv_fused_load" not in timings
+        for j in jobs:
+            m = j["model"]
+            e_ll, e_lr, e_rr = int(m.debug_buffer("goff_ll")[-1]), int(m.debug_buffer("offs_l")[-1]), int(m.debug_buffer("rr_goff")[-1])
+            edges.append(dict(n_res=j["n_res"], n_lig=j["n_lig"], lig_lig=e_ll, cross_each_direction=e_lr, rec_rec=e_rr,
+                              **({"lig_atom_each_direction": int(m.debug_buffer("offs_la_l")[-1]),
+                                  "atom_atom": int(m.debug_buffer("aa_goff")[-1]),
+                                  "atom_rec_each_direction": int(m.debug_buffer("ar_goff")[-1]),
+                                  "atoms": int(j["batch"]["atom"].pos.shape[0])} if args.all_atoms else {})))
+            work += conv_work(cfg, B * j["n_lig"], B * j["n_res"], e_ll, e_lr, e_rr, fused=fused, fused_lig=fused_lig)
+        n_forwards = args.steps * INFERENCE_STEPS * len(jobs)
         # ---- roofline of the dominant kernel (by HIP-event time inside the timed region)
         kern = {k: v for k, v in timings.items() if k.startswith("k_") or k == "conv_fc1_gemms"}
         dom = max(kern, key=lambda k: kern[k][0]) if kern else None
@@ -192,70 +289,93 @@ def main():
         if dom in ("k_edge_conv", "k_node_contract", "k_conv_fused") and not args.all_atoms:
             ms, n = kern[dom]
             avg_s = ms / max(n, 1) * 1e-3
-            work = [w[dom] for w in conv_work(cfg, B * N_LIG, B * N_RES, e_ll, e_lr, e_rr, fused="k_conv_fused" in kern,
-                                              fused_lig="k_edge_conv" not in kern and "k_conv_fused_load" not in kern)
-                    if dom in w]
-            launches_per_forward = len(work)
-            flops = sum(w["flops"] for w in work) / launches_per_forward
-            bytes_ = sum(w["bytes"] for w in work) / launches_per_forward
+            w_dom = [w[dom] for w in work if dom in w]
+            n_launch = len(w_dom)                         # launches of this kernel in one forward of every complex
+            flops = sum(w["flops"] for w in w_dom) / n_launch
+            ref_flops = sum(w["ref_flops"] for w in w_dom) / n_launch
+            bytes_ = sum(w["bytes"] for w in w_dom) / n_launch
             ridge = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+            traffic, traffic_src = None, None
+            if os.path.exists(TRAFFIC_RECORD):        # counter bytes are collected by a separate rocprofv3 --pmc pass (tools/round_profile.sh)
+                rec = json.load(open(TRAFFIC_RECORD))
+                if rec.get("kernel") == dom and rec.get("config") == args.config:
+                    traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
             if flops / bytes_ > ridge:
                 ach = flops / avg_s / 1e12
                 roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic}
             else:
                 ach = bytes_ / avg_s / 1e9
                 roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None}
-            roof.update({"avg_launch_ms": avg_s * 1e3, "launches": n, "launches_per_forward": launches_per_forward,
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic}
+            fwd_ms = timings.get("forward_total", (0.0, 0))[0] / max(n_forwards, 1)
+            conv_flops_fwd = sum(w["flops"] for w in w_dom) / len(jobs)
+            roof.update({"traffic_source": traffic_src, "traffic_unit": "bytes per launch (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE)",
+                         "avg_launch_ms": avg_s * 1e3, "launches": n, "launches_per_forward": n_launch // len(jobs),
                          "alg_flops_per_launch": flops, "alg_bytes_per_launch": bytes_,
+                         "alg_flops_reference_assoc": ref_flops,
+                         "frac_if_priced_by_reference_assoc": ref_flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         # wall-clock view: this kernel's algorithmic flops of one forward / the forward's HIP-event duration
+                         "wall_frac": (conv_flops_fwd / (fwd_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if fwd_ms > 0 else None,
+                         "forward_ms": fwd_ms,
                          "concurrent_streams": 1 if os.environ.get("DDMI_STREAMS") == "1" else 2,
                          "alg_definition": "mean over the launches of this kernel in one forward -- all four edge groups of every "
-                                           "layer, 22 launches (exact f32 on v_mfma_f32_16x16x4_f32, "
-                                           "peak = dense f32 MFMA); k_conv_fused: 2*145*sum(mul_in*mul_out*din) flop per gather node "
-                                           "+ 2*145*NT flop per edge, bytes = x rows + 576 B hidden row + 624 B message per edge; "
+                                           "layer (exact f32 on v_mfma_f32_16x16x4_f32, peak = dense f32 MFMA); "
+                                           "k_conv_fused: 2*145*sum(mul_in*mul_out*din) flop per gather node "
+                                           "+ 2*145*NT flop per edge (the re-associated contraction, DESIGN 2: 13x fewer flops than the "
+                                           "reference's association, which alg_flops_reference_assoc prices by SURVEY 8d's formula), "
+                                           "bytes = x rows + 576 B hidden row + 624 B message per edge; "
                                            "k_edge_conv: 2*145*NT flop/edge, bytes = contracted rows Y (145*NT*4 B per gather node) + "
                                            "hidden + message rows; k_node_contract: node flops, Y written once.  With 2 streams the "
                                            "ligand-gather launches run concurrently with the receptor-gather ones, so the launch "
-                                           "durations overlap (their sum exceeds the wall time); DDMI_STREAMS=1 serialises them"})
-            if roof["concurrent_streams"] == 2 and dom == "k_conv_fused" and world == 1:
+                                           "durations overlap (their sum exceeds the wall time): `serialised` times the same kernel on "
+                                           "one stream, `wall_frac` uses the forward's own duration"})
+            if roof["concurrent_streams"] == 2 and dom == "k_conv_fused" and world == 1 and len(jobs) == 1:
                 # the same kernel timed with the launches serialised on ONE stream (untimed extra pass, second handle):
                 # with two streams the launch durations overlap, so the figures above understate the kernel alone
+                j = jobs[0]
                 os.environ["DDMI_STREAMS"] = "1"
                 m1 = MIScoreModel(cfg, device=str(dev), lib_path=args.lib)
                 del os.environ["DDMI_STREAMS"]
                 m1.load_state_dict(sd)
                 m1.set_tables(so3_t, tor_t)
-                m1.sample_batch(batch, INFERENCE_STEPS, (sched, sched, sched), seed=7, sample_ids=ids, no_final_step_noise=True, **TEMP)
+                m1.sample_batch(j["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=7, sample_ids=j["ids"], no_final_step_noise=True, **TEMP)
                 m1.set_kernel_timing(True)
-                m1.sample_batch(batch, INFERENCE_STEPS, (sched, sched, sched), seed=8, sample_ids=ids, no_final_step_noise=True, **TEMP)
+                m1.sample_batch(j["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=8, sample_ids=j["ids"], no_final_step_noise=True, **TEMP)
                 torch.cuda.synchronize()
-                ms1, n1 = m1.kernel_timings()[dom]
+                t1 = m1.kernel_timings()
+                ms1, n1 = t1[dom]
                 ach1 = flops / (ms1 / max(n1, 1) * 1e-3) / 1e12
                 roof["serialised"] = {"avg_launch_ms": ms1 / max(n1, 1), "launches": n1, "achieved": ach1,
-                                      "frac": ach1 / MFMA_F32_PEAK_TFLOPS}
+                                      "frac": ach1 / MFMA_F32_PEAK_TFLOPS,
+                                      "forward_ms": t1["forward_total"][0] / max(t1["forward_total"][1], 1)}
                 del m1
-        cpu = None if (args.no_cpu_baseline or args.all_atoms or world > 1) else cpu_baseline(cfg, sd, so3_t, tor_t, g)   # N = 1 only
+        cpu = None
+        if not (args.no_cpu_baseline or args.all_atoms or world > 1):     # N = 1 only
+            cpu = cpu_baseline(cfg, sd, so3_t, tor_t, jobs[len(jobs) // 2]["g"])
+            if len(jobs) > 1:
+                cpu["sample"] += " (the middle complex of the mix stands for all nine)"
+        (n_res0, n_lig0, _) = wl["complexes"][0]
+        shape = f"synthetic {n_res0}-residue receptor / {n_lig0}-atom ligand" if len(jobs) == 1 else f"{len(jobs)} synthetic complexes"
+        total_poses = (S if strong else world * S) * len(jobs)
         out = {
             "metric": "poses/sec (20 steps x 40 samples, DiffDock-L score model)" if not args.all_atoms else
                       "poses/sec (20 steps x 40 samples, all-atom score model -- secondary workload)",
-            "value": world * B * args.steps / dt,
+            "value": total_poses * args.steps / dt,
             "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: DDL-synth score model (ns=48 nv=10 6 layers sh_lmax=1), "
-                                   f"{INFERENCE_STEPS} steps x {B} poses/GPU, synthetic {N_RES}-residue receptor / "
-                                   f"{N_LIG}-atom ligand, cross graph pinned at its upper bound (static 80 A cutoff), "
-                                   f"low-temperature SDE, random-init weights",
-                       "poses_per_gpu": B, "inference_steps": INFERENCE_STEPS, "edges_per_layer": edges_per_layer,
-                       "edges": {"lig_lig": e_ll, "cross_each_direction": e_lr, "rec_rec": e_rr,
-                                 **({"lig_atom_each_direction": int(model.debug_buffer("offs_la_l")[-1]),
-                                     "atom_atom": int(model.debug_buffer("aa_goff")[-1]),
-                                     "atom_rec_each_direction": int(model.debug_buffer("ar_goff")[-1]),
-                                     "atoms": int(batch["atom"].pos.shape[0])} if args.all_atoms else {})},
-                       "parallelism": f"pose-sharded x{world}, 1 all_gather/step" if world > 1 else "single GPU"},
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{wl['label']}: DDL-synth score model (ns=48 nv=10 6 layers sh_lmax=1), "
+                                   f"{INFERENCE_STEPS} steps x {S} poses per complex, {shape}, cross graph pinned at its upper bound "
+                                   f"(static 80 A cutoff), low-temperature SDE, random-init weights",
+                       "name": args.config, "poses_per_complex": S, "poses_per_gpu": B * len(jobs), "inference_steps": INFERENCE_STEPS,
+                       "complexes": len(jobs), "edges": edges[0] if len(edges) == 1 else edges,
+                       "edges_per_layer": sum(e["lig_lig"] + 2 * e["cross_each_direction"] + e["rec_rec"] for e in edges),
+                       "parallelism": ("single GPU" if world == 1 else
+                                       f"strong: the {S} poses of a complex sharded in blocks over {world} GPUs, 1 all_gather per complex" if strong else
+                                       f"weak: {S} poses per GPU x {world} GPUs (pose-sharded, 1 all_gather per complex)")},
             "roofline": roof, "cpu_baseline": cpu,
-            "phase_ms_per_forward": {k: v[0] / max(args.steps * INFERENCE_STEPS, 1) for k, v in timings.items()},
+            "phase_ms_per_forward": {k: v[0] / max(n_forwards, 1) for k, v in timings.items()},
         }
         print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,179 @@
+"""Minimal featurisation I/O: PDB -> C-alpha receptor graph, SDF/MOL (V2000) -> ligand geometry graph.
+
+What the reference does with ProDy + RDKit (datasets/process_mols.py:117-200 receptor, :279-301 ligand,
+utils/torsion.py:15-45 rotatable-bond masks) restated for the parts that are plain geometry / graph theory:
+
+  read_pdb_calpha      residues that have a CA atom (ProDy's `pdb.ca`), residue-type index in
+                       `possible_amino_acids` (process_mols.py:48-50; non-standard names -> 'misc')
+  receptor_graph       `new_extract_receptor_structure` (:161-200): neighbours within `neighbor_cutoff`, the
+                       `max_neighbors` nearest if there are more, the nearest one if there is none; edge_index = [neighbour; centre]
+  read_sdf             V2000 atom / bond blocks; hydrogens dropped like `remove_hs=True`
+  ligand_graph         get_lig_graph (:279-301): both directions interleaved, one-hot bond type (single, double, triple, aromatic)
+  transformation_mask  get_transformation_mask (utils/torsion.py:15-45) with networkx, same component choice
+
+NOT restated (declared external inputs): the 15 RDKit chemistry-perception atom features (chirality, degree incl. implicit
+hydrogens, formal charge, implicit valence, hybridisation, aromaticity, ring membership -- process_mols.py:97-112; only the
+atomic-number column is filled, the rest is 0 unless `atom_features` is passed in), aromaticity perception of bond
+types (a kekulised file keeps its single/double types), and the ESM language-model embeddings (`lm_embeddings`).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .hetero import HeteroData
+
+POSSIBLE_AMINO_ACIDS = ['ALA', 'ARG', 'ASN', 'ASP', 'CYS', 'GLN', 'GLU', 'GLY', 'HIS', 'ILE', 'LEU', 'LYS', 'MET',
+                        'PHE', 'PRO', 'SER', 'THR', 'TRP', 'TYR', 'VAL', 'HIP', 'HIE', 'TPO', 'HID', 'LEV', 'MEU',
+                        'PTR', 'GLV', 'CYT', 'SEP', 'HIZ', 'CYM', 'GLM', 'ASQ', 'TYS', 'CYX', 'GLZ', 'misc']
+_STANDARD = set(POSSIBLE_AMINO_ACIDS[:20])
+_ELEMENTS = ("H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn Ga Ge As Se Br Kr Rb Sr Y Zr "
+             "Nb Mo Tc Ru Rh Pd Ag Cd In Sn Sb Te I Xe Cs Ba La Ce Pr Nd Pm Sm Eu Gd Tb Dy Ho Er Tm Yb Lu Hf Ta W Re Os Ir "
+             "Pt Au Hg Tl Pb Bi Po At Rn Fr Ra Ac Th Pa U Np Pu Am Cm Bk Cf Es Fm Md No Lr Rf Db Sg Bh Hs Mt Ds").split()
+_Z = {e.upper(): i + 1 for i, e in enumerate(_ELEMENTS)}
+BOND_TYPES = {1: 0, 2: 1, 3: 2, 4: 3}     # SDF bond order -> index in {SINGLE, DOUBLE, TRIPLE, AROMATIC} (process_mols.py:21)
+
+
+def read_pdb_calpha(path):
+    """-> (coords float64 [n,3], residue type index int64 [n], chain ids list[str]) for every residue with a CA atom, in
+    file order; alternate locations other than ' ' / 'A' and HETATM records are skipped."""
+    coords, types, chains, seen = [], [], [], set()
+    with open(path) as f:
+        for line in f:
+            if not line.startswith("ATOM"):
+                continue
+            if line[12:16].strip() != "CA" or line[16] not in (" ", "A"):
+                continue
+            key = (line[21], line[22:27])
+            if key in seen:
+                continue
+            seen.add(key)
+            res = line[17:20].strip()
+            # the reference goes through one-letter codes (pdb.ca.getSequence -> aa_short2long): anything ProDy does not map
+            # to one of the 20 letters becomes 'misc'
+            types.append(POSSIBLE_AMINO_ACIDS.index(res) if res in _STANDARD else len(POSSIBLE_AMINO_ACIDS) - 1)
+            coords.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+            chains.append(line[21])
+    return np.asarray(coords, dtype=np.float64), np.asarray(types, dtype=np.int64), chains
+
+
+def receptor_graph(coords, neighbor_cutoff=15.0, max_neighbors=24):
+    """process_mols.py:171-192 (non-kNN branch) on float32 coordinates, scipy-cdist distances in float64 like the reference."""
+    c = np.asarray(coords, dtype=np.float32).astype(np.float64)
+    d = np.sqrt(((c[:, None, :] - c[None, :, :]) ** 2).sum(-1))
+    src_list, dst_list = [], []
+    for i in range(len(c)):
+        dst = list(np.where(d[i] < neighbor_cutoff)[0])
+        dst.remove(i)
+        cap = max_neighbors if max_neighbors else 1000
+        if len(dst) > cap:
+            dst = list(np.argsort(d[i]))[1:cap + 1]
+        if len(dst) == 0:
+            dst = list(np.argsort(d[i]))[1:2]
+        src_list += [i] * len(dst)
+        dst_list += [int(x) for x in dst]
+    return np.asarray([dst_list, src_list], dtype=np.int64)
+
+
+def read_sdf(path, remove_hs=True):
+    """First molecule of a V2000 mol / sdf file -> (coords [n,3], atomic numbers [n], bonds [(a, b, order)])."""
+    with open(path) as f:
+        lines = f.read().splitlines()
+    counts = lines[3]
+    na, nb = int(counts[0:3]), int(counts[3:6])
+    if "V2000" not in counts:
+        raise ValueError("only V2000 connection tables are read")
+    xyz, z = [], []
+    for l in lines[4:4 + na]:
+        xyz.append([float(l[0:10]), float(l[10:20]), float(l[20:30])])
+        z.append(_Z.get(l[31:34].strip().upper(), 0))
+    bonds = []
+    for l in lines[4 + na:4 + na + nb]:
+        bonds.append((int(l[0:3]) - 1, int(l[3:6]) - 1, int(l[6:9])))
+    xyz, z = np.asarray(xyz, dtype=np.float64), np.asarray(z, dtype=np.int64)
+    if remove_hs:
+        keep = np.where(z != 1)[0]
+        remap = -np.ones(na, dtype=np.int64)
+        remap[keep] = np.arange(len(keep))
+        bonds = [(int(remap[a]), int(remap[b]), o) for a, b, o in bonds if remap[a] >= 0 and remap[b] >= 0]
+        xyz, z = xyz[keep], z[keep]
+    return xyz, z, bonds
+
+
+def ligand_bond_arrays(bonds):
+    """get_lig_graph: edge_index [2, 2*nb] (both directions interleaved) and one-hot edge_attr [2*nb, 4]."""
+    row, col, et = [], [], []
+    for a, b, o in bonds:
+        row += [a, b]
+        col += [b, a]
+        et += 2 * [BOND_TYPES.get(o, 0)]
+    attr = np.zeros((len(et), 4), dtype=np.float32)
+    attr[np.arange(len(et)), et] = 1.0
+    return np.asarray([row, col], dtype=np.int64).reshape(2, -1), attr
+
+
+def transformation_mask(n_atoms, edge_index):
+    """utils/torsion.py:15-45 with networkx (same calls: undirected copy, remove_edge, is_connected,
+    sorted(connected_components, key=len)[0]).  edge_index: [2, 2*nb], directed pairs interleaved."""
+    import networkx as nx
+    edges = np.asarray(edge_index).T
+    G = nx.DiGraph()
+    G.add_nodes_from(range(n_atoms))
+    G.add_edges_from((int(a), int(b)) for a, b in edges)
+    to_rotate = []
+    for i in range(0, edges.shape[0], 2):
+        assert edges[i, 0] == edges[i + 1, 1]
+        G2 = G.to_undirected()
+        G2.remove_edge(*edges[i])
+        if not nx.is_connected(G2):
+            l = list(sorted(nx.connected_components(G2), key=len)[0])
+            if len(l) > 1:
+                if edges[i, 0] in l:
+                    to_rotate += [[], l]
+                else:
+                    to_rotate += [l, []]
+                continue
+        to_rotate += [[], []]
+    mask_edges = np.asarray([len(l) > 0 for l in to_rotate], dtype=bool)
+    mask_rotate = np.zeros((int(mask_edges.sum()), n_atoms), dtype=bool)
+    idx = 0
+    for i, l in enumerate(to_rotate):
+        if mask_edges[i]:
+            mask_rotate[idx][np.asarray(l, dtype=int)] = True
+            idx += 1
+    return mask_edges, mask_rotate
+
+
+def complex_graph(pdb_path, sdf_path, receptor_radius=15.0, c_alpha_max_neighbors=24, lm_embeddings=None, atom_features=None,
+                  lm_dim=1280, name=None) -> HeteroData:
+    """HeteroData with the schema of the reference's preprocessed complex: receptor C-alpha graph, ligand
+    heavy-atom graph with rotatable-bond masks, both centred on the receptor's C-alpha centroid (`original_center`,
+    datasets/pdbbind.py get_complex).  `lm_embeddings` [n_res, 1280] and `atom_features` [n_lig, 16] are the external
+    inputs (ESM, RDKit); zeros / atomic number only when absent."""
+    rc, rtype, _ = read_pdb_calpha(pdb_path)
+    lc, z, bonds = read_sdf(sdf_path)
+    center = rc.mean(0, keepdims=True)
+    g = HeteroData()
+    rpos = torch.from_numpy((rc - center).astype(np.float32))
+    lm = torch.zeros(len(rc), lm_dim) if lm_embeddings is None else torch.as_tensor(lm_embeddings, dtype=torch.float32)
+    g["receptor"].x = torch.cat([torch.from_numpy(rtype.astype(np.float32))[:, None], lm], 1)
+    g["receptor"].pos = rpos
+    g["receptor"].side_chain_vecs = torch.zeros(len(rc), 10)
+    g["receptor", "rec_contact", "receptor"].edge_index = torch.from_numpy(
+        receptor_graph(rpos.numpy(), receptor_radius, c_alpha_max_neighbors))
+    ei, attr = ligand_bond_arrays(bonds)
+    if atom_features is None:
+        feats = np.zeros((len(z), 16), dtype=np.int64)
+        feats[:, 0] = np.where((z >= 1) & (z <= 118), z - 1, 118)       # safe_index(possible_atomic_num_list, Z)
+    else:
+        feats = np.asarray(atom_features, dtype=np.int64)
+    mask_edges, mask_rotate = transformation_mask(len(z), ei)
+    g["ligand"].x = torch.from_numpy(feats)
+    g["ligand"].pos = torch.from_numpy((lc - center).astype(np.float32))
+    g["ligand"].edge_mask = torch.from_numpy(mask_edges)
+    g["ligand"].mask_rotate = [mask_rotate]
+    g["ligand", "lig_bond", "ligand"].edge_index = torch.from_numpy(ei)
+    g["ligand", "lig_bond", "ligand"].edge_attr = torch.from_numpy(attr)
+    g.name = name or "complex"
+    g.original_center = torch.from_numpy(center.astype(np.float32))
+    return g

@@ -123,3 +123,42 @@ def same_shape_complexes_case(make, place, cfg=TINY):
     m.invalidate_complex()
     assert all(torch.equal(x.cpu(), y) for x, y in zip(m(batch_b)[:3], out_a))
     return out_a, out_b
+
+
+def config0_case(make, place, cfg, tol_pos=2e-3):
+    """BASELINE configs[0]: the reference's example complex data/1a0q (416 residues / 23 heavy atoms, read by
+    diffdock_amd.io -> tests/golden/1a0q_graph.pt), 4 inference steps x 2 samples: the device loop against the oracle's
+    loop on the real geometry (language-model embeddings and RDKit atom features are external inputs: seeded stand-ins)."""
+    from oracle.sampling import sampling as oracle_sampling
+    from util import graph_from_dict, load_fixture, rmsd
+    d = dict(load_fixture("1a0q_graph"))
+    rng = np.random.default_rng(3)
+    if cfg.lm_embedding_type:
+        d["rec_x"] = torch.cat([d["rec_x"], torch.from_numpy((rng.normal(size=(416, cfg.lm_embedding_dim)) * 0.2).astype(np.float32))], 1)
+    from diffdock_amd.config import LIG_FEATURE_DIMS
+    feats = d["lig_x"].clone()
+    for c in range(1, 16):
+        feats[:, c] = torch.from_numpy(rng.integers(0, LIG_FEATURE_DIMS[c], size=23))
+    d["lig_x"] = feats
+    g = graph_from_dict(d)
+    sd = init_state_dict(cfg, seed=17)
+    B, steps = 2, 4
+    dl = make_pose_list(g, B, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.2)
+    R = int(d["edge_mask"].sum())
+    gen = torch.Generator().manual_seed(4)
+    noise = (torch.randn(steps, B, 3, generator=gen), torch.randn(steps, B, 3, generator=gen), torch.randn(steps, B * R, generator=gen))
+    s = get_t_schedule(steps)
+    batch = HeteroBatch.from_data_list(dl)
+    set_time(batch, s[0], s[0], s[0], B)
+    om = oracle_model(cfg, sd)
+    ref0 = om(batch)[:3]
+    m = make(cfg, sd)
+    assert_scores_close(m(place(batch))[:3], ref0, what="1a0q step 0")
+    ref = oracle_sampling([x.clone() for x in dl], om, steps, cfg, noise, schedules=(s, s, s), batch_size=B,
+                          no_final_step_noise=True, **TEMP)
+    ref_pos = torch.stack([x["ligand"].pos for x in ref])
+    pos = m.sample_batch(place(HeteroBatch.from_data_list(dl)), steps, (s, s, s), noise=noise, no_final_step_noise=True,
+                         **TEMP).cpu().reshape(B, -1, 3)
+    r = rmsd(pos, ref_pos)
+    assert float(r.max()) < tol_pos, r
+    return r

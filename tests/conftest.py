@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` tests are skipped, not failed, on a box without a GPU (a plain `pytest` then stays green on the CPU).
+    On a GPU box nothing is skipped, and the HIP library must load: diffdock_amd.lib raises if libddmi.so is missing."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no GPU visible)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -122,6 +122,17 @@ def case_traj(n_poses=4, steps=20):
     wall = time.time() - t0
     final = torch.stack([d["ligand"].pos for d in out_list])
     print(f"reference sampling: {n_poses} poses x {steps} steps in {wall:.1f} s on {os.cpu_count()} cores", flush=True)
+    fx = dict(spec=spec, temp=TEMP, draws=draws, steps=[{k: v for k, v in r.items()} for r in rec], final_pos=final,
+              init_pos=torch.stack([d["ligand"].pos for d in dl]),
+              checks=dict(state_dict=checksum(sd), graph=checksum(graph_tensors(g))),
+              reference_wall_s=wall, reference_cores=os.cpu_count(), torch=torch.__version__)
+    torch.save(fx, os.path.join(HERE, "traj_300_30.pt"))     # reference part first; the float64 yardstick is added below
+    with open(os.path.join(ROOT, "profiles", "r02_cpu_reference_executed.json"), "w") as f:
+        json.dump({"what": "reference utils/sampling.sampling + models/cg_model.CGModel (FasterTensorProduct conv layers) executed "
+                           "under tests/golden/make_golden.py's third-party stand-ins, DDL-synth width, 300 residues / 30 atoms, "
+                           "all-pairs cross graph", "poses": n_poses, "steps": steps, "wall_s": wall,
+                   "poses_per_s": n_poses / wall, "cores": os.cpu_count(), "threads": torch.get_num_threads(),
+                   "torch": torch.__version__, "host": "build container (not the GPU box)"}, f, indent=1)
     # the same trajectory in float64 (oracle, same draws): how far rounding alone moves the final poses
     R = int(dl[0]["ligand"].edge_mask.sum())
     noise = split_draws(draws, steps, n_poses, R)
@@ -138,18 +149,8 @@ def case_traj(n_poses=4, steps=20):
     final64 = torch.stack([d["ligand"].pos for d in out64])
     rmsd64 = ((final64 - final.double()) ** 2).sum(-1).mean(-1).sqrt()
     print("final-pose RMSD float32 reference vs float64 oracle:", rmsd64.tolist(), flush=True)
-    fx = dict(spec=spec, temp=TEMP, draws=draws, steps=[{k: v for k, v in r.items()} for r in rec], final_pos=final,
-              final_pos_f64=final64, steps_f64=[dict(pos_in=r["pos_in"], tr=r["tr"], rot=r["rot"], tor=r["tor"]) for r in rec64],
-              init_pos=torch.stack([d["ligand"].pos for d in dl]),
-              checks=dict(state_dict=checksum(sd), graph=checksum(graph_tensors(g))),
-              reference_wall_s=wall, reference_cores=os.cpu_count(), torch=torch.__version__)
+    fx.update(final_pos_f64=final64, steps_f64=[dict(pos_in=r["pos_in"], tr=r["tr"], rot=r["rot"], tor=r["tor"]) for r in rec64])
     torch.save(fx, os.path.join(HERE, "traj_300_30.pt"))
-    with open(os.path.join(ROOT, "profiles", "r02_cpu_reference_executed.json"), "w") as f:
-        json.dump({"what": "reference utils/sampling.sampling + models/cg_model.CGModel (FasterTensorProduct conv layers) executed "
-                           "under tests/golden/make_golden.py's third-party stand-ins, DDL-synth width, 300 residues / 30 atoms, "
-                           "all-pairs cross graph", "poses": n_poses, "steps": steps, "wall_s": wall,
-                   "poses_per_s": n_poses / wall, "cores": os.cpu_count(), "threads": torch.get_num_threads(),
-                   "torch": torch.__version__, "host": "build container (not the GPU box)"}, f, indent=1)
 
 
 def case_big(n_poses=1):

@@ -32,6 +32,24 @@ def test_conv_work_counts_every_group_launch_once():
     assert abs(rr["bytes"] - (nR * 156 * 4 + e_rr * (144 + 156) * 4)) < 1.0
 
 
+def test_reference_association_flops_equal_the_survey_figure():
+    """2*(3ns*3ns + 3ns*W) + 6W flop per edge in the REFERENCE's association = 8.3 TFLOP per forward at
+    configs[2] (1.02 M edges per layer) -- reported next to the re-associated count, never used as the numerator of frac."""
+    b = load_bench()
+    w = b.conv_work(b.bench_cfg(), 1200, 12000, 40 * 30 * 14, 360000, 288000)
+    ref = sum(x["k_conv_fused"]["ref_flops"] for x in w)
+    mine = sum(x["k_conv_fused"]["flops"] for x in w)
+    assert abs(ref / 1e12 - 8.3) < 0.05 and 8.5 < ref / mine < 10.0
+
+
+def test_workloads_cover_the_baseline_configs():
+    b = load_bench()
+    assert b.WORKLOADS["configs2"]["complexes"] == [(300, 30, 0)] and b.WORKLOADS["configs2"]["samples"] == 40
+    assert b.WORKLOADS["configs1"]["samples"] == 10 and b.WORKLOADS["configs4"]["complexes"][0][:2] == (1500, 80)
+    mix = b.WORKLOADS["mix"]["complexes"]
+    assert sorted({c[0] for c in mix}) == [150, 300, 500] and sorted({c[1] for c in mix}) == [20, 30, 45] and len(mix) == 9
+
+
 def test_roofline_constants_match_the_microarchitecture_guide():
     b = load_bench()
     assert b.MFMA_F32_PEAK_TFLOPS == 157.3 and b.HBM_PEAK_GBS == 8000.0

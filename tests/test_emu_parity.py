@@ -13,7 +13,7 @@ from diffdock_amd.hetero import HeteroBatch, set_time
 from diffdock_amd.model import MIScoreModel
 from oracle.cg_model import CGModelOracle
 from oracle.conformer import get_t_schedule
-from util import fixture_case, graph_from_dict, load_fixture, oracle_model, rel_err, split_draws, tables
+from util import assert_scores_close, fixture_case, graph_from_dict, load_fixture, oracle_model, rel_err, split_draws, tables
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "hipemu", "libddmi_emu.so")
@@ -44,7 +44,7 @@ def test_forward_matches_reference_fixture(name, emu_lib):
     tr, rot, tor, none = m(batch)
     assert none is None
     ref = fx["forward"]
-    assert rel_err(tr, ref["tr"]) < 1e-4 and rel_err(rot, ref["rot"]) < 1e-4 and rel_err(tor, ref["tor"]) < 1e-4
+    assert_scores_close((tr, rot, tor), (ref["tr"], ref["rot"], ref["tor"]))
     if cfg.num_prot_emb_layers == 0:   # per-layer node tables (ligand + receptor rows)
         for l, ref_nodes in enumerate(ref["conv_out"]):
             mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))

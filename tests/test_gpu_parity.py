@@ -14,7 +14,7 @@ from diffdock_amd.synth import make_complex, make_pose_list
 from diffdock_amd.weights import init_state_dict
 from oracle.cg_model import CGModelOracle
 from oracle.conformer import get_t_schedule
-from util import fixture_case, graph_from_dict, load_fixture, oracle_model, rel_err, split_draws, tables
+from util import assert_scores_close, fixture_case, graph_from_dict, load_fixture, oracle_model, rel_err, split_draws, tables
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
@@ -43,7 +43,7 @@ def test_forward_matches_reference_fixture(name):
     tr, rot, tor, none = m(to_gpu(batch))
     ref = fx["forward"]
     assert none is None and tr.is_cuda
-    assert rel_err(tr.cpu(), ref["tr"]) < REL and rel_err(rot.cpu(), ref["rot"]) < REL and rel_err(tor.cpu(), ref["tor"]) < REL
+    assert_scores_close((tr, rot, tor), (ref["tr"], ref["rot"], ref["tor"]))
     if cfg.num_prot_emb_layers == 0:
         for l, ref_nodes in enumerate(ref["conv_out"]):
             mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))
@@ -96,7 +96,7 @@ def test_ddl_synth_forward_matches_oracle(lmax, t):
     tr, rot, tor, _ = CGModelOracle(cfg, sd, so3_t, tor_t)(batch)
     m = gpu_model(cfg, sd)
     tr2, rot2, tor2, _ = m(to_gpu(batch))
-    assert rel_err(tr2.cpu(), tr) < REL and rel_err(rot2.cpu(), rot) < REL and rel_err(tor2.cpu(), tor) < REL
+    assert_scores_close((tr2, rot2, tor2), (tr, rot, tor))
 
 
 @pytest.fixture(scope="module")
@@ -209,7 +209,7 @@ def test_all_atom_ddl_width_matches_oracle():
     m = gpu_model(cfg, sd)
     tr2, rot2, tor2, _ = m(to_gpu(batch))
     assert inter["edge_counts"][2] > 100 and int(m.debug_buffer("offs_la_l")[-1]) == inter["edge_counts"][2]
-    assert rel_err(tr2.cpu(), tr) < REL and rel_err(rot2.cpu(), rot) < REL and rel_err(tor2.cpu(), tor) < REL
+    assert_scores_close((tr2, rot2, tor2), (tr, rot, tor))
     for l in range(cfg.num_conv_layers - 1):   # all node rows: ligand, residues, atoms
         mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))
         ref = inter[f"node_attr{l + 1}"]
@@ -332,7 +332,7 @@ def test_ddl_synth_cropped_forward_matches_oracle():
     tr2, rot2, tor2, _ = m(to_gpu(batch))
     m.set_crop_cutoff(None)
     assert int(m.debug_buffer("crop_keep").sum()) == sum(c["receptor"].pos.shape[0] for c in cropped)
-    assert rel_err(tr2.cpu(), tr) < REL and rel_err(rot2.cpu(), rot) < REL and rel_err(tor2.cpu(), tor) < REL
+    assert_scores_close((tr2, rot2, tor2), (tr, rot, tor))
 
 
 def test_large_pocket_stress_config():
