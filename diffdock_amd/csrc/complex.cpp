@@ -227,6 +227,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         const long est_tiles = std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16);
         ys_req = (int)std::min(8L, std::max(1L, 768 / est_tiles));
       }
+      ys_req = std::max(ys_req, (L.n_fgran + 47) / 48);   // a workgroup keeps at most 64 granule descriptors in LDS
       const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
       f.ysplit = ys;
       f.gsplit[0] = 0;

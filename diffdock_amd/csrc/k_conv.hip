@@ -504,39 +504,48 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
   for (int v = blockIdx.x * 4 + wave; v < nvn; v += gridDim.x * 4) {
     const int d = a.vn_node[v], e0 = a.vn_e0[v];
     const int ne = min(32, a.goff[d + 1] - e0);
-    const float* __restrict__ qrow = a.Q + (size_t)d * H + 4 * lq;
-    const float* __restrict__ rbrow = nullptr;
-    if (a.rowbias && ne > 0) rbrow = a.rowbias + (size_t)a.ridx[a.arow ? a.arow[e0] : e0] * H + 4 * lq;
+    // All requests of a (virtual node, row tile) are issued before the first use and nothing in the tile body branches:
+    // a load -> wait -> MFMA -> store chain per 16 hidden units made this kernel latency-bound (0.24 of the HBM write
+    // roofline in round 1).  Rows past the node's edge count read the tile's first edge (valid memory) and store zeros.
+    float4 qv[NB];
+    {
+      const float* __restrict__ qrow = a.Q + (size_t)d * H + 4 * lq;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) qv[nb] = *reinterpret_cast<const float4*>(qrow + 16 * nb);
+      if (a.rowbias && ne > 0) {   // wave-uniform
+        const float* __restrict__ rbrow = a.rowbias + (size_t)a.ridx[a.arow ? a.arow[e0] : e0] * H + 4 * lq;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float4 t = *reinterpret_cast<const float4*>(rbrow + 16 * nb);
+          qv[nb].x += t.x; qv[nb].y += t.y; qv[nb].z += t.z; qv[nb].w += t.w;
+        }
+      }
+    }
 #pragma unroll 1
     for (int rt = 0; rt < 2; ++rt) {
       float* __restrict__ hp = a.Hb + fc_hb_off(v, rt, 0, lane, NG8 / 2);   // + 256 per pair of 8-k groups
-      const int el = 16 * rt + lr;
-      const bool live = el < ne;
-      if (16 * rt >= ne) {   // empty row tile: zero fragments where the consumer multiplies them
+      if (16 * rt >= ne) {   // empty row tile (wave-uniform): zero fragments where the consumer multiplies them
         if (!a.zero_fill) continue;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<float4*>(hp + (size_t)nb * 256) = make_float4(0.f, 0.f, 0.f, 0.f);
         continue;
       }
-      float4 ae[NSQ];
-      const float* __restrict__ prow = a.P + 4 * lq;
-      if (live) {
-        const int e = e0 + el;
-        const int ar = a.arow ? a.arow[e] : e;
-        const float* __restrict__ ep = a.ea + (size_t)ar * a.ns + KS * lq;
-        prow += (size_t)(a.tgt[e] - a.tbase) * H;
+      const int el = 16 * rt + lr;
+      const bool live = el < ne;
+      const int e = e0 + (live ? el : 16 * rt);
+      const int ar = a.arow ? a.arow[e] : e;
+      const float* __restrict__ ep = a.ea + (size_t)ar * a.ns + KS * lq;
+      const float* __restrict__ prow = a.P + (size_t)(a.tgt[e] - a.tbase) * H + 4 * lq;
+      float4 ae[NSQ], pv[NB];
 #pragma unroll
-        for (int j = 0; j < NSQ; ++j) ae[j] = *reinterpret_cast<const float4*>(ep + 4 * j);
-      } else {
+      for (int j = 0; j < NSQ; ++j) ae[j] = *reinterpret_cast<const float4*>(ep + 4 * j);
 #pragma unroll
-        for (int j = 0; j < NSQ; ++j) ae[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int nb = 0; nb < NB; ++nb) pv[nb] = *reinterpret_cast<const float4*>(prow + 16 * nb);
+      DDMI_SCHED_FENCE();   // every request of the tile is in flight before the first MFMA (the scheduler would sink them to their uses)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        float4 pq = *reinterpret_cast<const float4*>(qrow + 16 * nb);
-        if (rbrow) { const float4 t = *reinterpret_cast<const float4*>(rbrow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
-        if (live) { const float4 t = *reinterpret_cast<const float4*>(prow + 16 * nb); pq.x += t.x; pq.y += t.y; pq.z += t.z; pq.w += t.w; }
-        f32x4 acc = f32x4{pq.x, pq.y, pq.z, pq.w}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: a dependent f32 MFMA waits 40 cycles
+        f32x4 acc = f32x4{qv[nb].x + pv[nb].x, qv[nb].y + pv[nb].y, qv[nb].z + pv[nb].z, qv[nb].w + pv[nb].w};
+        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: a dependent f32 MFMA waits 40 cycles
         const float* __restrict__ wp = wl + lq * H + 16 * nb + lr;
 #pragma unroll
         for (int j = 0; j < NSQ; ++j) {
@@ -545,11 +554,9 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 2) * 4 * H], ae[j].z, acc, 0, 0, 0);
           acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 3) * 4 * H], ae[j].w, acc2, 0, 0, 0);
         }
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) {
-          o.x = fmaxf(acc[0] + acc2[0], 0.f); o.y = fmaxf(acc[1] + acc2[1], 0.f);
-          o.z = fmaxf(acc[2] + acc2[2], 0.f); o.w = fmaxf(acc[3] + acc2[3], 0.f);
-        }
+        float4 o;
+        o.x = live ? fmaxf(acc[0] + acc2[0], 0.f) : 0.f; o.y = live ? fmaxf(acc[1] + acc2[1], 0.f) : 0.f;
+        o.z = live ? fmaxf(acc[2] + acc2[2], 0.f) : 0.f; o.w = live ? fmaxf(acc[3] + acc2[3], 0.f) : 0.f;
         *reinterpret_cast<float4*>(hp + (size_t)nb * 256) = o;
       }
     }
@@ -561,7 +568,8 @@ void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {
   if (a.ns % 16 != 0 || a.ns > 64 || a.H != 3 * a.ns || a.NG8 * 8 != a.H)
     throw Error(DDMI_ERR_ARG, "k_edge_hidden_mm: unsupported width");
   const size_t smem = (size_t)(a.ns * a.H) * sizeof(float);
-  const int grid = std::min(cdiv(a.vcap, 4), 2048);
+  static const int eh_grid = getenv("DDMI_EH_GRID") ? atoi(getenv("DDMI_EH_GRID")) : 2048;   // tuning knob
+  const int grid = std::min(cdiv(a.vcap, 4), eh_grid);
   switch (a.ns / 16) {
     case 1: hipLaunchKernelGGL(k_edge_hidden_mm<1>, dim3(grid), dim3(256), smem, s, a); break;
     case 2: hipLaunchKernelGGL(k_edge_hidden_mm<2>, dim3(grid), dim3(256), smem, s, a); break;
@@ -572,6 +580,8 @@ void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {
 }
 
 constexpr int FC_VN = 16, FC_KC = 8, FC_WAVES = 8, FC_CAP0 = 12, FC_CAPN = 4;
+constexpr int FC_GWORDS = sizeof(FGran) / 4;   // granule descriptor, in 32-bit words
+constexpr int FC_MAXG = 64;                    // granule descriptors kept in LDS per workgroup (launches split larger ranges)
 // chunk buffer in LDS: [16 nodes][8 rows][64 columns], column = 16*slot + w; padded strides keep the transposing stores
 // (lanes = 16 w x 4 node quarters) and the B-fragment loads (lanes = 16 w x rows 2q + sub) on 64 distinct banks
 constexpr int FC_YROW = 72, FC_YVN = FC_KC * FC_YROW + 4, FC_YB = FC_VN * FC_YVN;
@@ -655,22 +665,27 @@ __device__ __forceinline__ void fc_store(float* yw, int slot, const f32x4& v) {
 template <int V>
 __device__ __forceinline__ void fc_store_rows(const float* __restrict__ stg, int RS, int L, int nrows, const float* __restrict__ erow,
                                               int ES, int ts_col, float* __restrict__ msg, int c0, int accumulate, int lane) {
+  // lane = 4 * row + q: a lane serves ONE row (message row index read once, no index division) and the V-float pieces
+  // q, q + 4, q + 8, ... of it; per request the 4 lanes of a row cover 4 * V consecutive floats.
   const int per_row = L / V;
-  for (int idx = lane; idx < nrows * per_row; idx += 64) {
-    const int row = idx / per_row, cv = idx - row * per_row;
-    const int ts = reinterpret_cast<const int*>(erow)[row * ES + ts_col];
-    float* __restrict__ p = msg + (size_t)ts * XS + c0 + V * cv;
-    const float* __restrict__ q = stg + row * RS + V * cv;
+  const int row = lane >> 2, q = lane & 3;
+  if (row >= nrows) return;
+  const int ts = reinterpret_cast<const int*>(erow)[row * ES + ts_col];
+  float* __restrict__ prow = msg + (size_t)ts * XS + c0;
+  const float* __restrict__ qrow = stg + row * RS;
+  for (int cv = q; cv < per_row; cv += 4) {
+    float* __restrict__ p = prow + V * cv;
+    const float* __restrict__ qq = qrow + V * cv;
     if (V == 4) {
-      float4 v = *reinterpret_cast<const float4*>(q);
+      float4 v = *reinterpret_cast<const float4*>(qq);
       if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
       *reinterpret_cast<float4*>(p) = v;
     } else if (V == 2) {
-      float2 v = *reinterpret_cast<const float2*>(q);
+      float2 v = *reinterpret_cast<const float2*>(qq);
       if (accumulate) { const float2 o = *reinterpret_cast<const float2*>(p); v.x += o.x; v.y += o.y; }
       *reinterpret_cast<float2*>(p) = v;
     } else {
-      float v = q[0];
+      float v = qq[0];
       if (accumulate) v += p[0];
       p[0] = v;
     }
@@ -988,7 +1003,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   float* ybuf = xbuf + FC_VN * NC_XS;                  // [2][16 x FC_YVN]
   float* gscr = ybuf + 2 * FC_YB;                      // per wave: [32 edge rows][MAXD][4 slots] (+8 pad) coupling rows of the current (granule, virtual node)
   float* escr = gscr + FC_WAVES * 32 * GS2;            // per wave: [2][32][ES] edge rows: sh (SHD), weight, message row
-  float* cgt = escr + FC_WAVES * 2 * 32 * ES;          // [granules of this workgroup][4 slots][MAXD][SHD] dense coupling rows
+  int* gdesc = reinterpret_cast<int*>(escr + FC_WAVES * 2 * 32 * ES);   // [granules of this workgroup] FGran copies (see below)
+  float* cgt = reinterpret_cast<float*>(gdesc + FC_MAXG * FC_GWORDS);   // [granules of this workgroup][4 slots][MAXD][SHD] dense coupling rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = DDMI_UNIFORM(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -1016,11 +1032,17 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     }
   }
   const int g_begin = a.gsplit[blockIdx.y], g_end = a.gsplit[blockIdx.y + 1];
+  // The granule descriptors are copied to LDS before the first message store: on gfx9-family parts loads and stores share
+  // the in-order vmcnt counter, so a descriptor field fetched from global memory AFTER a burst of message stores would wait
+  // for every one of them to be acknowledged (the compiler cannot keep the fields in registers across stores that may alias).
+  for (int idx = tid; idx < (g_end - g_begin) * FC_GWORDS; idx += 64 * FC_WAVES)
+    gdesc[idx] = reinterpret_cast<const int*>(a.gran + g_begin)[idx];
+  const FGran* __restrict__ gran_l = reinterpret_cast<const FGran*>(gdesc) - g_begin;   // gran_l[gi], gi in [g_begin, g_end)
   // dense coupling rows of this workgroup's granules: cgt[g][s][k'][j] = C_path(s)[comp(s)][j - s_off][k'] (0 outside the path's sh block)
   for (int idx = tid; idx < (g_end - g_begin) * CGN; idx += 64 * FC_WAVES) {
     const int gl = idx / CGN, rem = idx - gl * CGN;
     const int sl = rem / (MAXD * SHD), k = (rem / SHD) % MAXD, j = rem % SHD;
-    const FGran& Gq = a.gran[g_begin + gl];
+    const FGran& Gq = a.gran[g_begin + gl];   // (prologue: no store has been issued yet)
     float v = 0.f;
     if (Gq.g[sl] >= 0 && k < Gq.dout) {
       const GEntry E = a.gmap[Gq.g[sl] + k];
@@ -1069,7 +1091,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
   constexpr int NGR = MODE == 2 ? 2 : 1;   // granules per pass
   for (int gi = g_begin; gi < g_end; gi += NGR) {
-    const FGran& Gd = a.gran[gi];
+    const FGran& Gd = gran_l[gi];
     f32x4 acc_all[2][2][2][4];
 #pragma unroll
     for (int u = 0; u < NGR; ++u)
@@ -1217,7 +1239,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 #pragma unroll
     for (int u = 0; u < NGR; ++u) {
     if (gi + u >= g_end) break;
-    const FGran& Gd = a.gran[gi + u];
+    const FGran& Gd = gran_l[gi + u];
     f32x4 (&acc)[2][2][4] = acc_all[u];
     const float* __restrict__ cg = cgt + (gi + u - g_begin) * CGN;
 #pragma unroll
@@ -1290,7 +1312,8 @@ static void launch_conv_fused_t(const FusedConvArgs& a, hipStream_t s) {
   constexpr int GS2 = 4 * MAXD + 8, ES = SHD + 3, CGN = 4 * MAXD * SHD;
   int max_local = 0;
   for (int y = 0; y < a.ysplit; ++y) max_local = std::max(max_local, a.gsplit[y + 1] - a.gsplit[y]);
-  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FC_YB + FC_WAVES * 32 * GS2 + FC_WAVES * 2 * 32 * ES + max_local * CGN) * sizeof(float);
+  if (max_local > FC_MAXG) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: more granules per workgroup than descriptor slots (raise DDMI_FUSED_YS)");
+  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FC_YB + FC_WAVES * 32 * GS2 + FC_WAVES * 2 * 32 * ES + FC_MAXG * FC_GWORDS + max_local * CGN) * sizeof(float);
   if (smem > 160 * 1024) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: LDS budget exceeded (raise DDMI_FUSED_YS)");
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per instantiation)
   if (!lds_opt_in) {

@@ -5,7 +5,7 @@
 Tolerances.  Scores: north_star's 1e-4 relative fp32, asserted element-wise (|a - b| <= 1e-4 |ref| + 1e-5 max|ref|) and in
 max-norm.  Free-running trajectories: 20 steps of a chaotic map in fp32 amplify rounding, so the yardstick is the
 trajectory's own sensitivity -- the distance between the reference's float32 run and the same run in float64 (stored in
-the fixture): the device path must stay within 3x that distance (and within 0.05 A) of the float32 reference."""
+the fixture): the device path must stay within 3x that distance (floor 5e-4 A) of the float32 reference."""
 import numpy as np
 import pytest
 import torch
@@ -76,7 +76,7 @@ def test_twenty_step_free_running_rmsd_to_reference_execution(traj):
     print("rounding yardstick (reference f32 vs f64) [A]:   ", [f"{x:.2e}" for x in yard.tolist()],
           " pose displacement over the run [A]:", [f"{x:.1f}" for x in moved.tolist()])
     assert torch.isfinite(pos).all()
-    assert float(r.max()) <= max(3.0 * float(yard.max()), 1e-3) and float(r.max()) < 0.05
+    assert float(r.max()) <= max(3.0 * float(yard.max()), 5e-4)
     # the step-wise route (model(batch) + ddmi_perturb + ddmi_modify_conformer per step, the reference's loop structure)
     dl2 = [d.clone() for d in dl]
     out, _ = sampling(dl2, m, steps, sched, sched, sched, device=DEV, model_args=cfg, batch_size=B, no_final_step_noise=True,
