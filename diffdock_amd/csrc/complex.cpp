@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <string>
 #include <cstdlib>
 
 #include "model.h"
@@ -244,7 +245,9 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         }
         f.Yg = Y; f.HKp = L.HKp; f.n_gran = L.n_fgran;
       }
-      PhaseTimer t(m, load_mode ? "k_conv_fused_load" : "k_conv_fused", gs);
+      static const bool per_group = getenv("DDMI_TIME_GROUPS") != nullptr;   // profiling: one timing row per edge group
+      const std::string tname = std::string(load_mode ? "k_conv_fused_load" : "k_conv_fused") + (per_group ? ":g" + std::to_string(gi) : "");
+      PhaseTimer t(m, tname.c_str(), gs);
       launch_conv_fused(f, gs);
       continue;
     }
@@ -1167,7 +1170,8 @@ void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) 
     m.crop_cutoff = sc.use_crop ? s_tr * 3.0 + sc.crop_beyond : 0.0;   // sampling.py:107
     forward(m, lig_pos, c.s_t, c.s_t + B, c.s_t + 2 * B, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
     perturb_step(m, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, sc, k, ids_dev, s);
-    modify_conformer(m, lig_pos, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
+    static const bool freeze = getenv("DDMI_FREEZE_POSE") != nullptr;   // timing-only ablation builds produce garbage scores: keep the graphs fixed
+    if (!freeze) modify_conformer(m, lig_pos, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
   }
 }
 

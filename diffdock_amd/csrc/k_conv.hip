@@ -47,6 +47,9 @@ __device__ __forceinline__ float4 nt_load4(const float* p) {
   return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// fragment j of a lane's chain inside the packed weights (layout: see nc_lane_off)
+__device__ __forceinline__ int nc_fo(int j, int pstride) { return (j >> 2) * pstride + (j & 3); }
+
 // One slot (= one column of every item of the unit) for TWO 16-node sub-tiles sharing the weight fragments:
 //   acc[t] += sum_u x[node_t][u, comp] * W2[k][path][u][w]        (16 nodes x 16 w each, v_mfma_f32_16x16x4_f32)
 // NSTEPS = MFMA steps per chain, fully unrolled: all B (L2) and A (LDS) fragments are requested first, then the chains.
@@ -54,11 +57,11 @@ __device__ __forceinline__ float4 nt_load4(const float* p) {
 // neighbouring block of the finite x row).
 template <int NSTEPS>
 __device__ __forceinline__ void nc_chain(const float* __restrict__ bp, const float* __restrict__ xp,
-                                         int xstride, f32x4& acc0, f32x4& acc1, int dbg) {
+                                         int xstride, f32x4& acc0, f32x4& acc1, int dbg, int ps) {
   float bv[NSTEPS], a0[NSTEPS], a1[NSTEPS];
 #pragma unroll
   for (int j = 0; j < NSTEPS; ++j) {
-    bv[j] = (dbg & 256) ? 0.f : bp[j];   // a lane's fragments of one chain are contiguous: vector loads
+    bv[j] = (dbg & 256) ? 0.f : bp[nc_fo(j, ps)];   // 4 consecutive fragments of a lane are contiguous: vector loads
     a0[j] = xp[j * xstride];
     a1[j] = xp[16 * NC_XS + j * xstride];
   }
@@ -71,19 +74,24 @@ __device__ __forceinline__ void nc_chain(const float* __restrict__ bp, const flo
   }
 }
 
-// Packed second-layer weights of one (k, path): [16-w tile][lane = 16*lq + lr][step j] with u = 4j + lq, w = 16*tile + lr,
-// i.e. the B fragments of one chain lie side by side per lane (a wave's request covers whole cache lines).
+// Packed second-layer weights of one (k, path), per 16-w tile (u = 4j + lq, w = 16*tile + lr, lane = 16*lq + lr):
+//   chains of whole 4-step pieces (mul_in % 16 == 0):  [piece j/4][lane 64][j % 4]  -- a wave's 16-B request per piece is one
+//       contiguous KB (a per-lane run of 12 steps would put the lanes 48 B apart: 64 partial cache lines per request);
+//   other chains:                                        [lane 64][step j]          -- steps = 3: contiguous 12-B runs.
+// Fragment j of a lane sits at loff + (j >> 2) * pstride + (j & 3) with pstride = 256 / 4 respectively.
+__host__ __device__ __forceinline__ int nc_pstride(int steps) { return (steps & 3) == 0 ? 256 : 4; }
 __device__ __forceinline__ int nc_lane_off(const NcSlot& S, int w0, int lr, int lq) {
   const int steps = S.u_pad >> 2;
-  return ((w0 >> 4) * 64 + lq * 16 + lr) * steps;
+  return (w0 >> 4) * 64 * steps + (lq * 16 + lr) * ((steps & 3) == 0 ? 4 : steps);
 }
-struct NcSlotRt { const float* bp; const float* xp; int xstride, steps; };   // per-lane, k-invariant part
+struct NcSlotRt { const float* bp; const float* xp; int xstride, steps, ps; };   // per-lane, k-invariant part
 
 __device__ __forceinline__ NcSlotRt nc_slot_setup(const NcSlot S, const float* __restrict__ wpack, const float* __restrict__ xbuf,
                                                   int w0, int lr, int lq) {
   NcSlotRt R;
   R.steps = S.din == 0 ? 0 : (S.u_pad >> 2);
   R.bp = wpack + S.wk_off + nc_lane_off(S, w0, lr, lq);
+  R.ps = nc_pstride(S.u_pad >> 2);
   R.xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
   R.xstride = 4 * S.din;
   return R;
@@ -95,12 +103,13 @@ __device__ __forceinline__ void nc_slot(const NcSlotRt& R, size_t koff, f32x4& a
   const float* __restrict__ bp = R.bp + koff;
   const float* __restrict__ xp = R.xp;
   int steps = R.steps;
-  while (steps >= 12) { nc_chain<12>(bp, xp, R.xstride, acc0, acc1, dbg); bp += 12; xp += 12 * R.xstride; steps -= 12; }
-  if (steps >= 8) { nc_chain<8>(bp, xp, R.xstride, acc0, acc1, dbg); bp += 8; xp += 8 * R.xstride; steps -= 8; }
-  if (steps >= 4) { nc_chain<4>(bp, xp, R.xstride, acc0, acc1, dbg); bp += 4; xp += 4 * R.xstride; steps -= 4; }
-  if (steps == 3) nc_chain<3>(bp, xp, R.xstride, acc0, acc1, dbg);
-  else if (steps == 2) nc_chain<2>(bp, xp, R.xstride, acc0, acc1, dbg);
-  else if (steps == 1) nc_chain<1>(bp, xp, R.xstride, acc0, acc1, dbg);
+  const int ps = R.ps;   // whole 4-step pieces advance by ps floats (4 with the per-lane layout)
+  while (steps >= 12) { nc_chain<12>(bp, xp, R.xstride, acc0, acc1, dbg, ps); bp += 3 * ps; xp += 12 * R.xstride; steps -= 12; }
+  if (steps >= 8) { nc_chain<8>(bp, xp, R.xstride, acc0, acc1, dbg, ps); bp += 2 * ps; xp += 8 * R.xstride; steps -= 8; }
+  if (steps >= 4) { nc_chain<4>(bp, xp, R.xstride, acc0, acc1, dbg, ps); bp += ps; xp += 4 * R.xstride; steps -= 4; }
+  if (steps == 3) nc_chain<3>(bp, xp, R.xstride, acc0, acc1, dbg, ps);
+  else if (steps == 2) nc_chain<2>(bp, xp, R.xstride, acc0, acc1, dbg, ps);
+  else if (steps == 1) nc_chain<1>(bp, xp, R.xstride, acc0, acc1, dbg, ps);
 }
 
 // Workgroup = 32 gather nodes (two 16-row MFMA sub-tiles) x KC consecutive k.  The x rows sit in LDS (read-only after
@@ -587,13 +596,14 @@ constexpr int FC_MAXG = 64;                    // granule descriptors kept in LD
 constexpr int FC_YROW = 72, FC_YVN = FC_KC * FC_YROW + 4, FC_YB = FC_VN * FC_YVN;
 
 // k-invariant per-lane part of one slot chain: uniform weight base + 32-bit lane offset (scalar-base global loads)
-struct FcSlotRt { const float* wb; const float* xp; int loff, xstride, steps; };
+struct FcSlotRt { const float* wb; const float* xp; int loff, xstride, steps, ps; };
 __device__ __forceinline__ FcSlotRt fc_slot_setup(const NcSlot S, const float* __restrict__ wpack, const float* __restrict__ xbuf,
                                                   int w0, int lr, int lq) {
   FcSlotRt R;
   R.steps = S.din == 0 ? 0 : (S.u_pad >> 2);
   R.wb = wpack + S.wk_off;
   R.loff = nc_lane_off(S, w0, lr, lq);
+  R.ps = nc_pstride(S.u_pad >> 2);
   R.xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
   R.xstride = 4 * S.din;
   return R;
@@ -608,7 +618,7 @@ template <int N>
 __device__ __forceinline__ void fc_fetch_n(const FcSlotRt& R, size_t koff, float* bv) {
   const float* __restrict__ wb = R.wb + koff;
 #pragma unroll
-  for (int j = 0; j < N; ++j) bv[j] = (wb + j)[R.loff];
+  for (int j = 0; j < N; ++j) bv[j] = (wb + nc_fo(j, R.ps))[R.loff];
 }
 template <int N>
 __device__ __forceinline__ f32x4 fc_apply_n(const FcSlotRt& R, const float* bv) {
@@ -623,7 +633,7 @@ __device__ __forceinline__ void fc_fetch(const FcSlotRt& R, size_t koff, float* 
   const float* __restrict__ wb = R.wb + koff;
 #pragma unroll
   for (int j = 0; j < CAP; ++j)
-    if (j < R.steps) bv[j] = (wb + j)[R.loff];
+    if (j < R.steps) bv[j] = (wb + nc_fo(j, R.ps))[R.loff];
 }
 template <int CAP>
 __device__ __forceinline__ f32x4 fc_apply(const FcSlotRt& R, size_t koff, const float* bv) {
@@ -633,14 +643,14 @@ __device__ __forceinline__ f32x4 fc_apply(const FcSlotRt& R, size_t koff, const 
   for (int j = 0; j < CAP; ++j)
     if (j < R.steps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], bv[j], acc, 0, 0, 0);
   for (int j = CAP; j < R.steps; ++j)   // chains longer than the prefetch capacity (ns > 48)
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], (R.wb + koff + j)[R.loff], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[j * R.xstride], (R.wb + koff + nc_fo(j, R.ps))[R.loff], acc, 0, 0, 0);
   return acc;
 }
 template <int N>
 __device__ __forceinline__ void fc_direct_n(const FcSlotRt& R, size_t koff, int j0, f32x4& acc) {
   float bv[N], av[N];   // all fragments requested before the first MFMA: one L2 round trip per chain piece
 #pragma unroll
-  for (int j = 0; j < N; ++j) { bv[j] = (R.wb + koff + (j0 + j))[R.loff]; av[j] = R.xp[(j0 + j) * R.xstride]; }
+  for (int j = 0; j < N; ++j) { bv[j] = (R.wb + koff + nc_fo(j0 + j, R.ps))[R.loff]; av[j] = R.xp[(j0 + j) * R.xstride]; }
 #pragma unroll
   for (int j = 0; j < N; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
 }
@@ -743,7 +753,8 @@ struct FcOrder {   // issue order of the four slot chains: slot 0 alternating wi
   static constexpr int slot(int i) { return find(i, true); }
   static constexpr int step(int i) { return find(i, false); }
 };
-template <int S0, int SN, bool DENSE>
+// DUP: slots sharing one set of weight fragments (FGran::dup): they are requested once and feed several chains.
+template <int S0, int SN, bool DENSE, int DUP = 0>
 __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
                                                   int KS, int HK, int NG8, int wave, int lane,
                                                   const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr,
@@ -768,14 +779,17 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
   const unsigned gstep = 32u * (unsigned)KS;
   const FcBuf wbuf = fc_buf(wpack, (unsigned)HK * (unsigned)KS * 4u);
   // vector requests: slot 0 in pieces of 4 steps (or one piece of 3), slots 1..3 one piece of 3 each
-  constexpr int NL0 = S0 >= 4 ? S0 / 4 : (S0 > 0 ? 1 : 0), NL = NL0 + (SN > 0 ? 3 : 0);
+  constexpr int NLN = SN == 0 ? 0 : DUP == 1 ? 1 : DUP == 2 ? 1 : DUP == 3 ? 0 : 3;   // requests for slots 1..3
+  constexpr int NL0 = S0 >= 4 ? S0 / 4 : (S0 > 0 ? 1 : 0), NL = NL0 + NLN;
+  // slot whose fragments slot t multiplies with
+  auto wsl = [](int t) constexpr { return DUP == 1 ? (t == 0 ? 0 : 1) : DUP == 2 ? (t == 3 ? 3 : 0) : DUP == 3 ? 0 : t; };
   static_assert(S0 % 4 == 0 || S0 == 3, "slot-0 chains are whole 4-step pieces or one 3-step piece");
   static_assert(SN == 0 || SN == 3, "slots 1..3 hold 3-step chains");
   auto loadw = [&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    constexpr int t = i < NL0 ? 0 : 1 + (i - NL0);
+    constexpr int t = i < NL0 ? 0 : (DUP == 2 ? 3 : 1 + (i - NL0));   // DUP 2: the one extra request is slot 3's
     if constexpr (t == 0 && S0 >= 4) {
-      const float4 v = fc_buf_ld4(wbuf, lo[0] + 16u * i, woff[0]);
+      const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0]);   // piece i of the chain: one contiguous KB per wave
       bw[0][4 * i] = v.x; bw[0][4 * i + 1] = v.y; bw[0][4 * i + 2] = v.z; bw[0][4 * i + 3] = v.w;
     } else {
       const float3 v = fc_buf_ld3(wbuf, lo[t], woff[t]);
@@ -818,8 +832,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
       fc_sfor<0, NC>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int t = O::slot(i);
-        r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[t][O::step(i)], r[t], 0, 0, 0);
-        if constexpr (DO_H) { if (i < 4) loadh(hN, i); }
+        r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[wsl(t)][O::step(i)], r[t], 0, 0, 0);
         if (i == NC - 3) readq(0, eb, 0);
         DDMI_SCHED_FENCE();
       });
@@ -835,6 +848,14 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
         acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
       }
       if constexpr (DO_W) { if constexpr (m % 2 == 0 && m / 2 < NL) loadw(std::integral_constant<int, m / 2>{}); }
+      // The hidden rows of the next pair of chunks (HBM / Infinity Cache, slow) are requested AFTER this step's weight
+      // requests (L2, needed at the next contraction): vmcnt retires in order on this family, so a slow request issued
+      // ahead of the weights would be waited for together with them, one contraction too early.
+      if constexpr (DO_H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (m == (2 * NL - 1 + 2 * j < NE - 1 ? 2 * NL - 1 + 2 * j : NE - 1)) loadh(hN, j);
+      }
       if constexpr (DO_C) { if (m >= 2 && m < 2 + NP) store_piece(cb, m - 2); }
       if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
       DDMI_SCHED_FENCE();
@@ -867,7 +888,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
   fc_sfor<0, NC>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     constexpr int t = O::slot(i);
-    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[t][O::step(i)], r[t], 0, 0, 0);
+    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[wsl(t)][O::step(i)], r[t], 0, 0, 0);
   });
 #pragma unroll
   for (int pc = 0; pc < NP; ++pc) store_piece(0, pc);
@@ -1137,7 +1158,10 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       if (MODE == 0 || MODE == 3) {   // static chain shapes: hand-scheduled loop, dense (3) or sparse (0) rows
         constexpr bool DN = MODE == 3;
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
-        if (Gd.shape == 1) fc_mainloop_dense<12, 3, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
+        if (Gd.shape == 1 && Gd.dup == 1) fc_mainloop_dense<12, 3, DN, 1>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
+        else if (Gd.shape == 1) fc_mainloop_dense<12, 3, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
+        else if (Gd.shape == 2 && Gd.dup == 3) fc_mainloop_dense<3, 3, DN, 3>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
+        else if (Gd.shape == 2 && Gd.dup == 2) fc_mainloop_dense<3, 3, DN, 2>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
         else if (Gd.shape == 2) fc_mainloop_dense<3, 3, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
         else fc_mainloop_dense<12, 0, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
       } else {

@@ -357,8 +357,10 @@ static void commit_conv(Model& m, ConvW& L) {
         for (int u = 0; u < p.mul_in; ++u)
           for (int w = 0; w < p.mul_out; ++w) {
             const size_t slot = (size_t)p.w_off + (size_t)u * p.mul_out + w;
-            // [16-w tile][lane = 16*(u%4) + w%16][step u/4]: the fragments of one chain are contiguous per lane
-            const size_t at = ((size_t)(w / 16) * 64 + (size_t)(u % 4) * 16 + (size_t)(w % 16)) * steps + (size_t)(u / 4);
+            // per 16-w tile: chains of whole 4-step pieces [piece][lane = 16*(u%4) + w%16][4], others [lane][step] (k_conv.hip, nc_lane_off)
+            const size_t lane = (size_t)(u % 4) * 16 + (size_t)(w % 16), j = (size_t)(u / 4);
+            const size_t at = (size_t)(w / 16) * 64 * steps +
+                              (steps % 4 == 0 ? (j / 4) * 256 + lane * 4 + (j % 4) : lane * steps + j);
             pack[(size_t)k * KS + wk_off[pi] + at] = k < H ? w2.data[slot * H + k] : b2.data[slot];
           }
     }
@@ -417,6 +419,13 @@ static void commit_conv(Model& m, ConvW& L) {
             if (st(0) == 12 && st(1) == 0 && st(2) == 0 && st(3) == 0) G.shape = 3;
             else if (st(0) == 12 && fits(1, 3) && fits(2, 3) && fits(3, 3)) G.shape = 1;
             else if (st(0) == 3 && fits(1, 3) && fits(2, 3) && fits(3, 3)) G.shape = 2;
+          }
+          {   // weight sharing between the slots (components of one path): fewer weight requests per chunk in the fused kernel
+            auto same = [&](int a_, int b_) { return G.slot[b_].din == 0 || (G.slot[a_].din != 0 && G.slot[a_].wk_off == G.slot[b_].wk_off &&
+                                                                                G.slot[a_].u_pad == G.slot[b_].u_pad && G.slot[a_].w_pad == G.slot[b_].w_pad); };
+            G.dup = 0;
+            if (G.shape == 1 && G.slot[1].din != 0 && same(1, 2) && same(1, 3)) G.dup = 1;
+            if (G.shape == 2 && same(0, 1) && same(0, 2)) G.dup = same(0, 3) ? 3 : 2;
           }
           fg.push_back(G);
           L.fgran_unit.push_back((int)nc.size());

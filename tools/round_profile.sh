@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round-end evidence, run ON THE GPU BOX through gpurun:  tools/round_profile.sh <tag>
-# Writes gpurun_out/<tag>_{bench.json,rocprof_kernel_stats.txt,pmc_summary.txt,pytest_gpu.log,smoke.log}; copy them to profiles/.
+# Writes gpurun_out/<tag>_{pytest_gpu.log,smoke.log,bench*.json,rocprof_kernel_stats.txt,pmc_summary.txt,traffic.json}; copy them to profiles/.
 tag=${1:-rXX}
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q > $out/${tag}_pytest_gpu.log 2>&1
+( time python -m pytest tests -m gpu -q -s ) > $out/${tag}_pytest_gpu.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/${tag}_smoke.log 2>&1
-python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
+# counters first (the default bench line then picks up profiles/traffic_latest.json of THIS build)
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/kt.log 2>&1
 python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/prof_kt -name "*.db" | head -1) > $out/${tag}_rocprof_kernel_stats.txt 2>&1
 tail -1 /tmp/kt.log >> $out/${tag}_rocprof_kernel_stats.txt
@@ -16,6 +16,16 @@ tail -1 /tmp/kt.log >> $out/${tag}_rocprof_kernel_stats.txt
 i=0
 for p in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $p -d /tmp/pmc$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/pmc$i.log 2>&1
+  DDMI_STREAMS=1 rocprofv3 --kernel-trace --pmc $p -d /tmp/pmc$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/pmc$i.log 2>&1
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(find /tmp/pmc$i -name "*.db" | head -1) >> $out/${tag}_pmc_summary.txt 2>&1
 done
+python $GRAFT_REPO_ROOT/tools/traffic_json.py $(find /tmp/pmc3 -name "*.db" | head -1) $(find /tmp/pmc4 -name "*.db" | head -1) k_conv_fused configs2 \
+  "profiles/${tag}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernels serialised on one stream)" > $out/${tag}_traffic.json 2>> $out/${tag}_pmc_summary.txt
+cp $out/${tag}_traffic.json $GRAFT_REPO_ROOT/profiles/traffic_latest.json
+cd $GRAFT_REPO_ROOT
+python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+python bench.py --config configs1 > $out/${tag}_bench_configs1.json 2>> $out/${tag}_bench.err
+python bench.py --config mix --steps 2 > $out/${tag}_bench_mix.json 2>> $out/${tag}_bench.err
+python bench.py --config configs4 --steps 2 --warmup 1 > $out/${tag}_bench_configs4.json 2>> $out/${tag}_bench.err
+python bench.py --samples 5 --no-cpu-baseline > $out/${tag}_bench_b5.json 2>> $out/${tag}_bench.err
+python bench.py --all-atoms > $out/${tag}_bench_all_atoms.json 2>> $out/${tag}_bench.err
