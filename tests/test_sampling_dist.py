@@ -102,7 +102,7 @@ from util import fixture_case, tables
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
 fx, cfg, data_list = fixture_case("tiny_l2")
 cfg = cfg.replace(fixed_center_conv=True)   # batch-composition independent scores (see test above)
-data_list = [data_list[i % len(data_list)].clone() for i in range(3)]
+data_list = [data_list[i % len(data_list)].clone() for i in range(5)]
 m = MIScoreModel(cfg, device="cpu", lib_path={emu!r})
 m.load_state_dict(fx["state_dict"]); m.set_tables(*tables())
 sched = np.linspace(1, 0, 3)[:-1]
@@ -115,8 +115,8 @@ dist.destroy_process_group()
 
 
 def test_two_rank_gloo_run_reproduces_single_rank(emu_lib, tmp_path):
-    """3 poses on 2 ranks (blocks of 2 and 1, one all_gather) == the same 3 poses on one rank: per-sample noise
-    streams are keyed by the global sample index."""
+    """5 poses on 2 ranks (uneven blocks of 3 and 2, padded for the one all_gather) == the same 5 poses on one rank:
+    per-sample noise streams are keyed by the global sample index."""
     out = str(tmp_path / "pos.pt")
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, emu=emu_lib, out=out, port=29611))
@@ -127,7 +127,7 @@ def test_two_rank_gloo_run_reproduces_single_rank(emu_lib, tmp_path):
     multi = torch.load(out)
     fx, cfg, data_list = fixture_case("tiny_l2")
     cfg = cfg.replace(fixed_center_conv=True)
-    data_list = [data_list[i % len(data_list)].clone() for i in range(3)]
+    data_list = [data_list[i % len(data_list)].clone() for i in range(5)]
     m = MIScoreModel(cfg, device="cpu", lib_path=emu_lib)
     m.load_state_dict(fx["state_dict"])
     m.set_tables(*tables())

@@ -14,6 +14,6 @@ for name in sys.argv[1:]:
            join rocpd_info_kernel_symbol s on d.kernel_id = s.id
            group by s.kernel_name, d.grid_size_x, p.name order by 7 desc, 1, 2, 4"""
     for r in cur.execute(q):
-        if r[6] < 100:
+        if r[6] < 40:
             continue
         print(f"{r[0][:44]:44s} grid={r[1]:8d} wg={r[2]:4d} {r[3]:28s} n={r[4]:4d} per_dispatch={r[5]:.5g} avg_us={r[6]:.1f}")
