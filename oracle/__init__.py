@@ -23,7 +23,9 @@ so the pins are fixtures produced by EXECUTING the reference's own python
 (models/cg_model.py, models/tensor_layers.py, models/layers.py, utils/geometry.py,
 utils/torsion.py, utils/diffusion_utils.py, utils/sampling.py, utils/so3.py,
 utils/torus.py) with only the absent third-party modules substituted
-(tests/golden/make_golden.py, fixtures committed under tests/golden/).  The
+(tests/golden/make_golden.py and make_golden_fullsize.py -- the latter at the BASELINE.json
+shapes: 20 steps x 10 poses at 300 residues / 30 atoms, one forward at 1500 / 80 --
+fixtures committed under tests/golden/).  The
 third-party arithmetic itself (e3nn w3j / SH / BatchNorm, radius cap order) is a
 restatement of the published algorithm and stays "parity unpinned" at that
 boundary except for the in-repo pin FasterTensorProduct
