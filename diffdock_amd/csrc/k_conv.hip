@@ -739,14 +739,14 @@ template <int I, int N, class F>
 __device__ __forceinline__ void fc_sfor(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); fc_sfor<I + 1, N>(f); }
 }
-template <int S0, int SN>
-struct FcOrder {   // issue order of the four slot chains: slot 0 alternating with slots 1, 2, 3 (dependent MFMAs 40 cycles apart)
-  static constexpr int NC = S0 + 3 * SN, NJ = S0 > 3 * SN ? S0 : 3 * SN;
+template <int S0, int SN, int NLV = 3>
+struct FcOrder {   // issue order of the slot chains: slot 0 alternating with the NLV live slots 1.. (dependent MFMAs 40 cycles apart)
+  static constexpr int NC = S0 + NLV * SN, NJ = S0 > NLV * SN ? S0 : NLV * SN;
   static constexpr int find(int i, bool want_slot) {
     int c = 0;
     for (int j = 0; j < NJ; ++j) {
       if (j < S0) { if (c == i) return want_slot ? 0 : j; ++c; }
-      if (j < 3 * SN) { if (c == i) return want_slot ? 1 + j % 3 : j / 3; ++c; }
+      if (j < NLV * SN) { if (c == i) return want_slot ? 1 + j % NLV : j / NLV; ++c; }
     }
     return 0;
   }
@@ -754,14 +754,15 @@ struct FcOrder {   // issue order of the four slot chains: slot 0 alternating wi
   static constexpr int step(int i) { return find(i, false); }
 };
 // DUP: slots sharing one set of weight fragments (FGran::dup): they are requested once and feed several chains.
-template <int S0, int SN, bool DENSE, int DUP = 0>
+// NLV: live slots among 1..3 (FGran::nlive; padding slots trail): a padding slot is neither contracted nor multiplied.
+template <int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3>
 __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
                                                   int KS, int HK, int NG8, int wave, int lane,
                                                   const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr,
                                                   const float* yrd) {
   // sparse rows (!DENSE): the second 16-row tile of a virtual node with <= 16 edges is neither fetched nor multiplied
   const bool two[2] = {DENSE || vne[0] > 16, DENSE || vne[1] > 16};
-  using O = FcOrder<S0, SN>;
+  using O = FcOrder<S0, SN, NLV>;
   constexpr int NC = O::NC;
   float xa[NC];
   float bw[4][S0 > 3 ? S0 : 3];   // weight fragments [slot][step] (slot 0: S0 steps, slots 1..3: SN steps)
@@ -779,7 +780,8 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
   const unsigned gstep = 32u * (unsigned)KS;
   const FcBuf wbuf = fc_buf(wpack, (unsigned)HK * (unsigned)KS * 4u);
   // vector requests: slot 0 in pieces of 4 steps (or one piece of 3), slots 1..3 one piece of 3 each
-  constexpr int NLN = SN == 0 ? 0 : DUP == 1 ? 1 : DUP == 2 ? 1 : DUP == 3 ? 0 : 3;   // requests for slots 1..3
+  static_assert(DUP != 2 || NLV == 3, "DUP 2 keeps slot 3's own fragments");
+  constexpr int NLN = SN == 0 ? 0 : DUP == 1 ? 1 : DUP == 2 ? 1 : DUP == 3 ? 0 : NLV;   // requests for slots 1..3
   constexpr int NL0 = S0 >= 4 ? S0 / 4 : (S0 > 0 ? 1 : 0), NL = NL0 + NLN;
   // slot whose fragments slot t multiplies with
   auto wsl = [](int t) constexpr { return DUP == 1 ? (t == 0 ? 0 : 1) : DUP == 2 ? (t == 3 ? 3 : 0) : DUP == 3 ? 0 : t; };
@@ -808,7 +810,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
   };
   f32x4 r[4];
   // live 16-column blocks of the granule: a (12,-,-,-) granule (one item column) multiplies only block 0 in the edge product
-  constexpr int NCB = SN == 0 ? 1 : 4, NE = 8 * NCB, NP = SN == 0 ? 4 : 8;
+  constexpr int NCB = SN == 0 ? 1 : 1 + NLV, NE = 8 * NCB, NP = (SN == 0 || NLV == 1) ? 4 : 8;
   float q[2][NCB];             // B fragments of the edge product: [parity of the (virtual node, k pair) group][column block]
   auto readq = [&](int par, int buf, int grp) __attribute__((always_inline)) {
     const float* __restrict__ yb = yrd + buf * FC_YB + (grp >> 1) * FC_YVN + (grp & 1) * FC_YROW;
@@ -818,8 +820,8 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
   auto store_piece = [&](int buf, int piece) __attribute__((always_inline)) {   // rows of node quarter `rr`, slots 2h and 2h+1
     float* yw = ywr + buf * FC_YB;
     const int rr = piece & 3, h = piece >> 2;
-    yw[rr * FC_YVN + 16 * (2 * h)] = r[2 * h][rr];
-    if (SN > 0) yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
+    if (2 * h < NCB) yw[rr * FC_YVN + 16 * (2 * h)] = r[2 * h][rr];
+    if (2 * h + 1 < NCB) yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
   };
   // one chunk step (chunk g = 2 * pair + ODD): contraction of chunk g+1 into buffer ODD ^ 1 (DO_C), weight requests for
   // chunk g+2 (DO_W), hidden rows of the next pair of chunks (DO_H), edge product of chunk g out of buffer ODD
@@ -1158,11 +1160,17 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       if (MODE == 0 || MODE == 3) {   // static chain shapes: hand-scheduled loop, dense (3) or sparse (0) rows
         constexpr bool DN = MODE == 3;
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
-        if (Gd.shape == 1 && Gd.dup == 1) fc_mainloop_dense<12, 3, DN, 1>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
-        else if (Gd.shape == 1) fc_mainloop_dense<12, 3, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
-        else if (Gd.shape == 2 && Gd.dup == 3) fc_mainloop_dense<3, 3, DN, 3>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
-        else if (Gd.shape == 2 && Gd.dup == 2) fc_mainloop_dense<3, 3, DN, 2>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
-        else if (Gd.shape == 2) fc_mainloop_dense<3, 3, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
+#define FC_ML(S0_, SN_, DUP_, NLV_) fc_mainloop_dense<S0_, SN_, DN, DUP_, NLV_>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd)
+        const int dup = Gd.dup, nlv = Gd.nlive;
+        if (Gd.shape == 1 && dup == 1 && nlv == 3) FC_ML(12, 3, 1, 3);
+        else if (Gd.shape == 1 && dup == 1 && nlv == 2) FC_ML(12, 3, 1, 2);
+        else if (Gd.shape == 1) FC_ML(12, 3, 0, 3);          // (a padding slot is contracted like a live one: its result is never read)
+        else if (Gd.shape == 2 && dup == 3 && nlv == 2) FC_ML(3, 3, 3, 2);
+        else if (Gd.shape == 2 && dup == 3 && nlv == 1) FC_ML(3, 3, 3, 1);
+        else if (Gd.shape == 2 && dup == 3) FC_ML(3, 3, 3, 3);
+        else if (Gd.shape == 2 && dup == 2) FC_ML(3, 3, 2, 3);
+        else if (Gd.shape == 2) FC_ML(3, 3, 0, 3);
+#undef FC_ML
         else fc_mainloop_dense<12, 0, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
       } else {
       FcPre pre;

@@ -82,6 +82,7 @@ struct FGran {
   int accumulate;        // 0: first granule of its (output block, w tile) unit writes, later ones add
   int empty;             // no path reaches this granule: the message columns are zero
   int shape;             // chain-length class of the 4 slots: 1 = (12,3,3,3), 2 = (3,3,3,3), 3 = (12,-,-,-), 0 = generic
+  int nlive;             // live (non-padding) slots among 1..3; padding slots trail after the host's sort
   int dup;               // slots whose packed weights coincide (the components of one path share their weights; a padding slot may
                          // borrow any): 0 none, 1 = slots 1..3 use slot 1's fragments, 2 = slots 0..2 use slot 0's, 3 = all use slot 0's
 };

@@ -423,6 +423,8 @@ static void commit_conv(Model& m, ConvW& L) {
           {   // weight sharing between the slots (components of one path): fewer weight requests per chunk in the fused kernel
             auto same = [&](int a_, int b_) { return G.slot[b_].din == 0 || (G.slot[a_].din != 0 && G.slot[a_].wk_off == G.slot[b_].wk_off &&
                                                                                 G.slot[a_].u_pad == G.slot[b_].u_pad && G.slot[a_].w_pad == G.slot[b_].w_pad); };
+            G.nlive = 0;
+            for (int t = 1; t < 4; ++t) if (G.slot[t].din != 0) G.nlive = t;   // pads trail (sorted by chain length)
             G.dup = 0;
             if (G.shape == 1 && G.slot[1].din != 0 && same(1, 2) && same(1, 3)) G.dup = 1;
             if (G.shape == 2 && same(0, 1) && same(0, 2)) G.dup = same(0, 3) ? 3 : 2;
