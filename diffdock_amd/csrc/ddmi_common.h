@@ -31,6 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DDMI_WAVE_SYNC() hipemu_wave_sync()
 #define DDMI_UNIFORM(x) (x)
 #define DDMI_SCHED_FENCE() ((void)0)
+#define DDMI_WAIT_VMEM() ((void)0)
 #else
 // wave-uniform value -> scalar register
 #define DDMI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
@@ -42,6 +43,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
   } while (0)
 // nothing is scheduled across this point (hand-placed issue order of the MFMA main loops)
 #define DDMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// every outstanding vector-memory request of the wave has completed (vmcnt(0); expcnt / lgkmcnt untouched) -- a real
+// S_WAITCNT, which the compiler's own wait-count insertion takes into account
+#define DDMI_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
 #define DDMI_NT_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
 #define DDMI_NT_LOAD(ptr) __builtin_nontemporal_load((ptr))
 #endif

@@ -739,6 +739,16 @@ template <int I, int N, class F>
 __device__ __forceinline__ void fc_sfor(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); fc_sfor<I + 1, N>(f); }
 }
+// Effective (DUP, NLV) of the hand-scheduled loop variant a granule runs.  Combinations without an instance treat padding
+// slots like live ones.
+__device__ __forceinline__ void fc_variant(const FGran& G, int& vdup, int& vnlv) {
+  vdup = 0; vnlv = 3;
+  if (G.shape == 1) { if (G.dup == 1 && (G.nlive == 3 || G.nlive == 2)) { vdup = 1; vnlv = G.nlive; } }
+  else if (G.shape == 2) {
+    if (G.dup == 3) { vdup = 3; vnlv = (G.nlive == 2 || G.nlive == 1) ? G.nlive : 3; }
+    else if (G.dup == 2) vdup = 2;
+  }
+}
 template <int S0, int SN, int NLV = 3>
 struct FcOrder {   // issue order of the slot chains: slot 0 alternating with the NLV live slots 1.. (dependent MFMAs 40 cycles apart)
   static constexpr int NC = S0 + NLV * SN, NJ = S0 > NLV * SN ? S0 : NLV * SN;
@@ -881,9 +891,9 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
   // prologue: chunk 0 contracted, chunk 1 requested  (NG8 is even and >= 2 here: the host selects this loop for H % 16 == 0)
   fc_sfor<0, NL>(loadw);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) woff[t] += gstep;
-#pragma unroll
   for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) woff[t] += gstep;
   hoff += 1024u;
 #pragma unroll
   for (int t = 0; t < 4; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1027,7 +1037,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   float* gscr = ybuf + 2 * FC_YB;                      // per wave: [32 edge rows][MAXD][4 slots] (+8 pad) coupling rows of the current (granule, virtual node)
   float* escr = gscr + FC_WAVES * 32 * GS2;            // per wave: [2][32][ES] edge rows: sh (SHD), weight, message row
   int* gdesc = reinterpret_cast<int*>(escr + FC_WAVES * 2 * 32 * ES);   // [granules of this workgroup] FGran copies (see below)
-  float* cgt = reinterpret_cast<float*>(gdesc + FC_MAXG * FC_GWORDS);   // [granules of this workgroup][4 slots][MAXD][SHD] dense coupling rows
+  int* gorder = gdesc + FC_MAXG * FC_GWORDS;            // [granules of this workgroup] visiting order (rotated per workgroup, see below)
+  float* cgt = reinterpret_cast<float*>(gorder + FC_MAXG);   // [granules of this workgroup][4 slots][MAXD][SHD] dense coupling rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = DDMI_UNIFORM(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -1061,6 +1072,18 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   for (int idx = tid; idx < (g_end - g_begin) * FC_GWORDS; idx += 64 * FC_WAVES)
     gdesc[idx] = reinterpret_cast<const int*>(a.gran + g_begin)[idx];
   const FGran* __restrict__ gran_l = reinterpret_cast<const FGran*>(gdesc) - g_begin;   // gran_l[gi], gi in [g_begin, g_end)
+  // Visiting order of the granules, rotated by whole units per workgroup: tiles start together and take equal time, so with
+  // one common order all 256 CUs would issue their message stores (98 KB per tile and granule) in the same microseconds and
+  // then wait for that burst to drain; rotated, the stores of the chip spread over the whole granule period.
+  if (tid == 0) {
+    const int n = g_end - g_begin;
+    int n_units = 0;
+    for (int i = 0; i < n; ++i) n_units += a.gran[g_begin + i].accumulate == 0;
+    int want = (a.dbg & 2048) || n_units == 0 ? 0 : (int)(blockIdx.x % (unsigned)n_units), start = 0;
+    for (int i = 0, u = 0; i < n; ++i)
+      if (a.gran[g_begin + i].accumulate == 0) { if (u == want) start = i; ++u; }
+    for (int i = 0; i < n; ++i) gorder[i] = g_begin + (start + i) % n;
+  }
   // dense coupling rows of this workgroup's granules: cgt[g][s][k'][j] = C_path(s)[comp(s)][j - s_off][k'] (0 outside the path's sh block)
   for (int idx = tid; idx < (g_end - g_begin) * CGN; idx += 64 * FC_WAVES) {
     const int gl = idx / CGN, rem = idx - gl * CGN;
@@ -1113,7 +1136,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
   constexpr int NGR = MODE == 2 ? 2 : 1;   // granules per pass
-  for (int gi = g_begin; gi < g_end; gi += NGR) {
+  for (int go = g_begin; go < g_end; go += NGR) {
+    const int gi = MODE == 2 ? go : gorder[go - g_begin];
     const FGran& Gd = gran_l[gi];
     f32x4 acc_all[2][2][2][4];
 #pragma unroll
@@ -1161,17 +1185,18 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         constexpr bool DN = MODE == 3;
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
 #define FC_ML(S0_, SN_, DUP_, NLV_) fc_mainloop_dense<S0_, SN_, DN, DUP_, NLV_>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd)
-        const int dup = Gd.dup, nlv = Gd.nlive;
+        int dup, nlv;
+        fc_variant(Gd, dup, nlv);
         if (Gd.shape == 1 && dup == 1 && nlv == 3) FC_ML(12, 3, 1, 3);
-        else if (Gd.shape == 1 && dup == 1 && nlv == 2) FC_ML(12, 3, 1, 2);
+        else if (Gd.shape == 1 && dup == 1) FC_ML(12, 3, 1, 2);
         else if (Gd.shape == 1) FC_ML(12, 3, 0, 3);          // (a padding slot is contracted like a live one: its result is never read)
         else if (Gd.shape == 2 && dup == 3 && nlv == 2) FC_ML(3, 3, 3, 2);
         else if (Gd.shape == 2 && dup == 3 && nlv == 1) FC_ML(3, 3, 3, 1);
         else if (Gd.shape == 2 && dup == 3) FC_ML(3, 3, 3, 3);
         else if (Gd.shape == 2 && dup == 2) FC_ML(3, 3, 2, 3);
         else if (Gd.shape == 2) FC_ML(3, 3, 0, 3);
+        else FC_ML(12, 0, 0, 3);
 #undef FC_ML
-        else fc_mainloop_dense<12, 0, DN>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd);
       } else {
       FcPre pre;
       const int shape = Gd.shape;
@@ -1345,7 +1370,7 @@ static void launch_conv_fused_t(const FusedConvArgs& a, hipStream_t s) {
   int max_local = 0;
   for (int y = 0; y < a.ysplit; ++y) max_local = std::max(max_local, a.gsplit[y + 1] - a.gsplit[y]);
   if (max_local > FC_MAXG) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: more granules per workgroup than descriptor slots (raise DDMI_FUSED_YS)");
-  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FC_YB + FC_WAVES * 32 * GS2 + FC_WAVES * 2 * 32 * ES + FC_MAXG * FC_GWORDS + max_local * CGN) * sizeof(float);
+  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FC_YB + FC_WAVES * 32 * GS2 + FC_WAVES * 2 * 32 * ES + FC_MAXG * FC_GWORDS + FC_MAXG + max_local * CGN) * sizeof(float);
   if (smem > 160 * 1024) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: LDS budget exceeded (raise DDMI_FUSED_YS)");
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per instantiation)
   if (!lds_opt_in) {
