@@ -1079,7 +1079,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     const int n = g_end - g_begin;
     int n_units = 0;
     for (int i = 0; i < n; ++i) n_units += a.gran[g_begin + i].accumulate == 0;
-    int want = (a.dbg & 2048) || n_units == 0 ? 0 : (int)(blockIdx.x % (unsigned)n_units), start = 0;
+    const int phases = (a.dbg >> 12) & 15 ? min((a.dbg >> 12) & 15, n_units) : n_units;   // (profiling knob: fewer distinct start units)
+    int want = (a.dbg & 2048) || n_units == 0 ? 0 : (int)(blockIdx.x % (unsigned)phases) * (n_units / max(phases, 1)), start = 0;
     for (int i = 0, u = 0; i < n; ++i)
       if (a.gran[g_begin + i].accumulate == 0) { if (u == want) start = i; ++u; }
     for (int i = 0; i < n; ++i) gorder[i] = g_begin + (start + i) % n;
