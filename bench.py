@@ -298,7 +298,7 @@ def main():
             traffic, traffic_src = None, None
             if os.path.exists(TRAFFIC_RECORD):        # counter bytes are collected by a separate rocprofv3 --pmc pass (tools/round_profile.sh)
                 rec = json.load(open(TRAFFIC_RECORD))
-                if rec.get("kernel") == dom and rec.get("config") == args.config:
+                if rec.get("kernel") == dom and rec.get("config") == args.config and args.samples is None and world == 1:
                     traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
             if flops / bytes_ > ridge:
                 ach = flops / avg_s / 1e12
