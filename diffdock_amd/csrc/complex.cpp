@@ -181,9 +181,15 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
       PhaseTimer t(m, "conv_fc1_gemms", gs);
       const float* W1p = L.W1p[wg];
-      if (g.sig) { gemm(g.sig, ns, W1p, L.n_edge, nullptr, rowbias, H, c.B, H, ns, 0, gs); rb = rowbias; }
-      gemm(Xin + (size_t)g.tbase * XS, XS, W1p + (g.swap_pq ? 2 : 1) * ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
-      gemm(Xin + (size_t)g.gbase * XS, XS, W1p + (g.swap_pq ? 1 : 2) * ns, L.n_edge, L.b1p[wg], Q, H, g.gcount, H, ns, 0, gs);
+      GemmBatch gb;   // the group's per-graph and per-node terms of the first Linear: independent, one launch
+      auto add = [&](const float* A, int lda, const float* W, const float* bias, float* C, int M) {
+        GemmArgs& x = gb.g[gb.n++];
+        x.A = A; x.lda = lda; x.W = W; x.ldw = L.n_edge; x.bias = bias; x.C = C; x.ldc = H; x.M = M; x.N = H; x.K = ns;
+      };
+      if (g.sig) { add(g.sig, ns, W1p, nullptr, rowbias, c.B); rb = rowbias; }
+      add(Xin + (size_t)g.tbase * XS, XS, W1p + (g.swap_pq ? 2 : 1) * ns, nullptr, P, g.tcount);
+      add(Xin + (size_t)g.gbase * XS, XS, W1p + (g.swap_pq ? 1 : 2) * ns, L.b1p[wg], Q, g.gcount);
+      launch_gemm_batch(gb, gs);
     } else {
       PhaseTimer t(m, "conv_fc1_gemms", gs);
       if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]

@@ -7,18 +7,20 @@
 // L2-resident, so operands go straight to registers: lane l of a wave owns row (l&31) of
 // its 32x32 tile for both A and W and loads 4 consecutive k (16 B) per step; the k <-> lane
 // pairing of the MFMA (lanes 0-31: k, lanes 32-63: k') is free as long as A and B agree.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace ddmi {
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& a, int bx, int by) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   int M = a.M;
   if (a.m_dev) { int mv = *a.m_dev; M = mv < M ? mv : M; }
-  const int m0 = blockIdx.y * 64 + (wave >> 1) * 32;
-  const int n0 = blockIdx.x * 64 + (wave & 1) * 32;
+  const int m0 = by * 64 + (wave >> 1) * 32;
+  const int n0 = bx * 64 + (wave & 1) * 32;
   if (m0 >= M || n0 >= a.N) return;  // wave-uniform
   const int row = min(m0 + r, M - 1), col = min(n0 + r, a.N - 1);
   const float* __restrict__ Ap = a.A + (size_t)row * a.lda;
@@ -60,6 +62,31 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a) {
       a.C[(size_t)m * a.ldc + c] = v;
     }
   }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a) { gemm_tile<VEC>(a, blockIdx.x, blockIdx.y); }
+// up to 4 independent small GEMMs in one launch (blockIdx.z = problem): the per-node terms of one edge group's first layer
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_gemm_nt_batch(GemmBatch b) {
+  const GemmArgs& a = b.g[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= a.N || (int)blockIdx.y * 64 >= a.M) return;
+  gemm_tile<VEC>(a, blockIdx.x, blockIdx.y);
+}
+
+void launch_gemm_batch(const GemmBatch& b, hipStream_t s) {
+  int mx = 0, my = 0;
+  bool vec = true;
+  for (int i = 0; i < b.n; ++i) {
+    const GemmArgs& a = b.g[i];
+    mx = std::max(mx, cdiv(a.N, 64)); my = std::max(my, cdiv(a.M, 64));
+    vec = vec && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && (((uintptr_t)a.A | (uintptr_t)a.W) % 16 == 0);
+  }
+  if (b.n <= 0 || mx <= 0 || my <= 0) return;
+  dim3 grid(mx, my, b.n);
+  if (vec) hipLaunchKernelGGL(k_gemm_nt_batch<true>, grid, dim3(256), 0, s, b);
+  else hipLaunchKernelGGL(k_gemm_nt_batch<false>, grid, dim3(256), 0, s, b);
+  DDMI_CHECK_HIP(hipGetLastError());
 }
 
 void launch_gemm(const GemmArgs& a, hipStream_t s) {

@@ -164,23 +164,40 @@ __device__ __forceinline__ bool cross_in_range(const float* lp, const float* rp,
   return dist2_rn(rp[0], rp[1], rp[2], lp[0], lp[1], lp[2]) < cut * cut;
 }
 
-// threads [0,nL): per ligand atom (ranks along receptor index); threads [nL, nL+nR): per receptor node
-__global__ void k_cross_count(const float* __restrict__ lpos, const float* __restrict__ rpos,
+// blocks [0, ceil(nL / 4)): one WAVE per ligand atom -- its residues are tested 64 at a time and ranked with a shuffle scan
+// (ranks along the receptor index; a thread per atom walking 300-1500 residues was an 80-us latency chain per forward);
+// the remaining blocks: one thread per receptor node (its graph's few ligand atoms).
+__global__ __launch_bounds__(256) void k_cross_count(const float* __restrict__ lpos, const float* __restrict__ rpos,
                               const int* __restrict__ lbatch, const int* __restrict__ rbatch,
                               const int* __restrict__ lptr, const int* __restrict__ rptr, int nL, int nR, int maxNr,
                               const float* __restrict__ cutoff, float const_cutoff, const int* __restrict__ keep,
                               int* __restrict__ pairrank, int* __restrict__ cnt_l, int* __restrict__ cnt_r) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < nL) {
-    const int i = t, b = lbatch[i], lo = rptr[b], hi = rptr[b + 1];
+  const int lig_blocks = (nL + 3) / 4;
+  if ((int)blockIdx.x < lig_blocks) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nL) return;
+    const int b = lbatch[i], lo = rptr[b], hi = rptr[b + 1];
     const float cut = cutoff ? cutoff[b] : const_cutoff;
-    int c = 0;
+    const float lp[3] = {lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]};
     int* row = pairrank + (size_t)i * maxNr;
-    for (int j = lo; j < hi; ++j)
-      row[j - lo] = ((!keep || keep[j]) && cross_in_range(lpos + 3 * i, rpos + 3 * j, cut, cutoff != nullptr)) ? c++ : -1;
-    cnt_l[i] = c;
-  } else if (t < nL + nR) {
-    const int j = t - nL, b = rbatch[j], lo = lptr[b], hi = lptr[b + 1];
+    int running = 0;
+    for (int base = lo; base < hi; base += 64) {
+      const int j = base + lane;
+      const int hit = (j < hi && (!keep || keep[j]) && cross_in_range(lp, rpos + 3 * j, cut, cutoff != nullptr)) ? 1 : 0;
+      int incl = hit;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl(incl, lane >= d ? lane - d : lane, 64);
+        if (lane >= d) incl += up;
+      }
+      if (j < hi) row[j - lo] = hit ? running + incl - 1 : -1;
+      running += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) cnt_l[i] = running;
+  } else {
+    const int j = ((int)blockIdx.x - lig_blocks) * 256 + threadIdx.x;
+    if (j >= nR) return;
+    const int b = rbatch[j], lo = lptr[b], hi = lptr[b + 1];
     const float cut = cutoff ? cutoff[b] : const_cutoff;
     int c = 0;
     if (!keep || keep[j])
@@ -192,7 +209,7 @@ void launch_cross_count(const float* lpos, const float* rpos, const int* lbatch,
                         const int* rptr, int nL, int nR, int maxNr, const float* cutoff, float const_cutoff,
                         const int* keep, int* pairrank, int* cnt_l, int* cnt_r, hipStream_t s) {
   if (nL + nR <= 0) return;
-  hipLaunchKernelGGL(k_cross_count, dim3(cdiv(nL + nR, 64)), dim3(64), 0, s, lpos, rpos, lbatch, rbatch, lptr, rptr, nL,
+  hipLaunchKernelGGL(k_cross_count, dim3(cdiv(nL, 4) + cdiv(nR, 256)), dim3(256), 0, s, lpos, rpos, lbatch, rbatch, lptr, rptr, nL,
                      nR, maxNr, cutoff, const_cutoff, keep, pairrank, cnt_l, cnt_r);
   DDMI_CHECK_HIP(hipGetLastError());
 }

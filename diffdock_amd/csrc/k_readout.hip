@@ -134,9 +134,49 @@ __global__ void k_tp_apply(TpApplyArgs a) {
   const float w = (live && a.ew) ? a.ew[e] : 1.f;
   for (int k = 0; k < item.dout; ++k) a.out[(size_t)e * a.ldo + item.o_off + item.w * item.dout + k] = w * m[k];
 }
+// Same arithmetic with one WAVE per (edge, item): the lanes share the (path, u) terms of the item and meet in a shuffle
+// reduction.  For launches with few (edge, item) pairs (final_conv: one edge per ligand atom, 4 items) the thread-per-item
+// form above is a chain of ~100 dependent-latency iterations on a nearly empty chip (160 us); this form takes ~10 us.
+__global__ __launch_bounds__(256) void k_tp_apply_wave(TpApplyArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= (long)a.E * a.n_items) return;
+  const int e = (int)(t / a.n_items), it = (int)(t - (long)e * a.n_items);
+  const CgItem item = a.items[it];
+  float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool live = !a.valid_cnt || (e % a.cap) < a.valid_cnt[e / a.cap];
+  if (live) {
+    const float* __restrict__ x = a.X + (size_t)a.xrow[e] * XS;
+    const float* __restrict__ sh = a.sh + (size_t)e * a.lds_;
+    const float* __restrict__ wt = a.Wt + (size_t)e * a.ldw;
+    for (int p = item.path_begin; p < item.path_end; ++p) {
+      const DevPath P = a.paths[p];
+      const float* __restrict__ C = a.ctab + P.c_off;
+      for (int u = lane; u < P.mul_in; u += 64) {
+        const float w = wt[P.w_off + u * P.mul_out + item.w];
+        for (int i = 0; i < P.din; ++i) {
+          const float xw = x[P.i_off + u * P.din + i] * w;
+          for (int j = 0; j < P.ds; ++j) {
+            const float v = xw * sh[P.s_off + j];
+            for (int k = 0; k < P.dout; ++k) m[k] = fmaf(C[(i * P.ds + j) * P.dout + k], v, m[k]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    for (int off = 32; off > 0; off >>= 1) m[k] += __shfl_down(m[k], off, 64);
+  if (lane == 0) {
+    const float w = (live && a.ew) ? a.ew[e] : 1.f;
+    for (int k = 0; k < item.dout; ++k) a.out[(size_t)e * a.ldo + item.o_off + item.w * item.dout + k] = w * m[k];
+  }
+}
 void launch_tp_apply(const TpApplyArgs& a, hipStream_t s) {
   if (a.E <= 0 || a.n_items <= 0) return;
-  hipLaunchKernelGGL(k_tp_apply, dim3(cdiv((long)a.E * a.n_items, 128)), dim3(128), 0, s, a);
+  const long pairs = (long)a.E * a.n_items;
+  if (pairs <= 32768) hipLaunchKernelGGL(k_tp_apply_wave, dim3(cdiv(pairs, 4)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_tp_apply, dim3(cdiv(pairs, 128)), dim3(128), 0, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

@@ -19,6 +19,8 @@ struct GemmArgs {
   int act = 0;  // 0 none, 1 relu, 2 tanh
 };
 void launch_gemm(const GemmArgs& a, hipStream_t s);
+struct GemmBatch { GemmArgs g[4]; int n = 0; };
+void launch_gemm_batch(const GemmBatch& b, hipStream_t s);   // independent problems, one launch
 
 // ---------------------------------------------------------------- k_conv.hip
 // Column layout of a contracted node row Y_d[k][n] ("item-major"): for every output block ob and every output
