@@ -495,7 +495,8 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
   DDMI_DYN_SMEM(float, smem);
   constexpr int KS = 4 * NSQ;                        // MFMA steps = floats per lane quarter
   constexpr int H = 48 * NSQ, NB = H / 16, NG8 = H / 8;
-  float* wl = smem;                                  // [KS][4][H]
+  constexpr int HP = H + 1;                          // odd row stride: the staging writes (consecutive threads = consecutive rows) spread over the banks
+  float* wl = smem;                                  // [KS][4][HP]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = DDMI_UNIFORM(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
   for (int idx = tid; idx < H * 4 * KS; idx += 256) {   // k fastest: coalesced reads of the weight rows
     const int k = idx % (4 * KS), n = idx / (4 * KS);
     const int q = k / KS, t = k - q * KS;
-    wl[(t * 4 + q) * H + n] = a.W1[(size_t)n * a.ldw + k];
+    wl[(t * 4 + q) * HP + n] = a.W1[(size_t)n * a.ldw + k];
   }
   __syncthreads();
   for (int v = blockIdx.x * 4 + wave; v < nvn; v += gridDim.x * 4) {
@@ -555,13 +556,13 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
       for (int nb = 0; nb < NB; ++nb) {
         f32x4 acc = f32x4{qv[nb].x + pv[nb].x, qv[nb].y + pv[nb].y, qv[nb].z + pv[nb].z, qv[nb].w + pv[nb].w};
         f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: a dependent f32 MFMA waits 40 cycles
-        const float* __restrict__ wp = wl + lq * H + 16 * nb + lr;
+        const float* __restrict__ wp = wl + lq * HP + 16 * nb + lr;
 #pragma unroll
         for (int j = 0; j < NSQ; ++j) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 0) * 4 * H], ae[j].x, acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 1) * 4 * H], ae[j].y, acc2, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 2) * 4 * H], ae[j].z, acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 3) * 4 * H], ae[j].w, acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 0) * 4 * HP], ae[j].x, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 1) * 4 * HP], ae[j].y, acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 2) * 4 * HP], ae[j].z, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 3) * 4 * HP], ae[j].w, acc2, 0, 0, 0);
         }
         float4 o;
         o.x = live ? fmaxf(acc[0] + acc2[0], 0.f) : 0.f; o.y = live ? fmaxf(acc[1] + acc2[1], 0.f) : 0.f;
@@ -576,8 +577,14 @@ void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {
   if (a.vcap <= 0) return;
   if (a.ns % 16 != 0 || a.ns > 64 || a.H != 3 * a.ns || a.NG8 * 8 != a.H)
     throw Error(DDMI_ERR_ARG, "k_edge_hidden_mm: unsupported width");
-  const size_t smem = (size_t)(a.ns * a.H) * sizeof(float);
-  static const int eh_grid = getenv("DDMI_EH_GRID") ? atoi(getenv("DDMI_EH_GRID")) : 2048;   // tuning knob
+  const size_t smem = (size_t)(a.ns * (a.H + 1)) * sizeof(float);
+  // persistent grid: 3 workgroups per CU (the kernel's occupancy at 136 VGPRs), each staging the weights once
+  static const int eh_grid = [] {
+    if (getenv("DDMI_EH_GRID")) return atoi(getenv("DDMI_EH_GRID"));   // tuning knob
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 3 * std::max(cus, 1);
+  }();
   const int grid = std::min(cdiv(a.vcap, 4), eh_grid);
   switch (a.ns / 16) {
     case 1: hipLaunchKernelGGL(k_edge_hidden_mm<1>, dim3(grid), dim3(256), smem, s, a); break;
