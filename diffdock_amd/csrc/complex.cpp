@@ -232,7 +232,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       int ys_req = m.fused_ysplit;
       if (ys_req <= 0) {
         const long est_tiles = std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16);
-        ys_req = (int)std::min(8L, std::max(1L, 768 / est_tiles));
+        ys_req = (int)std::min(6L, std::max(1L, 768 / est_tiles));   // (measured at 5 / 10 / 20 / 40 poses: beyond 6 the repeated prologues cost more than the extra workgroups bring)
       }
       ys_req = std::max(ys_req, (L.n_fgran + 47) / 48);   // a workgroup keeps at most 64 granule descriptors in LDS
       const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
