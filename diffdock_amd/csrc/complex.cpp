@@ -244,6 +244,9 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         f.gsplit[y] = std::max(b, f.gsplit[y - 1]);
       }
       f.gsplit[ys] = L.n_fgran;
+      f.n_units = 0;
+      for (int gq = 0; gq < L.n_fgran && f.n_units < 48; ++gq)
+        if (gq == 0 || L.fgran_unit[gq] != L.fgran_unit[gq - 1]) f.ustart[f.n_units++] = (short)gq;
       if (load_mode) {
         {
           PhaseTimer t(m, "k_node_contract", gs);

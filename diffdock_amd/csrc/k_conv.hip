@@ -1078,14 +1078,14 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   // Visiting order of the granules, rotated by whole units per workgroup: tiles start together and take equal time, so with
   // one common order all 256 CUs would issue their message stores (98 KB per tile and granule) in the same microseconds and
   // then wait for that burst to drain; rotated, the stores of the chip spread over the whole granule period.
-  if (tid == 0) {
+  if (tid == 0) {   // (unit starts come with the kernel arguments: no global loads on this path)
     const int n = g_end - g_begin;
     int n_units = 0;
-    for (int i = 0; i < n; ++i) n_units += a.gran[g_begin + i].accumulate == 0;
-    const int phases = (a.dbg >> 12) & 15 ? min((a.dbg >> 12) & 15, n_units) : n_units;   // (profiling knob: fewer distinct start units)
-    int want = (a.dbg & 2048) || n_units == 0 ? 0 : (int)(blockIdx.x % (unsigned)phases) * (n_units / max(phases, 1)), start = 0;
-    for (int i = 0, u = 0; i < n; ++i)
-      if (a.gran[g_begin + i].accumulate == 0) { if (u == want) start = i; ++u; }
+    for (int u = 0; u < a.n_units; ++u) n_units += a.ustart[u] >= g_begin && a.ustart[u] < g_end;
+    const int want = (a.dbg & 2048) || n_units == 0 ? 0 : (int)(blockIdx.x % (unsigned)n_units);
+    int start = 0;
+    for (int u = 0, k = 0; u < a.n_units; ++u)
+      if (a.ustart[u] >= g_begin && a.ustart[u] < g_end) { if (k == want) start = a.ustart[u] - g_begin; ++k; }
     for (int i = 0; i < n; ++i) gorder[i] = g_begin + (start + i) % n;
   }
   // dense coupling rows of this workgroup's granules: cgt[g][s][k'][j] = C_path(s)[comp(s)][j - s_off][k'] (0 outside the path's sh block)

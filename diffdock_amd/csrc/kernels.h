@@ -125,6 +125,7 @@ struct FusedConvArgs {
   const GEntry* gmap; const float* ctab; int maxd;
   int generic;                           // some granule has no static chain shape: predicated kernel variant
   int dense;                             // most virtual nodes hold > 16 edges: multiply both row tiles unconditionally
+  int n_units; short ustart[48];         // first granule of every (output block, w tile) unit: workgroups rotate their visiting order by units
   float* msg;                            // [E][XS]
   int dbg = 0;
 };
