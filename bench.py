@@ -194,7 +194,11 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if os.environ.get("DDMI_BENCH_SHARE_GPU"):     # test hook: all ranks on cuda:0 over gloo (exercises the multi-rank code path on a 1-GPU box)
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
