@@ -125,7 +125,7 @@ def same_shape_complexes_case(make, place, cfg=TINY):
     return out_a, out_b
 
 
-def config0_case(make, place, cfg, tol_pos=2e-3):
+def config0_case(make, place, cfg, tol_pos=2e-3, steps=4):
     """BASELINE configs[0]: the reference's example complex data/1a0q (416 residues / 23 heavy atoms, read by
     diffdock_amd.io -> tests/golden/1a0q_graph.pt), 4 inference steps x 2 samples: the device loop against the oracle's
     loop on the real geometry (language-model embeddings and RDKit atom features are external inputs: seeded stand-ins)."""
@@ -142,7 +142,7 @@ def config0_case(make, place, cfg, tol_pos=2e-3):
     d["lig_x"] = feats
     g = graph_from_dict(d)
     sd = init_state_dict(cfg, seed=17)
-    B, steps = 2, 4
+    B = 2
     dl = make_pose_list(g, B, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.2)
     R = int(d["edge_mask"].sum())
     gen = torch.Generator().manual_seed(4)

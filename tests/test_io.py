@@ -59,7 +59,7 @@ def test_graph_builders_agree_with_the_synthetic_generators():
 
 
 def test_configs0_plumbing_on_the_cpu_emulation():
-    """BASELINE configs[0] (data/1a0q, 4 steps x 2 samples) with the small preset through the emulated kernels."""
+    """BASELINE configs[0] geometry (data/1a0q, 2 samples) with the small preset through the emulated kernels, 2 steps."""
     r = subprocess.run(["make", "-j8", "-C", os.path.join(ROOT, "diffdock_amd", "csrc"), "emu"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
 
@@ -68,4 +68,4 @@ def test_configs0_plumbing_on_the_cpu_emulation():
         m.load_state_dict(sd)
         m.set_tables(*tables())
         return m
-    cases.config0_case(make, lambda b: b, TINY.replace(lm_embedding_type=None))
+    cases.config0_case(make, lambda b: b, TINY.replace(lm_embedding_type=None, num_conv_layers=3), steps=2)   # (4 steps, full width: -m gpu)

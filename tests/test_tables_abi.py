@@ -14,18 +14,21 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def test_so3_table_matches_reference_module():
-    mine, ref = T.so3_exp_score_norms(), np.load(os.path.join(GOLD, "so3_exp_score_norms.npy"))
-    # eps >= 0.0074 (index 600): the whole range a model can reach (rot_sigma_min is 0.03 .. 0.1); below it the
-    # reference's L=2000 truncated series is not converged (it even yields NaN there) and nothing is pinned
-    assert not np.isnan(mine[600:]).any()
-    assert np.max(np.abs(mine[600:] - ref[600:]) / np.abs(ref[600:])) < 1e-6
+    """The table generator against the array the reference module holds, bit for bit, on a spread of rows (the full 2000-row
+    computation takes over a minute; the SHIPPED table is compared in full below): the unconverged small-eps rows, the NaN
+    rows 153..170 of the reference, the range a model can reach (index >= 600) and the last rows."""
+    ref = np.load(os.path.join(GOLD, "so3_exp_score_norms.npy"))
+    rows = sorted({0, 1, 50, 153, 160, 170, 261, 399, 400, 600, 601, 911, 1000, 1109, 1500, 1789, 1999})
+    mine = T.so3_exp_score_norms(indices=set(rows))
+    assert np.array_equal(mine[rows], ref[rows], equal_nan=True)
+    assert np.isnan(ref[[153, 160, 170, 261]]).all() and not np.isnan(ref[600:]).any()
 
 
 def test_shipped_tables_equal_reference_fixtures():
     so3, tor = T.default_tables(cache=False)
     ref_so3, ref_tor = np.load(os.path.join(GOLD, "so3_exp_score_norms.npy")), np.load(os.path.join(GOLD, "torus_score_norm.npy"))
     assert np.array_equal(tor, ref_tor)          # seeded Monte-Carlo, same call sequence as utils/torus.py
-    assert np.max(np.abs(so3[600:] - ref_so3[600:]) / np.abs(ref_so3[600:])) < 1e-6
+    assert np.array_equal(so3, ref_so3, equal_nan=True)   # every index, unconverged entries and NaNs included
 
 
 @pytest.fixture(scope="module")
