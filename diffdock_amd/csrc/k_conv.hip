@@ -1034,7 +1034,7 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const
 template <int MAXD, int SHD, int MODE>
 __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
-  constexpr int GS2 = 4 * MAXD + 8, ES = SHD + 3, CGN = 4 * MAXD * SHD;
+  constexpr int GS2 = 4 * MAXD + 8, ES = SHD == 4 ? 8 : SHD + 3, CGN = 4 * MAXD * SHD;   // ES: edge-row stride (sh, weight, message row); 8 keeps 4 harmonics one 16-B read
   float* xbuf = smem;                                  // [16][XS+1]
   float* ybuf = xbuf + FC_VN * NC_XS;                  // [2][16 x FC_YVN]
   float* gscr = ybuf + 2 * FC_YB;                      // per wave: [32 edge rows][MAXD][4 slots] (+8 pad) coupling rows of the current (granule, virtual node)
@@ -1309,11 +1309,17 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       if (ne == 0 || (a.dbg & 32)) continue;
       const float* __restrict__ erow = ew_ + vi * 32 * ES;
       DDMI_WAVE_SYNC();
-      {   // G[el][s][k'] = sum_j cg[s][k'][j] * sh_el[j] : lane = (edge row, slot pair)
+      {   // G[el][s][k'] = we_el * sum_j cg[s][k'][j] * sh_el[j] : lane = (edge row, slot pair); the edge weight rides along
         const int el = lane & 31, half = lane >> 5;
         float sh[SHD];
+        if constexpr (SHD == 4) {
+          const float4 s4 = *reinterpret_cast<const float4*>(erow + el * ES);
+          sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < SHD; ++j) sh[j] = erow[el * ES + j];
+          for (int j = 0; j < SHD; ++j) sh[j] = erow[el * ES + j];
+        }
+        const float we = erow[el * ES + SHD];
 #pragma unroll
         for (int k = 0; k < MAXD; ++k) {
           float2 v = make_float2(0.f, 0.f);
@@ -1322,6 +1328,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
             v.x = fmaf(cg[((2 * half) * MAXD + k) * SHD + j], sh[j], v.x);
             v.y = fmaf(cg[((2 * half + 1) * MAXD + k) * SHD + j], sh[j], v.y);
           }
+          v.x *= we; v.y *= we;
           *reinterpret_cast<float2*>(gw + el * GS2 + 4 * k + 2 * half) = v;   // the four slots of (row, k') side by side
         }
       }
@@ -1330,6 +1337,14 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         float* stg = ybuf + wave * ((2 * FC_YB) / FC_WAVES);   // the chunk buffers are idle during the coupling phase
         const int RS = 16 * Gd.dout, L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
         const int V = ((c0 | L) & 3) == 0 ? 4 : ((c0 | L) & 1) == 0 ? 2 : 1;
+        // message value of (row, k') from the lane's four slot accumulators
+        auto couple = [&](const float* __restrict__ G, int k, float t0, float t1, float t2, float t3) __attribute__((always_inline)) {
+          const float4 g4 = *reinterpret_cast<const float4*>(G + 4 * k);
+          float v = g4.x * t0;
+          v = fmaf(g4.y, t1, v);
+          v = fmaf(g4.z, t2, v);
+          return fmaf(g4.w, t3, v);
+        };
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           if (ne <= 16 * rt) break;
@@ -1338,17 +1353,15 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
             const int row = 4 * lq + r, el = rt * 16 + row;
             const float* __restrict__ G = gw + el * GS2;
             const float t0 = acc[vi][rt][0][r], t1 = acc[vi][rt][1][r], t2 = acc[vi][rt][2][r], t3 = acc[vi][rt][3][r];
-            const float we = erow[el * ES + SHD];
+            if (Gd.dout == 1) {          // scalar output blocks
+              stg[row * 16 + lr] = couple(G, 0, t0, t1, t2, t3);
+            } else if (Gd.dout == 3) {   // vector output blocks: the three components of (row, w) side by side
+              float* __restrict__ o = stg + row * 48 + lr * 3;
+              o[0] = couple(G, 0, t0, t1, t2, t3); o[1] = couple(G, 1, t0, t1, t2, t3); o[2] = couple(G, 2, t0, t1, t2, t3);
+            } else {
 #pragma unroll
-            for (int k = 0; k < MAXD; ++k) {
-              if (k < Gd.dout) {
-                const float4 g4 = *reinterpret_cast<const float4*>(G + 4 * k);
-                float v = g4.x * t0;
-                v = fmaf(g4.y, t1, v);
-                v = fmaf(g4.z, t2, v);
-                v = fmaf(g4.w, t3, v);
-                stg[row * RS + lr * Gd.dout + k] = v * we;
-              }
+              for (int k = 0; k < MAXD; ++k)
+                if (k < Gd.dout) stg[row * RS + lr * Gd.dout + k] = couple(G, k, t0, t1, t2, t3);
             }
           }
           DDMI_WAVE_SYNC();
@@ -1370,7 +1383,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 
 template <int MAXD, int SHD>
 static void launch_conv_fused_t(const FusedConvArgs& a, hipStream_t s) {
-  constexpr int GS2 = 4 * MAXD + 8, ES = SHD + 3, CGN = 4 * MAXD * SHD;
+  constexpr int GS2 = 4 * MAXD + 8, ES = SHD == 4 ? 8 : SHD + 3, CGN = 4 * MAXD * SHD;   // ES: edge-row stride (sh, weight, message row); 8 keeps 4 harmonics one 16-B read
   int max_local = 0;
   for (int y = 0; y < a.ysplit; ++y) max_local = std::max(max_local, a.gsplit[y + 1] - a.gsplit[y]);
   if (max_local > FC_MAXG) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: more granules per workgroup than descriptor slots (raise DDMI_FUSED_YS)");
