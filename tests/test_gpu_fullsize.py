@@ -121,3 +121,25 @@ def test_configs0_plumbing_1a0q_full_width():
     from diffdock_amd.config import DDL_SYNTH
     r = cases.config0_case(gpu_model, place, DDL_SYNTH)
     print("1a0q 4-step RMSD to the oracle loop [A]:", r.tolist())
+
+
+@pytest.mark.parametrize("n_res,n_lig,lmax", [(150, 20, 1), (500, 45, 1), (500, 45, 2)])
+def test_mix_shapes_forward_matches_oracle(n_res, n_lig, lmax):
+    """The corner shapes of bench.py's PDBBind-like mix (Nr in {150, 300, 500} x Nl in {20, 30, 45}) against the
+    oracle, all pairs connected: 20-atom ligands leave the 32-row edge tiles of a residue 37 % empty, 45-atom ligands give
+    every residue two virtual nodes (32 + 13 edges); with sh_lmax = 2 the e3nn-style tensor product (generic granules)."""
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    from oracle.cg_model import CGModelOracle
+    cfg = DDL_SYNTH.replace(dynamic_max_cross=False, cross_max_distance=80.0, sh_lmax=lmax)
+    sd = init_state_dict(cfg, seed=1234)
+    g = make_complex(seed=10 + n_res // 100, n_res=n_res, n_lig=n_lig)
+    dl = make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=3, initial_noise_std_proportion=0.3)
+    batch = HeteroBatch.from_data_list(dl)
+    set_time(batch, 0.45, 0.45, 0.45, 2)
+    ref = CGModelOracle(cfg, sd, *tables())(batch)[:3]
+    m = gpu_model(cfg, sd)
+    out = m(place(batch))[:3]
+    assert int(m.debug_buffer("offs_l")[-1]) == 2 * n_res * n_lig
+    assert_scores_close(out, ref, what=f"{n_res}/{n_lig} lmax {lmax}")
