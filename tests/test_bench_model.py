@@ -50,6 +50,17 @@ def test_workloads_cover_the_baseline_configs():
     assert sorted({c[0] for c in mix}) == [150, 300, 500] and sorted({c[1] for c in mix}) == [20, 30, 45] and len(mix) == 9
 
 
+def test_committed_traffic_record_is_what_bench_reads():
+    """profiles/traffic_latest.json (written by tools/round_profile.sh from the FETCH_SIZE / WRITE_SIZE passes) carries the keys
+    bench.py copies into `roofline.traffic`, for the default workload and the dominant kernel."""
+    import json
+    b = load_bench()
+    rec = json.load(open(b.TRAFFIC_RECORD))
+    assert rec["kernel"] == "k_conv_fused" and rec["config"] == "configs2"
+    assert rec["bytes_per_launch"] == (2.0 * rec["fetch_size_kb_per_launch_raw"] + rec["write_size_kb_per_launch"]) * 1024.0
+    assert 1e8 < rec["bytes_per_launch"] < 1e10 and rec["source"].startswith("profiles/")
+
+
 def test_roofline_constants_match_the_microarchitecture_guide():
     b = load_bench()
     assert b.MFMA_F32_PEAK_TFLOPS == 157.3 and b.HBM_PEAK_GBS == 8000.0
