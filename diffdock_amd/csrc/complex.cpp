@@ -751,6 +751,10 @@ static void score_readouts(Model& m, const float* XL, const float* lig_pos, cons
   Cx& c = *m.cx;
   const ddmi_config& cfg = m.cfg;
   const int ns = m.ns, sd = m.sd, B = c.B, nL = c.nL;
+  if (m.two_streams && m.side_stream && c.nT > 0 && tor_out) {   // the torsion head below forks here
+    DDMI_CHECK_HIP(hipEventRecord(m.ev_fork, s));
+    DDMI_CHECK_HIP(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0));
+  }
   // ---- translation / rotation heads (cg_model.py:368-395)
   const ConvW& F = m.final_conv;
   launch_center_edges(lig_pos, c.lig_batch, c.lig_ptr, B, nL, c.c_dist, c.c_nvec, s);
@@ -773,9 +777,13 @@ static void score_readouts(Model& m, const float* XL, const float* lig_pos, cons
     a.tr_out = tr_out; a.rot_out = rot_out;
     launch_score_heads(a, s);
   }
-  // ---- torsion head (cg_model.py:404-423)
+  // ---- torsion head (cg_model.py:404-423); independent of the translation / rotation heads: with two streams it runs on the
+  // side stream next to them (both chains are ~10 small launches on an otherwise idle chip)
   if (c.nT > 0 && tor_out) {
     const ConvW& T = m.tor_conv;
+    const hipStream_t s_main = s;
+    const bool fork = m.two_streams && m.side_stream;
+    if (fork) s = m.side_stream;
     launch_tor_radius(lig_pos, c.lig_ptr, c.tor_u, c.tor_v, c.tor_batch, c.nT, cfg.lig_max_radius, c.tor_cap,
                       cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.t_cnt, c.t_atom, c.t_dist, c.t_nvec, c.t_ew, c.t_bond_nvec, s);
     launch_edge_mlp(mlp_args(m.final_edge, ns, c.Et, nullptr, c.t_dist, m.off_lig, m.D, m.coeff_lig, 0, m.final_edge.b0,
@@ -792,6 +800,10 @@ static void score_readouts(Model& m, const float* XL, const float* lig_pos, cons
     a.tor_batch = c.tor_batch; a.t_tor = t_tor; a.smin = cfg.tor_sigma_min; a.smax = cfg.tor_sigma_max;
     a.scale_by_sigma = cfg.scale_by_sigma; a.torus_table = m.torus_table; a.torus_n = m.torus_n; a.out = tor_out;
     launch_tor_head(a, s);
+    if (fork) {
+      DDMI_CHECK_HIP(hipEventRecord(m.ev_join, m.side_stream));
+      DDMI_CHECK_HIP(hipStreamWaitEvent(s_main, m.ev_join, 0));
+    }
   }
 }
 
@@ -909,15 +921,23 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   std::unique_ptr<PhaseTimer> t_phase(new PhaseTimer(m, "embed_and_graphs", s));
   // ---- per-graph time terms
   launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, c.temb, s);
-  gemm(c.temb, sd, m.rec_sigma.W0, sd, m.rec_sigma.b0, c.hidB, ns, B, ns, sd, 1, s);
-  gemm(c.hidB, ns, m.rec_sigma.W3, ns, m.rec_sigma.b3, c.rec_sig, ns, B, ns, ns, 0, s);
-  gemm(c.temb, sd, m.lig_enc.W0 + ns, ns + sd, m.lig_enc.b0, c.ligsig, ns, B, ns, sd, 0, s);
-  gemm(c.temb, sd, m.lig_edge.W0 + m.nf, m.lig_edge.in, m.lig_edge.b0, c.ll_gvec, ns, B, ns, sd, 0, s);
-  gemm(c.temb, sd, m.cross_edge.W0, m.cross_edge.in, m.cross_edge.b0, c.cross_gvec, ns, B, ns, sd, 0, s);
-  if (!conf) {
-    gemm(c.temb, sd, m.center_edge.W0 + m.D, m.center_edge.in, m.center_edge.b0, c.center_gvec, ns, B, ns, sd, 0, s);
-    gemm(c.temb, sd, m.tr_final.W0 + 1, 1 + sd, m.tr_final.b0, c.tr_sig, ns, B, ns, sd, 0, s);
-    gemm(c.temb, sd, m.rot_final.W0 + 1, 1 + sd, m.rot_final.b0, c.rot_sig, ns, B, ns, sd, 0, s);
+  {   // the per-graph terms of the time embedding: independent tiny GEMMs, one launch (+ the second layer of rec_sigma)
+    GemmBatch gb;
+    auto add = [&](const float* W, int ldw, const float* bias, float* C, int act) {
+      GemmArgs& x = gb.g[gb.n++];
+      x.A = c.temb; x.lda = sd; x.W = W; x.ldw = ldw; x.bias = bias; x.C = C; x.ldc = ns; x.M = B; x.N = ns; x.K = sd; x.act = act;
+    };
+    add(m.rec_sigma.W0, sd, m.rec_sigma.b0, c.hidB, 1);
+    add(m.lig_enc.W0 + ns, ns + sd, m.lig_enc.b0, c.ligsig, 0);
+    add(m.lig_edge.W0 + m.nf, m.lig_edge.in, m.lig_edge.b0, c.ll_gvec, 0);
+    add(m.cross_edge.W0, m.cross_edge.in, m.cross_edge.b0, c.cross_gvec, 0);
+    if (!conf) {
+      add(m.center_edge.W0 + m.D, m.center_edge.in, m.center_edge.b0, c.center_gvec, 0);
+      add(m.tr_final.W0 + 1, 1 + sd, m.tr_final.b0, c.tr_sig, 0);
+      add(m.rot_final.W0 + 1, 1 + sd, m.rot_final.b0, c.rot_sig, 0);
+    }
+    launch_gemm_batch(gb, s);
+    gemm(c.hidB, ns, m.rec_sigma.W3, ns, m.rec_sigma.b3, c.rec_sig, ns, B, ns, ns, 0, s);
   }
   // ---- node tables: ligand rows [0,nL), receptor rows [nL, nL+nR)
   float* X0 = c.X[0];
