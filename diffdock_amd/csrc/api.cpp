@@ -37,6 +37,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_fork));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_join));
+    DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_cross));
     *out = h;
   });
 }

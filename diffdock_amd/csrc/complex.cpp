@@ -939,6 +939,31 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     launch_gemm_batch(gb, s);
     gemm(c.hidB, ns, m.rec_sigma.W3, ns, m.rec_sigma.b3, c.rec_sig, ns, B, ns, ns, 0, s);
   }
+  // ---- cross graph (cg_model.py:539-562): needs only the ligand positions and the time terms, so without a per-step crop it
+  // is built on the side stream while the ligand graph is built on this one (each chain is ~8 small launches)
+  const bool crop = m.crop_cutoff > 0.0;
+  DDMI_REQUIRE(!(crop && cfg.all_atoms), DDMI_ERR_ARG, "crop_beyond is not implemented for the all-atom model (aa_model.py:365-367)");
+  const float* cut_dev = cfg.dynamic_max_cross ? c.cutoff : nullptr;
+  auto cross_graph = [&](hipStream_t cs, const int* keep_) {
+    if (cfg.dynamic_max_cross)   // cutoff_b = 3 * tr_sigma_b + 20 (cg_model.py:321-322)
+      launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, cs, conf ? 1 : 0);
+    launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
+                       cfg.cross_max_distance, keep_, c.pairrank, c.cnt_l, c.cnt_r, cs);
+    launch_exclusive_scan(c.cnt_l, c.offs_l, nL, cs);
+    launch_exclusive_scan(c.cnt_r, c.offs_r, nR, cs);
+    launch_cross_fill(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, c.pairrank, c.offs_l, c.offs_r,
+                      cut_dev, cfg.cross_max_distance, cfg.smooth_edges, c.g1_tgt, c.g1_tslot, c.g3_tgt, c.g3_tslot, c.pbatch,
+                      c.pdist, c.pnvec, c.pew, cs);
+    launch_edge_mlp(mlp_args(m.cross_edge, ns, c.Elr_cap, c.offs_l + nL, c.pdist, m.off_cross, m.Dc, m.coeff_cross, sd,
+                             c.cross_gvec, c.pbatch, c.cross_ea), cs);
+  };
+  const bool early_cross = m.two_streams && m.side_stream && !crop;
+  if (early_cross) {
+    DDMI_CHECK_HIP(hipEventRecord(m.ev_fork, s));
+    DDMI_CHECK_HIP(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0));
+    cross_graph(m.side_stream, nullptr);
+    DDMI_CHECK_HIP(hipEventRecord(m.ev_cross, m.side_stream));
+  }
   // ---- node tables: ligand rows [0,nL), receptor rows [nL, nL+nR)
   float* X0 = c.X[0];
   launch_lig_node_embed(c.lig_x, nL, m.lig_emb, m.lig_emb_off, 16, ns, c.embsum, s);
@@ -964,8 +989,6 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   for (size_t i = 0; i < m.lig_emb_layers.size(); ++i, ++xi)
     run_conv(m, m.lig_emb_layers[i], {g_ll}, c.rg_ll, 1, c.X[xi], c.X[xi + 1], 0, nL, s);
   // ---- per-step receptor crop (utils/sampling.py:104-109): residue mask + re-compacted contact graph
-  const bool crop = m.crop_cutoff > 0.0;
-  DDMI_REQUIRE(!(crop && cfg.all_atoms), DDMI_ERR_ARG, "crop_beyond is not implemented for the all-atom model (aa_model.py:365-367)");
   const int* keep = nullptr;
   if (crop) {
     const double cd = m.crop_cutoff;
@@ -988,21 +1011,8 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   } else {
     launch_add_rowvec(c.X[xi] + (size_t)nL * XS, XS, c.rec_node_base, XS, c.rec_sig, ns, c.rec_batch, nR, c.rec_base_dim, ns, s);
   }
-  // ---- cross graph
-  const float* cut_dev = nullptr;
-  if (cfg.dynamic_max_cross) {  // cutoff_b = 3 * tr_sigma_b + 20 (cg_model.py:321-322)
-    launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, s, conf ? 1 : 0);
-    cut_dev = c.cutoff;
-  }
-  launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
-                     cfg.cross_max_distance, keep, c.pairrank, c.cnt_l, c.cnt_r, s);
-  launch_exclusive_scan(c.cnt_l, c.offs_l, nL, s);
-  launch_exclusive_scan(c.cnt_r, c.offs_r, nR, s);
-  launch_cross_fill(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, c.pairrank, c.offs_l, c.offs_r,
-                    cut_dev, cfg.cross_max_distance, cfg.smooth_edges, c.g1_tgt, c.g1_tslot, c.g3_tgt, c.g3_tslot, c.pbatch,
-                    c.pdist, c.pnvec, c.pew, s);
-  launch_edge_mlp(mlp_args(m.cross_edge, ns, c.Elr_cap, c.offs_l + nL, c.pdist, m.off_cross, m.Dc, m.coeff_cross, sd,
-                           c.cross_gvec, c.pbatch, c.cross_ea), s);
+  if (early_cross) DDMI_CHECK_HIP(hipStreamWaitEvent(s, m.ev_cross, 0));
+  else cross_graph(s, keep);
   // ---- interaction layers over [ll ; lig<-rec ; rec-rec ; rec<-lig]  (cg_model.py:329-349)
   RunGroup g_lr{nL, nR, 0, nL, c.offs_r, c.g1_tgt, c.g1_tslot, c.g1_tslot, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                       nullptr, c.pnvec, c.pew, 1.f, c.msg[1]};

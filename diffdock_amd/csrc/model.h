@@ -89,7 +89,7 @@ struct Model {
   // ---- complex + workspace
   bool has_complex = false;
   hipStream_t side_stream = nullptr;   // ligand-gather edge groups run here, concurrently with the receptor-gather ones
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cross = nullptr;
   bool two_streams = true;
   bool fused = true;        // receptor-gather edge groups use k_conv_fused (DDMI_FUSED=0: contracted rows through HBM)
   int fused_lig = 3;        // ligand-gather groups (DDMI_FUSED_LIG): 3 = k_conv_fused contracting per virtual node like every other
