@@ -194,6 +194,10 @@ int ddmi_wigner_3j(int l1, int l2, int l3, double* out) {
 int ddmi_set_kernel_timing(ddmi_model* h, int enabled) {
   if (!h) return DDMI_ERR_ARG;
   resolve_timings(h->m);
+#ifdef DDMI_PROFILING
+  (void)hipDeviceSynchronize();
+  ddmi::fc_prof_report();   // in-kernel phase clocks since the last call (profiling builds only)
+#endif
   h->m.timing = enabled != 0;
   if (enabled) h->m.phases.clear();
   return DDMI_OK;

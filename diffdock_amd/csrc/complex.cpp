@@ -228,6 +228,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.gmap = L.gmap;
       f.ctab = L.ctab; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
       f.dense = dense_rows ? 1 : 0;
+      f.prof_slot = (int)gi;
       // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
       int ys_req = m.fused_ysplit;
       if (ys_req <= 0) {
@@ -1209,7 +1210,11 @@ void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) 
     m.crop_cutoff = sc.use_crop ? s_tr * 3.0 + sc.crop_beyond : 0.0;   // sampling.py:107
     forward(m, lig_pos, c.s_t, c.s_t + B, c.s_t + 2 * B, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
     perturb_step(m, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, sc, k, ids_dev, s);
-    static const bool freeze = getenv("DDMI_FREEZE_POSE") != nullptr;   // timing-only ablation builds produce garbage scores: keep the graphs fixed
+#ifdef DDMI_PROFILING   // timing-only ablation builds produce garbage scores: DDMI_FREEZE_POSE keeps the graphs fixed (never in the shipped library)
+    static const bool freeze = getenv("DDMI_FREEZE_POSE") != nullptr;
+#else
+    constexpr bool freeze = false;
+#endif
     if (!freeze) modify_conformer(m, lig_pos, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
   }
 }

@@ -34,8 +34,63 @@ namespace ddmi {
 // Y[node][super-tile][k][64] -- the exact order k_edge_conv reads them back.
 constexpr int NC_NODES = 32, NC_KC = 15, NC_XS = XS + 1;
 
-// Ablation mask for profiling (env DDMI_ABLATE, 0 in production): lets bench runs switch off individual phases.
+// Profiling builds only (-DDDMI_PROFILING, tools/build_variant.sh): DDMI_ABLATE switches individual kernel phases off
+// (garbage scores, timing only) and k_conv_fused accumulates per-phase cycle counts (fc_prof_report).  The shipped library
+// contains neither: DDMI_ABL() folds to false and the stamps to nothing.
+#ifdef DDMI_PROFILING
 static int ablate_mask() { static int m = getenv("DDMI_ABLATE") ? atoi(getenv("DDMI_ABLATE")) : 0; return m; }
+#define DDMI_ABL(mask, bit) (((mask) & (bit)) != 0)
+// per-wave phase clocks of k_conv_fused (s_memtime at the phase boundaries, summed per edge-group slot)
+constexpr int FC_NPROF = 16, FC_PROF_SLOTS = 12;
+__device__ unsigned long long g_fc_prof[FC_PROF_SLOTS * FC_NPROF];
+struct FcProf {
+  unsigned t; unsigned acc[FC_NPROF];
+  __device__ __forceinline__ void start() {
+    t = (unsigned)__builtin_readcyclecounter();
+#pragma unroll
+    for (int i = 0; i < FC_NPROF; ++i) acc[i] = 0;
+  }
+  __device__ __forceinline__ void stamp(int i) {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned now = (unsigned)__builtin_readcyclecounter();
+    acc[i] += now - t; t = now;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};
+#define FC_STAMP(pf, i) (pf).stamp(i)
+#define FC_COUNT(pf, i) ((pf).acc[i] += 1)
+#if DDMI_PROFILING >= 2   // also the barrier waits inside the main loop (two more clock reads per chunk: perturbs the loop)
+#define FC_STAMP_FINE(pf, i) (pf).stamp(i)
+#define DDMI_PROF_FINE 1
+#else
+#define FC_STAMP_FINE(pf, i) ((void)0)
+#define DDMI_PROF_FINE 0
+#endif
+static const char* const fc_prof_names[FC_NPROF] = {"kernel_prologue", "granule_setup", "ml_prologue", "ml_steady", "bias", "barrier_pre_couple",
+                                                    "G_rows", "couple_stage", "store_rows", "barrier_end", "wave_total", "ml_barrier_wait", "-", "-",
+                                                    "granules", "waves"};
+void fc_prof_report() {
+  unsigned long long h[FC_PROF_SLOTS * FC_NPROF];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fc_prof), sizeof(h)) != hipSuccess) return;
+  for (int sl = 0; sl < FC_PROF_SLOTS; ++sl) {
+    const unsigned long long* r = h + sl * FC_NPROF;
+    if (r[15] == 0) continue;
+    fprintf(stderr, "FCPROF slot=%d waves=%llu granules_per_wave=%.2f", sl, r[15], (double)r[14] / (double)r[15]);
+    for (int i = 0; i < 12; ++i) fprintf(stderr, " %s=%.0f", fc_prof_names[i], (double)r[i] / (double)r[15]);
+    fprintf(stderr, "\n");
+  }
+  memset(h, 0, sizeof(h));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fc_prof), h, sizeof(h));
+}
+#else
+static int ablate_mask() { return 0; }
+#define DDMI_ABL(mask, bit) false
+struct FcProf {};
+#define FC_STAMP(pf, i) ((void)0)
+#define FC_STAMP_FINE(pf, i) ((void)0)
+#define FC_COUNT(pf, i) ((void)0)
+#define DDMI_PROF_FINE 0
+#endif
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void nt_store4(float* p, float a, float b, float c, float d) {
@@ -61,11 +116,11 @@ __device__ __forceinline__ void nc_chain(const float* __restrict__ bp, const flo
   float bv[NSTEPS], a0[NSTEPS], a1[NSTEPS];
 #pragma unroll
   for (int j = 0; j < NSTEPS; ++j) {
-    bv[j] = (dbg & 256) ? 0.f : bp[nc_fo(j, ps)];   // 4 consecutive fragments of a lane are contiguous: vector loads
+    bv[j] = DDMI_ABL(dbg, 256) ? 0.f : bp[nc_fo(j, ps)];   // 4 consecutive fragments of a lane are contiguous: vector loads
     a0[j] = xp[j * xstride];
     a1[j] = xp[16 * NC_XS + j * xstride];
   }
-  if (!(dbg & 512)) {
+  if (!DDMI_ABL(dbg, 512)) {
 #pragma unroll
     for (int j = 0; j < NSTEPS; ++j) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bv[j], acc0, 0, 0, 0);
@@ -163,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restric
             if (n0 < n_live) { float* y = yg + (size_t)n0 * node_stride; y[p0] = a00[r]; y[p1] = a10[r]; y[p2] = a20[r]; y[p3] = a30[r]; }
             if (n0 + 16 < n_live) { float* y = yg + (size_t)(n0 + 16) * node_stride; y[p0] = a01[r]; y[p1] = a11[r]; y[p2] = a21[r]; y[p3] = a31[r]; }
           }
-        } else if (lr < U.n_w && !(dbg & 2048)) {
+        } else if (lr < U.n_w && !DDMI_ABL(dbg, 2048)) {
           float* __restrict__ yk = yp + (size_t)k * 64;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -272,7 +327,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
     for (int idx = tid; idx < EC_E * H4; idx += nthr) {
       const int el = idx / H4, k4 = idx - el * H4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (el < ne && !(a.dbg & 1)) {
+      if (el < ne && !DDMI_ABL(a.dbg, 1)) {
         const float4 x = nt_load4(a.HE + (size_t)ibuf[el * 3] * a.H + 4 * k4);
         const float4 p = *reinterpret_cast<const float4*>(a.P + (size_t)ibuf[el * 3 + 1] * a.H + 4 * k4);
         const float4 q = *reinterpret_cast<const float4*>(Qd + 4 * k4);
@@ -309,14 +364,14 @@ __global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
       const int nsteps = a.HKp >> 2;
       float4 cur[4], nxt[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) cur[j] = (j < nsteps && !(a.dbg & 2)) ? nt_load4(yp + (size_t)j * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < 4; ++j) cur[j] = (j < nsteps && !DDMI_ABL(a.dbg, 2)) ? nt_load4(yp + (size_t)j * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
       for (int s0 = 0; s0 < nsteps; s0 += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          nxt[j] = ((s0 + 4 + j) < nsteps && !(a.dbg & 2)) ? nt_load4(yp + (size_t)(s0 + 4 + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+          nxt[j] = ((s0 + 4 + j) < nsteps && !DDMI_ABL(a.dbg, 2)) ? nt_load4(yp + (size_t)(s0 + 4 + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (s0 + j >= nsteps || (a.dbg & 4)) break;
+          if (s0 + j >= nsteps || DDMI_ABL(a.dbg, 4)) break;
           const float4 b = cur[j];
           const float a0 = hp0[(s0 + j) * 4];
           acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc0[0], 0, 0, 0);
@@ -356,7 +411,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
       const bool writer = ob >= 0 && qi == 0;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        if ((rt == 1 && !two) || (a.dbg & 8)) break;
+        if ((rt == 1 && !two) || DDMI_ABL(a.dbg, 8)) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int el = rt * 16 + 4 * lq + r;
@@ -391,7 +446,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
     }
     __syncthreads();
     // ---- phase 3
-    for (int idx = tid; idx < ne * a.D_out && !(a.dbg & 16); idx += nthr) {
+    for (int idx = tid; idx < ne * a.D_out && !DDMI_ABL(a.dbg, 16); idx += nthr) {
       const int el = idx / a.D_out, c = idx - el * a.D_out;
       DDMI_NT_STORE(mbuf[el * MS + c], a.msg + (size_t)ibuf[el * 3 + 2] * XS + c);
     }
@@ -772,7 +827,7 @@ template <int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3>
 __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
                                                   int KS, int HK, int NG8, int wave, int lane,
                                                   const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr,
-                                                  const float* yrd) {
+                                                  const float* yrd, FcProf& pf) {
   // sparse rows (!DENSE): the second 16-row tile of a virtual node with <= 16 edges is neither fetched nor multiplied
   const bool two[2] = {DENSE || vne[0] > 16, DENSE || vne[1] > 16};
   using O = FcOrder<S0, SN, NLV>;
@@ -911,17 +966,26 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
 #pragma unroll
   for (int t = 0; t < 4; ++t) woff[t] += gstep;
   __syncthreads();
+  FC_STAMP(pf, 2);
   for (int g = 0; g + 2 < NG8; g += 2) {   // pairs with a successor pair
     step(T{}, T{}, T{}, Even{});
+    FC_STAMP_FINE(pf, 3);
     __syncthreads();
+    FC_STAMP_FINE(pf, 11);
     step(T{}, T{}, F{}, Odd{});
+    FC_STAMP_FINE(pf, 3);
     __syncthreads();
+    FC_STAMP_FINE(pf, 11);
     roll();
   }
   step(T{}, F{}, F{}, Even{});             // last pair: one contraction left, nothing to request
+  FC_STAMP_FINE(pf, 3);
   __syncthreads();
+  FC_STAMP_FINE(pf, 11);
   step(F{}, F{}, F{}, Odd{});
+  FC_STAMP_FINE(pf, 3);
   __syncthreads();
+  FC_STAMP(pf, 3 + 8 * (DDMI_PROF_FINE));
 }
 
 // Load mode (gather nodes with many edges each, e.g. ligand atoms towards all residues): the contracted rows come
@@ -1048,6 +1112,11 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   const int nvn = *a.nvn;
   const int v0 = blockIdx.x * FC_VN;
   if (v0 >= nvn) return;
+  FcProf pf;
+#ifdef DDMI_PROFILING
+  pf.start();
+  const unsigned pf_t0 = pf.t;
+#endif
   const int nv_live = min(FC_VN, nvn - v0);
   int* stab = reinterpret_cast<int*>(xbuf);
   if (MODE == 2) {
@@ -1082,7 +1151,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     const int n = g_end - g_begin;
     int n_units = 0;
     for (int u = 0; u < a.n_units; ++u) n_units += a.ustart[u] >= g_begin && a.ustart[u] < g_end;
-    const int want = (a.dbg & 2048) || n_units == 0 ? 0 : (int)(blockIdx.x % (unsigned)n_units);
+    const int want = DDMI_ABL(a.dbg, 2048) || n_units == 0 ? 0 : (int)(blockIdx.x % (unsigned)n_units);
     int start = 0;
     for (int u = 0, k = 0; u < a.n_units; ++u)
       if (a.ustart[u] >= g_begin && a.ustart[u] < g_end) { if (k == want) start = a.ustart[u] - g_begin; ++k; }
@@ -1140,7 +1209,9 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
   constexpr int NGR = MODE == 2 ? 2 : 1;   // granules per pass
+  FC_STAMP(pf, 0);
   for (int go = g_begin; go < g_end; go += NGR) {
+    FC_COUNT(pf, 14);
     const int gi = MODE == 2 ? go : gorder[go - g_begin];
     const FGran& Gd = gran_l[gi];
     f32x4 acc_all[2][2][2][4];
@@ -1180,7 +1251,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
               acc_all[u][vi][rt][2][r] += b2; acc_all[u][vi][rt][3][r] += b3;
             }
         }
-    } else if (!Gd.empty && !(a.dbg & 128)) {
+    } else if (!Gd.empty && !DDMI_ABL(a.dbg, 128)) {
       const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
@@ -1188,7 +1259,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       if (MODE == 0 || MODE == 3) {   // static chain shapes: hand-scheduled loop, dense (3) or sparse (0) rows
         constexpr bool DN = MODE == 3;
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
-#define FC_ML(S0_, SN_, DUP_, NLV_) fc_mainloop_dense<S0_, SN_, DN, DUP_, NLV_>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd)
+        FC_STAMP(pf, 1);
+#define FC_ML(S0_, SN_, DUP_, NLV_) fc_mainloop_dense<S0_, SN_, DN, DUP_, NLV_>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd, pf)
         int dup, nlv;
         fc_variant(Gd, dup, nlv);
         if (Gd.shape == 1 && dup == 1 && nlv == 3) FC_ML(12, 3, 1, 3);
@@ -1277,7 +1349,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       }
       }
       // ---- bias row (k = H, h = 1): waves 0..3 contract one slot each, every edge row receives the node's bias row
-      if (wave < 4 && !(a.dbg & 64)) {
+      if (wave < 4 && !DDMI_ABL(a.dbg, 64)) {
         const FcSlotRt& sb = wave == 0 ? s0 : wave == 1 ? s1 : wave == 2 ? s2 : s3;
         const f32x4 rb = fc_direct(sb, (size_t)H * a.KS);
         fc_store(ybuf + (4 * lq) * FC_YVN + lr, wave, rb);    // row 0 of buffer 0
@@ -1295,7 +1367,9 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
           }
       }
     }
+    FC_STAMP(pf, 4);
     __syncthreads();   // the coupling phase stages message rows in the (now idle) chunk buffers
+    FC_STAMP(pf, 5);
     // ---- coupling with the spherical harmonics and message stores (wave-local: no workgroup barrier)
 #pragma unroll
     for (int u = 0; u < NGR; ++u) {
@@ -1306,7 +1380,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi) {
       const int ne = vne[vi];
-      if (ne == 0 || (a.dbg & 32)) continue;
+      if (ne == 0 || DDMI_ABL(a.dbg, 32)) continue;
       const float* __restrict__ erow = ew_ + vi * 32 * ES;
       DDMI_WAVE_SYNC();
       {   // G[el][s][k'] = we_el * sum_j cg[s][k'][j] * sh_el[j] : lane = (edge row, slot pair); the edge weight rides along
@@ -1333,6 +1407,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         }
       }
       DDMI_WAVE_SYNC();
+      FC_STAMP(pf, 6);
       {
         float* stg = ybuf + wave * ((2 * FC_YB) / FC_WAVES);   // the chunk buffers are idle during the coupling phase
         const int RS = 16 * Gd.dout, L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
@@ -1365,7 +1440,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
             }
           }
           DDMI_WAVE_SYNC();
-          if (!(a.dbg & 256)) {
+          FC_STAMP(pf, 7);
+          if (!DDMI_ABL(a.dbg, 256)) {
             const int nrows = min(16, ne - 16 * rt);
             const float* __restrict__ er = erow + rt * 16 * ES;
             if (V == 4) fc_store_rows<4>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, Gd.accumulate, lane);
@@ -1373,12 +1449,23 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
             else fc_store_rows<1>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, Gd.accumulate, lane);
           }
           DDMI_WAVE_SYNC();
+          FC_STAMP(pf, 8);
         }
       }
     }
     }
+    FC_STAMP(pf, 7);
     __syncthreads();   // chunk buffers / coupling scratch are reused by the next granule
+    FC_STAMP(pf, 9);
   }
+#ifdef DDMI_PROFILING
+  pf.acc[10] = pf.t - pf_t0;
+  pf.acc[15] = 1;
+  if (lane == 0 && a.prof_slot >= 0 && a.prof_slot < FC_PROF_SLOTS) {
+#pragma unroll
+    for (int i = 0; i < FC_NPROF; ++i) atomicAdd(&g_fc_prof[a.prof_slot * FC_NPROF + i], (unsigned long long)pf.acc[i]);
+  }
+#endif
 }
 
 template <int MAXD, int SHD>

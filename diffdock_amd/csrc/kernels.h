@@ -128,7 +128,11 @@ struct FusedConvArgs {
   int n_units; short ustart[48];         // first granule of every (output block, w tile) unit: workgroups rotate their visiting order by units
   float* msg;                            // [E][XS]
   int dbg = 0;
+  int prof_slot = 0;                     // profiling builds: edge-group slot of the in-kernel phase clocks
 };
+#ifdef DDMI_PROFILING
+void fc_prof_report();                   // prints and clears the phase clocks of k_conv_fused (stderr)
+#endif
 void launch_conv_fused(const FusedConvArgs& a, hipStream_t s);
 
 struct ReduceGroup { const int* toff; const float* msg; int tbase, tcount; };
