@@ -81,7 +81,7 @@ def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr, fused=True, fused_lig=True):
     (DESIGN.md section 4).  NT = columns of a contracted node row (sum over paths of din*mul_out), K = 3ns + 1.
     Groups that run k_conv_fused keep the contracted rows in LDS: their HBM bytes are the x rows, the hidden rows and the
     messages, and their node term is counted once per gather NODE (the kernel repeats it per 32-edge virtual node of a
-    ligand atom -- that repetition is not algorithmic work).  With DDMI_FUSED_LIG < 3 the ligand-gather groups run
+    ligand atom -- that repetition is not algorithmic work).  With DDMI_FUSED_LIG=0 the ligand-gather groups run
     k_node_contract + k_edge_conv with the rows Y in HBM.  `ref_flops` = the same launch priced by SURVEY 8(d)'s formula
     for the REFERENCE's association (per edge 2*(3ns*3ns + 3ns*W) + 6W, W = weight_numel): the re-association removes
     13x of it, so a fraction of peak computed with it would exceed 1."""
@@ -275,7 +275,7 @@ def main():
         # edges actually processed by the last forward of the run, per complex
         edges, work = [], []
         fused = "k_conv_fused" in timings
-        fused_lig = "k_edge_conv" not in timings and "k_conv_fused_load" not in timings
+        fused_lig = "k_edge_conv" not in timings
         for j in jobs:
             m = j["model"]
             e_ll, e_lr, e_rr = int(m.debug_buffer("goff_ll")[-1]), int(m.debug_buffer("offs_l")[-1]), int(m.debug_buffer("rr_goff")[-1])

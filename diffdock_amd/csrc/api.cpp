@@ -31,6 +31,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     if (const char* e = getenv("DDMI_STREAMS")) h->m.two_streams = atoi(e) != 1;
     if (const char* e = getenv("DDMI_FUSED")) h->m.fused = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_LIG")) h->m.fused_lig = atoi(e);
+    if (const char* e = getenv("DDMI_FUSED_PACK")) h->m.fused_pack = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_DENSE")) h->m.fused_dense = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_YS")) h->m.fused_ysplit = std::max(0, atoi(e));
@@ -194,7 +195,7 @@ int ddmi_wigner_3j(int l1, int l2, int l3, double* out) {
 int ddmi_set_kernel_timing(ddmi_model* h, int enabled) {
   if (!h) return DDMI_ERR_ARG;
   resolve_timings(h->m);
-#ifdef DDMI_PROFILING
+#if defined(DDMI_PROFILING) && DDMI_PROFILING >= 2
   (void)hipDeviceSynchronize();
   ddmi::fc_prof_report();   // in-kernel phase clocks since the last call (profiling builds only)
 #endif

@@ -168,14 +168,11 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const int wg = std::min<int>((int)gi, L.G - 1);
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
-    // Ligand gather nodes (few nodes, many edges each).  fused_lig: 0 unfused (k_node_contract + k_edge_conv), 1 the fused
-    // kernel contracts per virtual node when a node carries >= 64 edges (several virtual nodes then repeat their node's
-    // contraction -- still cheaper than a round trip of the contracted rows through HBM), 2 load mode (rows from
-    // k_node_contract, shared by the node's virtual nodes), 3 fused for every such group.
-    const bool load_mode = g.load && m.fused_lig == 2;
-    const bool lig_ok = !g.load || m.fused_lig >= 2 || (m.fused_lig == 1 && g.ea_rows >= 64 * (long)g.gcount);
-    const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb && lig_ok &&
-                      (!load_mode || (c.y_chunk <= 0 && (size_t)g.gcount * L.n_fgran * L.HKp * 256 < 0xf0000000ull));   // 32-bit row offsets in the kernel
+    // Ligand gather nodes (few nodes, many edges each): the fused kernel contracts per 32-edge virtual node like every other
+    // group (several virtual nodes of an atom repeat its contraction -- cheaper than a round trip of the contracted rows
+    // through HBM); DDMI_FUSED_LIG=0 runs them unfused (k_node_contract + k_edge_conv).
+    const bool lig_ok = !g.load || m.fused_lig != 0;
+    const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb && lig_ok;
     float* Hb = side ? c.Hb_b : c.Hb;
     const bool fuse_mm = fuse && m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
     if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
@@ -204,7 +201,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       Cx::VnSet& vs = c.vn[g.vn];
       if (vs.built_goff != g.goff || vs.epoch != c.epoch) {
         PhaseTimer t(m, "vn_build", gs);
-        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, gs, load_mode ? 1 : 0);
+        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, gs);
         vs.built_goff = g.goff; vs.epoch = c.epoch;
       }
       const int* nvn = vs.voff + g.gcount;
@@ -216,7 +213,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         h.nvn = nvn; h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
         h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = L.W1p[wg]; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
         h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb;
-        h.zero_fill = (!L.fgran_generic && !load_mode && dense_rows) ? 1 : 0;
+        h.zero_fill = (!L.fgran_generic && dense_rows) ? 1 : 0;
         launch_edge_hidden_mm(h, gs);
       } else {
         PhaseTimer t(m, "k_edge_hidden", gs);
@@ -225,8 +222,8 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       FusedConvArgs f{};
       f.nvn = nvn; f.vcap = vs.vcap; f.vn_node = vs.node; f.vn_e0 = vs.e0; f.goff = g.goff; f.tslot = g.tslot; f.arow = g.arow;
       f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
-      f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.gmap = L.gmap;
-      f.ctab = L.ctab; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
+      f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.cgt = L.cgt;
+      f.max_nb = L.max_nb; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
       f.dense = dense_rows ? 1 : 0;
       f.prof_slot = (int)gi;
       // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
@@ -235,7 +232,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         const long est_tiles = std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16);
         ys_req = (int)std::min(6L, std::max(1L, 768 / est_tiles));   // (measured at 5 / 10 / 20 / 40 poses: beyond 6 the repeated prologues cost more than the extra workgroups bring)
       }
-      ys_req = std::max(ys_req, (L.n_fgran + 47) / 48);   // a workgroup keeps at most 64 granule descriptors in LDS
+      ys_req = std::max(ys_req, (L.n_fgran + 19) / 20);   // a workgroup keeps at most 24 granule descriptors in LDS
       const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
       f.ysplit = ys;
       f.gsplit[0] = 0;
@@ -248,17 +245,15 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       f.n_units = 0;
       for (int gq = 0; gq < L.n_fgran && f.n_units < 48; ++gq)
         if (gq == 0 || L.fgran_unit[gq] != L.fgran_unit[gq - 1]) f.ustart[f.n_units++] = (short)gq;
-      if (load_mode) {
-        {
-          PhaseTimer t(m, "k_node_contract", gs);
-          launch_node_contract(Xin, g.gbase, g.gcount, L.wpack[wg], L.nc_units, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, Y, gs, L.n_fgran);
-        }
-        f.Yg = Y; f.HKp = L.HKp; f.n_gran = L.n_fgran;
-      }
       static const bool per_group = getenv("DDMI_TIME_GROUPS") != nullptr;   // profiling: one timing row per edge group
-      const std::string tname = std::string(load_mode ? "k_conv_fused_load" : "k_conv_fused") + (per_group ? ":g" + std::to_string(gi) : "");
-      PhaseTimer t(m, tname.c_str(), gs);
-      launch_conv_fused(f, gs);
+      if (m.timing && per_group) {
+        const std::string tname = "k_conv_fused:g" + std::to_string(gi);
+        PhaseTimer t(m, tname.c_str(), gs);
+        launch_conv_fused(f, gs);
+      } else {
+        PhaseTimer t(m, "k_conv_fused", gs);
+        launch_conv_fused(f, gs);
+      }
       continue;
     }
     EdgeConvArgs a{};

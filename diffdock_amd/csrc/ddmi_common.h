@@ -32,7 +32,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DDMI_UNIFORM(x) (x)
 #define DDMI_SCHED_FENCE() ((void)0)
 #define DDMI_WAIT_VMEM() ((void)0)
+#define DDMI_ROW_XOR8(v) __shfl_xor((v), 8, 64)
+#define DDMI_OPAQUE(x) ((void)0)
 #else
+// the compiler may not assume anything about x past this point (keeps loop-invariant address arithmetic inside the loop)
+#define DDMI_OPAQUE(x) asm volatile("" : "+v"(x))
 // wave-uniform value -> scalar register
 #define DDMI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // LDS hand-off between lanes of ONE wave (lock-step on the hardware: order the ds ops, keep the compiler from moving them)
@@ -46,6 +50,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // every outstanding vector-memory request of the wave has completed (vmcnt(0); expcnt / lgkmcnt untouched) -- a real
 // S_WAITCNT, which the compiler's own wait-count insertion takes into account
 #define DDMI_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+// value of lane ^ 8 (the other half of the lane's row of 16): DPP row rotate by 8, no LDS traffic
+#define DDMI_ROW_XOR8(v) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), 0x128, 0xf, 0xf, false))
 #define DDMI_NT_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
 #define DDMI_NT_LOAD(ptr) __builtin_nontemporal_load((ptr))
 #endif

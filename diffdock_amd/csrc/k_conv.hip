@@ -40,6 +40,12 @@ constexpr int NC_NODES = 32, NC_KC = 15, NC_XS = XS + 1;
 #ifdef DDMI_PROFILING
 static int ablate_mask() { static int m = getenv("DDMI_ABLATE") ? atoi(getenv("DDMI_ABLATE")) : 0; return m; }
 #define DDMI_ABL(mask, bit) (((mask) & (bit)) != 0)
+#else
+static int ablate_mask() { return 0; }
+#define DDMI_ABL(mask, bit) false
+#endif
+#if defined(DDMI_PROFILING) && DDMI_PROFILING >= 2   // (the clocks cost registers: -DDDMI_PROFILING=1 builds carry the ablation hooks only)
+#define DDMI_PHASE_CLOCKS 1
 // per-wave phase clocks of k_conv_fused (s_memtime at the phase boundaries, summed per edge-group slot)
 constexpr int FC_NPROF = 16, FC_PROF_SLOTS = 12;
 __device__ unsigned long long g_fc_prof[FC_PROF_SLOTS * FC_NPROF];
@@ -59,7 +65,7 @@ struct FcProf {
 };
 #define FC_STAMP(pf, i) (pf).stamp(i)
 #define FC_COUNT(pf, i) ((pf).acc[i] += 1)
-#if DDMI_PROFILING >= 2   // also the barrier waits inside the main loop (two more clock reads per chunk: perturbs the loop)
+#if DDMI_PROFILING >= 3   // also the barrier waits inside the main loop (two more clock reads per chunk: perturbs the loop)
 #define FC_STAMP_FINE(pf, i) (pf).stamp(i)
 #define DDMI_PROF_FINE 1
 #else
@@ -83,8 +89,6 @@ void fc_prof_report() {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fc_prof), h, sizeof(h));
 }
 #else
-static int ablate_mask() { return 0; }
-#define DDMI_ABL(mask, bit) false
 struct FcProf {};
 #define FC_STAMP(pf, i) ((void)0)
 #define FC_STAMP_FINE(pf, i) ((void)0)
@@ -175,7 +179,7 @@ __device__ __forceinline__ void nc_slot(const NcSlotRt& R, size_t koff, f32x4& a
 __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
                                                        const float* __restrict__ wpack,
                                                        const NcUnit* __restrict__ units, int n_units, int KS, int HK,
-                                                       int HKp, int NTs, float* __restrict__ Y, int dbg, int n_gran, int kc) {
+                                                       int HKp, int NTs, float* __restrict__ Y, int dbg, int kc) {
   DDMI_DYN_SMEM(float, smem);
   float* xbuf = smem;                                   // [32][XS+1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,13 +193,12 @@ __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restric
   __syncthreads();
   const int lr = lane & 15, lq = lane >> 4;
   const int n_live = min(NC_NODES, gcount - node0);
-  const size_t node_stride = n_gran > 0 ? (size_t)n_gran * HKp * 64 : (size_t)n_super * HKp * 64;
+  const size_t node_stride = (size_t)n_super * HKp * 64;
   for (int it = wave; it < n_units; it += 4) {
     const NcUnit& U = units[it];
     if (U.n_w == 0) continue;
     const int col = U.col_base + (U.w0 + lr) * U.itemw;
     for (int q = 0; q < (U.itemw >> 2); ++q) {
-      if (n_gran > 0 && U.gran[q] < 0) continue;
       const NcSlotRt s0 = nc_slot_setup(U.slot[4 * q + 0], wpack, xbuf, U.w0, lr, lq);
       const NcSlotRt s1 = nc_slot_setup(U.slot[4 * q + 1], wpack, xbuf, U.w0, lr, lq);
       const NcSlotRt s2 = nc_slot_setup(U.slot[4 * q + 2], wpack, xbuf, U.w0, lr, lq);
@@ -209,16 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restric
         nc_slot(s1, koff, a10, a11, dbg);
         nc_slot(s2, koff, a20, a21, dbg);
         nc_slot(s3, koff, a30, a31, dbg);
-        if (n_gran > 0) {   // granule-major rows: column 16 * (slot position) + w, all 16 lanes (padding w are zero-weight columns)
-          float* __restrict__ yg = Y + (size_t)node0 * node_stride + ((size_t)U.gran[q] * HKp + k) * 64 + lr;
-          const int p0 = 16 * U.perm[4 * q], p1 = 16 * U.perm[4 * q + 1], p2 = 16 * U.perm[4 * q + 2], p3 = 16 * U.perm[4 * q + 3];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int n0 = 4 * lq + r;
-            if (n0 < n_live) { float* y = yg + (size_t)n0 * node_stride; y[p0] = a00[r]; y[p1] = a10[r]; y[p2] = a20[r]; y[p3] = a30[r]; }
-            if (n0 + 16 < n_live) { float* y = yg + (size_t)(n0 + 16) * node_stride; y[p0] = a01[r]; y[p1] = a11[r]; y[p2] = a21[r]; y[p3] = a31[r]; }
-          }
-        } else if (lr < U.n_w && !DDMI_ABL(dbg, 2048)) {
+        if (lr < U.n_w && !DDMI_ABL(dbg, 2048)) {
           float* __restrict__ yk = yp + (size_t)k * 64;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -233,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restric
 }
 
 void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcUnit* units, int n_units,
-                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s, int n_gran) {
+                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s) {
   if (gcount <= 0 || n_units <= 0) return;
   const size_t smem = (size_t)(NC_NODES * NC_XS) * sizeof(float);
   // k rows per workgroup: 15 for large node sets (each x tile is read HK/15 times); fewer for small ones (ligand atoms), so
@@ -242,7 +236,7 @@ void launch_node_contract(const float* X, int gbase, int gcount, const float* wp
   while (kc > 3 && (long)cdiv(gcount, NC_NODES) * cdiv(HK, kc) < 1500) kc -= 2;
   dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, kc));
   hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, units, n_units, KS, HK, HKp, NTs, Y,
-                     ablate_mask(), n_gran, kc);
+                     ablate_mask(), kc);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -470,23 +464,21 @@ void launch_edge_conv(const EdgeConvArgs& a_in, hipStream_t s) {
 
 // ------------------------------------------------------------------ fused contraction + edge kernel
 // Virtual nodes: gather node d with edges [goff[d], goff[d+1]) becomes ceil(deg/32) entries (d, first edge).
-__global__ void k_vn_count(const int* __restrict__ goff, int gcount, int pad_even, int* __restrict__ cnt) {
+__global__ void k_vn_count(const int* __restrict__ goff, int gcount, int* __restrict__ cnt) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= gcount) return;
-  int n = (goff[d + 1] - goff[d] + 31) >> 5;
-  if (pad_even) n = (n + 1) & ~1;   // load mode: a node starts on an even slot, so a 16-entry tile spans <= 8 nodes
-  cnt[d] = n;
+  cnt[d] = (goff[d + 1] - goff[d] + 31) >> 5;
 }
 __global__ void k_vn_fill(const int* __restrict__ goff, const int* __restrict__ voff, int gcount, int* __restrict__ vn_node,
                           int* __restrict__ vn_e0) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= gcount) return;
   const int v0 = voff[d], n = voff[d + 1] - v0, e0 = goff[d], e1 = goff[d + 1];
-  for (int b = 0; b < n; ++b) { vn_node[v0 + b] = d; vn_e0[v0 + b] = min(e0 + 32 * b, e1); }   // padding entry: no edges
+  for (int b = 0; b < n; ++b) { vn_node[v0 + b] = d; vn_e0[v0 + b] = min(e0 + 32 * b, e1); }
 }
-void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s, int pad_even) {
+void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s) {
   if (gcount <= 0) return;
-  hipLaunchKernelGGL(k_vn_count, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, gcount, pad_even, cnt_tmp);
+  hipLaunchKernelGGL(k_vn_count, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, gcount, cnt_tmp);
   launch_exclusive_scan(cnt_tmp, voff, gcount, s);
   hipLaunchKernelGGL(k_vn_fill, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, voff, gcount, vn_node, vn_e0);
   DDMI_CHECK_HIP(hipGetLastError());
@@ -648,10 +640,14 @@ void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {
 
 constexpr int FC_VN = 16, FC_KC = 8, FC_WAVES = 8, FC_CAP0 = 12, FC_CAPN = 4;
 constexpr int FC_GWORDS = sizeof(FGran) / 4;   // granule descriptor, in 32-bit words
-constexpr int FC_MAXG = 64;                    // granule descriptors kept in LDS per workgroup (launches split larger ranges)
-// chunk buffer in LDS: [16 nodes][8 rows][64 columns], column = 16*slot + w; padded strides keep the transposing stores
+constexpr int FC_MAXG = 24;                    // granule descriptors kept in LDS per workgroup (launches split larger ranges)
+// chunk buffer in LDS: [16 nodes][8 rows][16 * NBK columns] (NBK = column blocks of the widest granule of the launch: 4, or 5
+// with a packed 7-slot granule); classic granules: column = 16*slot + w.  The padded strides keep the transposing stores
 // (lanes = 16 w x 4 node quarters) and the B-fragment loads (lanes = 16 w x rows 2q + sub) on 64 distinct banks
-constexpr int FC_YROW = 72, FC_YVN = FC_KC * FC_YROW + 4, FC_YB = FC_VN * FC_YVN;
+// (YROW = 8 mod 16, YVN = 4 mod 8).
+template <int NBK> struct FcDim {
+  static constexpr int YROW = 16 * NBK + 8, YVN = FC_KC * YROW + 4, YB = FC_VN * YVN;
+};
 
 // k-invariant per-lane part of one slot chain: uniform weight base + 32-bit lane offset (scalar-base global loads)
 struct FcSlotRt { const float* wb; const float* xp; int loff, xstride, steps, ps; };
@@ -723,9 +719,10 @@ __device__ __forceinline__ f32x4 fc_direct(const FcSlotRt& R, size_t koff) {   /
   return acc;
 }
 // transposing store of one chain result: lane (lr, lq) holds nodes 4lq .. 4lq+3 of column (slot, w = lr)
-__device__ __forceinline__ void fc_store(float* yw, int slot, const f32x4& v) {
+template <int NBK>
+__device__ __forceinline__ void fc_store(float* yw, int col, const f32x4& v) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) yw[r * FC_YVN + 16 * slot] = v[r];
+  for (int r = 0; r < 4; ++r) yw[r * FcDim<NBK>::YVN + col] = v[r];
 }
 
 // Message columns of 16 edge rows, staged row-major in LDS ([16][RS]), streamed to their message rows with V-float
@@ -823,11 +820,12 @@ struct FcOrder {   // issue order of the slot chains: slot 0 alternating with th
 };
 // DUP: slots sharing one set of weight fragments (FGran::dup): they are requested once and feed several chains.
 // NLV: live slots among 1..3 (FGran::nlive; padding slots trail): a padding slot is neither contracted nor multiplied.
-template <int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3>
-__device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
+template <int NBK, int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3>
+__device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
                                                   int KS, int HK, int NG8, int wave, int lane,
                                                   const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr,
                                                   const float* yrd, FcProf& pf) {
+  constexpr int FC_YROW = FcDim<NBK>::YROW, FC_YVN = FcDim<NBK>::YVN, FC_YB = FcDim<NBK>::YB;
   // sparse rows (!DENSE): the second 16-row tile of a virtual node with <= 16 edges is neither fetched nor multiplied
   const bool two[2] = {DENSE || vne[0] > 16, DENSE || vne[1] > 16};
   using O = FcOrder<S0, SN, NLV>;
@@ -891,6 +889,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
     if (2 * h < NCB) yw[rr * FC_YVN + 16 * (2 * h)] = r[2 * h][rr];
     if (2 * h + 1 < NCB) yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
   };
+  static_assert(NCB <= NBK, "column blocks of the granule exceed the chunk buffer");
   // one chunk step (chunk g = 2 * pair + ODD): contraction of chunk g+1 into buffer ODD ^ 1 (DO_C), weight requests for
   // chunk g+2 (DO_W), hidden rows of the next pair of chunks (DO_H), edge product of chunk g out of buffer ODD
   auto step = [&](auto do_c, auto do_w, auto do_h, auto odd) __attribute__((always_inline)) {
@@ -988,100 +987,219 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][4], const F
   FC_STAMP(pf, 3 + 8 * (DDMI_PROF_FINE));
 }
 
-// Load mode (gather nodes with many edges each, e.g. ligand atoms towards all residues): the contracted rows come
-// precomputed from k_node_contract (granule-major), one copy per DISTINCT gather node of the tile (slot table stab:
-// [0,8) node of slot, [16,32) slot of virtual node, [32] slot count; the virtual-node list pads every node to an even
-// count, so a tile holds <= 8 nodes).  No contraction registers are needed here, so TWO granules (128 columns) are
-// multiplied per pass and the hidden rows -- the dominant HBM stream of this mode -- are read half as often.
-// Chunk buffer: [granule 2][slot 8] row blocks.  Same pipeline: rows of group g+2 are requested while group g is multiplied.
-__device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const float* __restrict__ yg, size_t gran_stride,
-                                                 size_t node_stride, int ng, const int* stab, int NG8,
-                                                 const float* __restrict__ hb_tile, int wave, int lane, const int (&vne)[2],
-                                                 const int (&vslot)[2], float* ybuf, int tid, int lr, int lq) {
-  const int nslots = stab[32];
-  const int lu = tid >> 8, ls = (tid >> 7) & 1, row = (tid >> 4) & 7, c4 = tid & 15;
-  const FcBuf ybuf_g = fc_buf(yg, 0xfffffff0u);   // uniform base + 32-bit lane offsets (the host keeps the rows below 4 GB)
-  unsigned src[4];
-  bool on[4];
+// ---- packed granules (kernels.h, FGran): slots = [a 12-step chain (S0 = 12) or none (S0 = 0)] + NG groups of three 3-step
+// chains, the three sharing one set of weight fragments (components of one vector path).  Column of (slot s, channel w):
+// w < 8: 8*s + w (two slots per 16-column block), w = 8, 9: 16*(NB - 1) + 2*s + w - 8 (tail block), NB = ceil(NS / 2) + 1.
+// k-invariant per-lane part of a packed granule: x fragments of the long chain at xp0[4 * step], of group g, component i
+// at xg[g][i + 12 * step]; packed weights of request source t (0 = long chain, 1 + g = group g) at wk[t] (uniform) + loff[t]
+struct FcPackRt { const float* xp0; const float* xg[2]; int wk[3], loff[3]; };
+__device__ __forceinline__ FcPackRt fc_pack_setup(const FGran& G, const float* __restrict__ xbuf, int lr, int lq) {
+  FcPackRt P;
+  const int c0 = G.shape == 5 ? 0 : 1, ng = G.shape == 6 ? 1 : 2;
+  const NcSlot& S0_ = G.slot[0];
+  P.xp0 = xbuf + lr * NC_XS + S0_.x_off + lq;
+  P.wk[0] = S0_.wk_off; P.loff[0] = nc_lane_off(S0_, 0, lr, lq);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    on[p] = 2 * p + ls < nslots && lu < ng;
-    src[p] = (unsigned)((on[p] ? (size_t)lu * gran_stride + (size_t)stab[2 * p + ls] * node_stride : 0) + row * 64 + 4 * c4) * 4u;
+  for (int g = 0; g < 2; ++g) {
+    const NcSlot& S = G.slot[g < ng ? c0 + 3 * g : 0];
+    P.xg[g] = xbuf + lr * NC_XS + S.x_off + 3 * lq;
+    P.wk[1 + g] = S.wk_off; P.loff[1 + g] = nc_lane_off(S, 0, lr, lq);
   }
-  float* dst = ybuf + (lu * 8 + ls) * FC_YVN + row * FC_YROW + 4 * c4;
-  float4 yq[4];
-#define FC_FETCHY(g)                                                                      \
-  do {                                                                                    \
-    _Pragma("unroll") for (int p = 0; p < 4; ++p) if (on[p]) yq[p] = fc_buf_ld4(ybuf_g, src[p], (unsigned)(g) * 2048u); \
-  } while (0)
-#define FC_STOREY(buf)                                                                    \
-  do {                                                                                    \
-    _Pragma("unroll") for (int p = 0; p < 4; ++p)                                         \
-      if (on[p]) *reinterpret_cast<float4*>(dst + (buf) * FC_YB + 2 * p * FC_YVN) = yq[p]; \
-  } while (0)
-  float4 hC[2][2], hN[2][2];   // hidden-row fragments of the current / next pair of 8-k groups
-  const bool two0 = vne[0] > 16, two1 = vne[1] > 16;
-  const unsigned rts = (unsigned)fc_ngp(NG8) * 1024u;                    // bytes per (virtual node, row tile)
+  return P;
+}
+template <int S0, int NG>
+struct FcPackOrder {   // issue order of the contraction: the 12-step chain spread evenly between the short chains, which run
+                       // group after group (step-major inside a group: dependent MFMAs >= 3 apart), so that a group's results
+                       // can leave for the chunk buffer while the next group is still being contracted
+  static constexpr int N3 = 9 * NG, NC = S0 + N3, C0 = S0 > 0 ? 1 : 0;
+  static constexpr bool is_c0(int i) {   // position i carries a step of the long chain
+    if (S0 == 0) return false;
+    for (int k = 0; k < S0; ++k) if (k * NC / S0 == i) return true;
+    return false;
+  }
+  static constexpr int rank(int i, bool c0) { int n = 0; for (int j = 0; j < i; ++j) n += is_c0(j) == c0; return n; }
+  static constexpr int slot(int i) { return is_c0(i) ? 0 : C0 + 3 * (rank(i, false) / 9) + rank(i, false) % 3; }
+  static constexpr int step(int i) { return is_c0(i) ? rank(i, true) : (rank(i, false) % 9) / 3; }
+  static constexpr int last_pos(int t) { int p = 0; for (int i = 0; i < NC; ++i) if (slot(i) == t) p = i; return p; }   // position of slot t's last step
+};
+template <int NBK, int S0, int NG, bool DENSE>
+__device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], const FcPackRt& P, const float* __restrict__ wpack,
+                                                   int KS, int HK, int NG8, int wave, int lane,
+                                                   const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr0,
+                                                   const float* yrd, FcProf& pf) {
+  constexpr int FC_YROW = FcDim<NBK>::YROW, FC_YVN = FcDim<NBK>::YVN, FC_YB = FcDim<NBK>::YB;
+  using O = FcPackOrder<S0, NG>;
+  constexpr int C0 = O::C0, NS = C0 + 3 * NG, NB = (NS + 1) / 2 + 1, NC = O::NC;
+  static_assert(NB <= NBK, "column blocks of the granule exceed the chunk buffer");
+  static_assert(S0 == 0 || S0 == 12, "the long chain has 12 steps");
+  const bool two[2] = {DENSE || vne[0] > 16, DENSE || vne[1] > 16};
+  const int lr = lane & 15;
+  // column of this lane's channel in slot s: cb + cs * s (channels >= 10 do not exist: those lanes store into the row padding)
+  const int cb = lr < 8 ? lr : lr < 10 ? 16 * (NB - 1) + lr - 8 : 16 * NBK + lr - 10;
+  const int cs = lr < 8 ? 8 : lr < 10 ? 2 : 0;
+  float* const ywr = ywr0 + cb;
+  // x fragments: the long chain's stay in registers; the short chains' are re-read from the (read-only) x tile in LDS a few
+  // MFMAs ahead of their use -- 18 registers less than keeping them, for one LDS read per short-chain MFMA
+  constexpr int XW = 5;          // read-ahead distance of the window, in contraction positions
+  float xa0[S0 > 0 ? S0 : 1], xw[NC];
+  if constexpr (S0 > 0) {
+#pragma unroll
+    for (int j = 0; j < S0; ++j) xa0[j] = P.xp0[4 * j];                    // scalar input: u = 4 * step + lane / 16
+  }
+  auto xread = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < NC && !O::is_c0(i < NC ? i : 0)) {
+      constexpr int t = O::slot(i) - C0;                                     // component t % 3 of group t / 3, vector input (3 floats per u)
+      xw[i] = P.xg[t / 3][t % 3 + 12 * O::step(i)];
+    }
+  };
+  float bw0[S0 > 0 ? S0 : 1], bwg[NG][3];   // weight fragments: the long chain, one 3-step set per group
+  unsigned woff[1 + NG], lo[1 + NG];        // uniform byte offset of row k = 8g + wave / per-lane byte offset, per request source
+#pragma unroll
+  for (int t = 0; t < 1 + NG; ++t) {
+    woff[t] = (unsigned)DDMI_UNIFORM(P.wk[t] + wave * KS) * 4u;
+    lo[t] = (unsigned)P.loff[t] * 4u;
+  }
+  const unsigned gstep = 32u * (unsigned)KS;
+  const FcBuf wbuf = fc_buf(wpack, (unsigned)HK * (unsigned)KS * 4u);
+  constexpr int NL0 = S0 / 4, NL = NL0 + NG;
+  auto loadw = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < NL0) {
+      const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0]);
+      bw0[4 * i] = v.x; bw0[4 * i + 1] = v.y; bw0[4 * i + 2] = v.z; bw0[4 * i + 3] = v.w;
+    } else {
+      constexpr int g = i - NL0;
+      const float3 v = fc_buf_ld3(wbuf, lo[1 + g], woff[1 + g]);
+      bwg[g][0] = v.x; bwg[g][1] = v.y; bwg[g][2] = v.z;
+    }
+  };
+  float4 hC[2][2], hN[2][2];
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) hC[pc >> 1][pc & 1] = hN[pc >> 1][pc & 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned rts = (unsigned)(NG8 >> 1) * 1024u;
   const FcBuf hbuf = fc_buf(hb_tile, (unsigned)FC_VN * 2u * rts);
   unsigned hoff = (unsigned)(2 * wave) * 2u * rts;
   const unsigned hlane = (unsigned)lane * 16u;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define FC_LOADH(dst_)                                                                   \
-  do {                                                                                   \
-    dst_[0][0] = fc_buf_ld4(hbuf, hlane, hoff);                                          \
-    dst_[0][1] = two0 ? fc_buf_ld4(hbuf, hlane, hoff + rts) : z4;                        \
-    dst_[1][0] = fc_buf_ld4(hbuf, hlane, hoff + 2u * rts);                               \
-    dst_[1][1] = two1 ? fc_buf_ld4(hbuf, hlane, hoff + 3u * rts) : z4;                   \
-    hoff += 1024u;                                                                       \
-  } while (0)
-#define FC_LOAD_STEP(g_, ODD_)                                                           \
-  do {                                                                                   \
-    if ((g_) + 1 < NG8) {                                                                \
-      FC_STOREY(((g_) + 1) & 1);                                                         \
-      if ((g_) + 2 < NG8) FC_FETCHY((g_) + 2);                                           \
-      if (!(ODD_) && (g_) + 2 < NG8) FC_LOADH(hN);                                       \
-    }                                                                                    \
-    const float* __restrict__ yb0 = ybuf + ((g_) & 1) * FC_YB + (2 * lq) * FC_YROW + lr; \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                      \
-      if (u >= ng) break;                                                                \
-      _Pragma("unroll") for (int vi = 0; vi < 2; ++vi) {                                 \
-        _Pragma("unroll") for (int sub = 0; sub < 2; ++sub) {                            \
-          const float* __restrict__ yb = yb0 + (u * 8 + vslot[vi]) * FC_YVN + sub * FC_YROW; \
-          const float q0 = yb[0], q1 = yb[16], q2 = yb[32], q3 = yb[48];                 \
-          const float a0 = (ODD_) ? (sub == 0 ? hC[vi][0].z : hC[vi][0].w) : (sub == 0 ? hC[vi][0].x : hC[vi][0].y); \
-          acc[u][vi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q0, acc[u][vi][0][0], 0, 0, 0); \
-          acc[u][vi][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q1, acc[u][vi][0][1], 0, 0, 0); \
-          acc[u][vi][0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q2, acc[u][vi][0][2], 0, 0, 0); \
-          acc[u][vi][0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, q3, acc[u][vi][0][3], 0, 0, 0); \
-          if (vi == 0 ? two0 : two1) {                                                   \
-            const float a1 = (ODD_) ? (sub == 0 ? hC[vi][1].z : hC[vi][1].w) : (sub == 0 ? hC[vi][1].x : hC[vi][1].y); \
-            acc[u][vi][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q0, acc[u][vi][1][0], 0, 0, 0); \
-            acc[u][vi][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q1, acc[u][vi][1][1], 0, 0, 0); \
-            acc[u][vi][1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q2, acc[u][vi][1][2], 0, 0, 0); \
-            acc[u][vi][1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, q3, acc[u][vi][1][3], 0, 0, 0); \
-          }                                                                              \
-        }                                                                                \
-      }                                                                                  \
-    }                                                                                    \
-    __syncthreads();                                                                     \
-  } while (0)
-  FC_FETCHY(0);
-  FC_LOADH(hC);
-  FC_STOREY(0);
-  if (NG8 > 1) FC_FETCHY(1);
-  __syncthreads();
-  for (int g = 0; g < NG8; g += 2) {
-    FC_LOAD_STEP(g, 0);
-    if (g + 1 < NG8) FC_LOAD_STEP(g + 1, 1);
+  auto loadh = [&](float4 (&dst)[2][2], int piece) __attribute__((always_inline)) {
+    if (DENSE || !(piece & 1) || two[piece >> 1]) dst[piece >> 1][piece & 1] = fc_buf_ld4(hbuf, hlane, hoff + (unsigned)piece * rts);
+  };
+  f32x4 r[NS];
+  // results leave for the chunk buffer as soon as their chain is complete: the slots finished >= 12 positions before the
+  // end of the contraction (first group when there are two) during the contraction itself, the rest during the edge product
+  constexpr int NEARLY = (NG == 2) ? 3 : 0;                      // slots C0 .. C0 + 2 (group 0)
+  constexpr int EARLY0 = NEARLY ? O::last_pos(C0 + 2) + 2 : NC;  // first contraction position that carries an early store
+  constexpr int EPP = NEARLY ? (4 * NEARLY + (NC - EARLY0) - 1) / (NC - EARLY0) : 1;   // early stores per contraction position
+  static_assert(NEARLY == 0 || (EARLY0 < NC && EPP <= 2), "early stores fit behind their chains");
+  constexpr int NE = 8 * NB, NP = 4 * (NS - NEARLY);
+  static_assert(NE >= 2 * NL + 8 && NE >= NP + 2, "edge-product slots for the requests and the row stores");
+  float q[2][NB];
+  auto readq = [&](int par, int buf, int grp) __attribute__((always_inline)) {
+    const float* __restrict__ yb = yrd + buf * FC_YB + (grp >> 1) * FC_YVN + (grp & 1) * FC_YROW;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) q[par][c] = yb[16 * c];
+  };
+  auto store_slot = [&](int buf, int s_, int rr) __attribute__((always_inline)) {   // node quarter rr of slot s_
+    ywr[buf * FC_YB + rr * FC_YVN + cs * s_] = r[s_][rr];
+  };
+  // late stores: slot 0 (long chain) and the slots behind the early ones
+  auto late_slot = [](int piece) constexpr { const int k = piece >> 2; return (C0 && k == 0) ? 0 : C0 + NEARLY + (k - C0); };
+  auto contract = [&](auto ic, int buf, bool stores) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int t = O::slot(i), j = O::step(i);
+    xread(std::integral_constant<int, i + XW>{});
+    float b, x;
+    if constexpr (C0 == 1 && t == 0) { b = bw0[j]; x = xa0[j]; } else { b = bwg[(t - C0) / 3][j]; x = xw[i]; }
+    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b, r[t], 0, 0, 0);
+    if constexpr (NEARLY > 0 && i >= EARLY0) {
+      if (stores) {
+#pragma unroll
+        for (int e = EPP * (i - EARLY0); e < EPP * (i - EARLY0 + 1); ++e)
+          if (e < 4 * NEARLY) store_slot(buf, C0 + e / 4, e % 4);
+      }
+    }
+  };
+  auto step = [&](auto do_c, auto do_w, auto do_h, auto odd) __attribute__((always_inline)) {
+    constexpr bool DO_C = decltype(do_c)::value, DO_W = decltype(do_w)::value, DO_H = decltype(do_h)::value;
+    constexpr int ODD = decltype(odd)::value, eb = ODD, cb_ = ODD ^ 1;
+    if constexpr (DO_C) {
+#pragma unroll
+      for (int t = 0; t < NS; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      fc_sfor<0, NC>([&](auto ic) {
+        contract(ic, cb_, true);
+        if (decltype(ic)::value == NC - 3) readq(0, eb, 0);
+        DDMI_SCHED_FENCE();
+      });
+    } else {
+      readq(0, eb, 0);
+    }
+    fc_sfor<0, NE>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int grp = m / (2 * NB), t8 = m % (2 * NB), vi = grp >> 1, sub = grp & 1, rt = t8 / NB, c = t8 % NB;
+      if (DENSE || rt == 0 || two[vi]) {
+        const float av = ODD ? (sub == 0 ? hC[vi][rt].z : hC[vi][rt].w) : (sub == 0 ? hC[vi][rt].x : hC[vi][rt].y);
+        acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
+      }
+      if constexpr (DO_W) { if constexpr (m % 2 == 0 && m / 2 < NL) loadw(std::integral_constant<int, m / 2>{}); }
+      if constexpr (DO_H) {   // (after this step's weight requests: vmcnt retires in order)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (m == 2 * NL - 1 + 2 * j) loadh(hN, j);
+      }
+      if constexpr (DO_C) { if constexpr (m >= 2 && m < 2 + NP) store_slot(cb_, late_slot(m - 2), (m - 2) & 3); }
+      if constexpr (DO_C && m >= NE - XW) xread(std::integral_constant<int, m - (NE - XW)>{});   // window of the next contraction (x tile: read-only)
+      if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
+      DDMI_SCHED_FENCE();
+    });
+    if constexpr (DO_W) {
+#pragma unroll
+      for (int t = 0; t < 1 + NG; ++t) woff[t] += gstep;
+    }
+    if constexpr (DO_H) hoff += 1024u;
+  };
+  auto roll = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using Even = std::integral_constant<int, 0>;
+  using Odd = std::integral_constant<int, 1>;
+  // prologue: chunk 0 contracted, chunk 1 requested
+  fc_sfor<0, NL>(loadw);
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
+#pragma unroll
+  for (int t = 0; t < 1 + NG; ++t) woff[t] += gstep;
+  hoff += 1024u;
+#pragma unroll
+  for (int t = 0; t < NS; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fc_sfor<0, XW>(xread);
+  fc_sfor<0, NC>([&](auto ic) { contract(ic, 0, false); });
+#pragma unroll
+  for (int t = 0; t < NS; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) store_slot(0, t, rr);
+  fc_sfor<0, NL>(loadw);
+#pragma unroll
+  for (int t = 0; t < 1 + NG; ++t) woff[t] += gstep;
+  fc_sfor<0, XW>(xread);   // window of the first in-loop contraction
+  __syncthreads();
+  FC_STAMP(pf, 2);
+  for (int g = 0; g + 2 < NG8; g += 2) {
+    step(T{}, T{}, T{}, Even{});
+    __syncthreads();
+    step(T{}, T{}, F{}, Odd{});
+    __syncthreads();
+    roll();
   }
-#undef FC_LOAD_STEP
-#undef FC_FETCHY
-#undef FC_STOREY
-#undef FC_LOADH
+  step(T{}, F{}, F{}, Even{});
+  __syncthreads();
+  step(F{}, F{}, F{}, Odd{});
+  __syncthreads();
+  FC_STAMP(pf, 3);
 }
 
 // Workgroup = 16 virtual nodes x the granules [gsplit[y], gsplit[y+1]), 8 waves: wave w owns virtual nodes 2w, 2w+1 in the
@@ -1089,23 +1207,29 @@ __device__ __forceinline__ void fc_mainloop_load(f32x4 (&acc)[2][2][2][4], const
 // a PAIR of groups (k = 8g + 2q + sub, g = 2p, 2p + 1) are one 16-B request of the fragment-ordered hidden rows.  The
 // contracted group is double-buffered in LDS; per iteration a wave contracts row w of group g+1 (weights requested one
 // iteration earlier), requests the weights of group g+2 and -- every second iteration -- the hidden fragments of the next
-// pair, and multiplies group g into its edge accumulators: one barrier per 8 k (fc_mainloop_dense).  The bias row of the
-// packed second layer (h = 1) is added outside the MFMA loop; the epilogue of a granule couples the accumulators with sh_e
-// and streams the message columns out through an LDS staging area (wave-local).
+// pair, and multiplies group g into its edge accumulators: one barrier per 8 k (fc_mainloop_dense / fc_mainloop_packed).  The
+// bias row of the packed second layer (h = 1) is added outside the MFMA loop; the epilogue of a granule couples the
+// accumulators with sh_e, 16 edge rows at a time, and streams the message columns out through an LDS staging area
+// (wave-local).
 // MODE 0: static chain shapes, sparse rows (the second 16-edge tile of a virtual node with <= 16 edges is skipped),
-// 1: generic (predicated, compiler-scheduled) contraction, 2: load mode (rows from k_node_contract, two granules per pass),
-// 3: static shapes, dense rows (both row tiles of every virtual node are multiplied: straight-line chunk body)
-template <int MAXD, int SHD, int MODE>
+// 1: generic (predicated, compiler-scheduled) contraction of classic granules, 3: static shapes, dense rows (both row tiles of
+// every virtual node are multiplied: straight-line chunk body).  NBK = column blocks of the chunk buffer (widest granule).
+template <int MAXD, int SHD, int MODE, int NBK>
 __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
-  constexpr int GS2 = 4 * MAXD + 8, ES = SHD == 4 ? 8 : SHD + 3, CGN = 4 * MAXD * SHD;   // ES: edge-row stride (sh, weight, message row); 8 keeps 4 harmonics one 16-B read
+  using D = FcDim<NBK>;
+  constexpr int FC_YROW = D::YROW, FC_YVN = D::YVN, FC_YB = D::YB;
+  constexpr bool PACK = MODE != 1 && MAXD == 3 && SHD == 4;   // packed granules exist only with the static l <= 1 shapes
+  // GS2: coupling row of one edge: classic [k'][4 slots]; packed [k'][even slots 0,2,4,6 | odd slots 1,3,5,7]
+  // (row strides 20 / 36: the 16 rows written per request land on 8 distinct bank groups)
+  constexpr int GS2 = PACK ? 8 * MAXD + 12 : 4 * MAXD + 8, ES = SHD == 4 ? 8 : SHD + 3, CGN = FC_MAXSLOT * MAXD * SHD;   // ES: edge-row stride (sh, weight, message row); 8 keeps 4 harmonics one 16-B read
   float* xbuf = smem;                                  // [16][XS+1]
   float* ybuf = xbuf + FC_VN * NC_XS;                  // [2][16 x FC_YVN]
-  float* gscr = ybuf + 2 * FC_YB;                      // per wave: [32 edge rows][MAXD][4 slots] (+8 pad) coupling rows of the current (granule, virtual node)
-  float* escr = gscr + FC_WAVES * 32 * GS2;            // per wave: [2][32][ES] edge rows: sh (SHD), weight, message row
+  float* gscr = ybuf + 2 * FC_YB;                      // per wave: [16 edge rows][GS2] coupling rows of the current (granule, virtual node, row tile)
+  float* escr = gscr + FC_WAVES * 16 * GS2;            // per wave: [2][32][ES] edge rows: sh (SHD), weight, message row
   int* gdesc = reinterpret_cast<int*>(escr + FC_WAVES * 2 * 32 * ES);   // [granules of this workgroup] FGran copies (see below)
   int* gorder = gdesc + FC_MAXG * FC_GWORDS;            // [granules of this workgroup] visiting order (rotated per workgroup, see below)
-  float* cgt = reinterpret_cast<float*>(gorder + FC_MAXG);   // [granules of this workgroup][4 slots][MAXD][SHD] dense coupling rows
+  float* cgt = reinterpret_cast<float*>(gorder + FC_MAXG);   // [granules of this workgroup][8 slots][MAXD][SHD] dense coupling rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = DDMI_UNIFORM(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -1113,29 +1237,14 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   const int v0 = blockIdx.x * FC_VN;
   if (v0 >= nvn) return;
   FcProf pf;
-#ifdef DDMI_PROFILING
+#ifdef DDMI_PHASE_CLOCKS
   pf.start();
   const unsigned pf_t0 = pf.t;
 #endif
   const int nv_live = min(FC_VN, nvn - v0);
-  int* stab = reinterpret_cast<int*>(xbuf);
-  if (MODE == 2) {
-    if (tid == 0) {   // distinct gather nodes of the tile (virtual nodes are sorted by node)
-      int ns_ = 0, prev = -1;
-      for (int i = 0; i < FC_VN; ++i) {
-        if (i < nv_live) {
-          const int node = a.vn_node[v0 + i];
-          if (node != prev && ns_ < 8) { stab[ns_++] = node; prev = node; }
-        }
-        stab[16 + i] = ns_ > 0 ? ns_ - 1 : 0;
-      }
-      stab[32] = ns_;
-    }
-  } else {
-    for (int idx = tid; idx < FC_VN * XS; idx += 64 * FC_WAVES) {
-      const int nl = idx / XS, c = idx - nl * XS;
-      xbuf[nl * NC_XS + c] = nl < nv_live ? a.X[(size_t)(a.gbase + a.vn_node[v0 + nl]) * XS + c] : 0.f;
-    }
+  for (int idx = tid; idx < FC_VN * XS; idx += 64 * FC_WAVES) {
+    const int nl = idx / XS, c = idx - nl * XS;
+    xbuf[nl * NC_XS + c] = nl < nv_live ? a.X[(size_t)(a.gbase + a.vn_node[v0 + nl]) * XS + c] : 0.f;
   }
   const int g_begin = a.gsplit[blockIdx.y], g_end = a.gsplit[blockIdx.y + 1];
   // The granule descriptors are copied to LDS before the first message store: on gfx9-family parts loads and stores share
@@ -1157,20 +1266,10 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       if (a.ustart[u] >= g_begin && a.ustart[u] < g_end) { if (k == want) start = a.ustart[u] - g_begin; ++k; }
     for (int i = 0; i < n; ++i) gorder[i] = g_begin + (start + i) % n;
   }
-  // dense coupling rows of this workgroup's granules: cgt[g][s][k'][j] = C_path(s)[comp(s)][j - s_off][k'] (0 outside the path's sh block)
-  for (int idx = tid; idx < (g_end - g_begin) * CGN; idx += 64 * FC_WAVES) {
-    const int gl = idx / CGN, rem = idx - gl * CGN;
-    const int sl = rem / (MAXD * SHD), k = (rem / SHD) % MAXD, j = rem % SHD;
-    const FGran& Gq = a.gran[g_begin + gl];   // (prologue: no store has been issued yet)
-    float v = 0.f;
-    if (Gq.g[sl] >= 0 && k < Gq.dout) {
-      const GEntry E = a.gmap[Gq.g[sl] + k];
-      if (j >= E.s_off && j < E.s_off + E.ds) v = a.ctab[E.c_idx + (j - E.s_off) * E.dout];
-    }
-    cgt[idx] = v;
-  }
+  // dense coupling rows of this workgroup's granules (host-built, weights.cpp): cgt[g][s][k'][j]
+  for (int idx = tid; idx < (g_end - g_begin) * CGN; idx += 64 * FC_WAVES) cgt[idx] = a.cgt[(size_t)g_begin * CGN + idx];
   int ve0[2], vne[2];
-  float* gw = gscr + wave * 32 * GS2;
+  float* gw = gscr + wave * 16 * GS2;
   float* ew_ = escr + wave * 2 * 32 * ES;
 #pragma unroll
   for (int vi = 0; vi < 2; ++vi) {
@@ -1199,59 +1298,47 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     }
   }
   __syncthreads();
-  int vslot[2] = {2 * wave, 2 * wave + 1};   // chunk-buffer row block of each virtual node
-  if (MODE == 2) { vslot[0] = stab[16 + 2 * wave]; vslot[1] = stab[17 + 2 * wave]; }
   const int H = a.HK - 1;
   const int NG8 = a.NG8;
   const float* __restrict__ hb_tile = a.Hb + fc_hb_off(v0, 0, 0, 0, fc_ngp(NG8));   // uniform: hidden rows of this tile
   (void)hb_tile;
   const float* __restrict__ hfrag = a.Hb + fc_hb_off(v0 + 2 * wave, 0, 0, lane, fc_ngp(NG8));   // + fc_hb_off(vi, rt, g, 0)
-  float* const ywr = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW + lr;           // node 4lq (+r), row = wave, column 16*slot + lr
+  float* const ywr0 = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW;               // node 4lq (+r), row = wave; + the lane's column
+  float* const ywr = ywr0 + lr;                                                // classic granules: column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
-  constexpr int NGR = MODE == 2 ? 2 : 1;   // granules per pass
   FC_STAMP(pf, 0);
-  for (int go = g_begin; go < g_end; go += NGR) {
+  for (int go = g_begin; go < g_end; ++go) {
     FC_COUNT(pf, 14);
-    const int gi = MODE == 2 ? go : gorder[go - g_begin];
+    const int gi = gorder[go - g_begin];
     const FGran& Gd = gran_l[gi];
-    f32x4 acc_all[2][2][2][4];
+    if (DDMI_ABL(a.dbg, 4096) && Gd.accumulate) continue;   // timing-only: the second granule of a wide unit dropped
+    const bool packed = PACK && Gd.shape >= 4;
+    const int NB = packed ? Gd.nb : 4;                       // live column blocks of this granule
+    f32x4 acc[2][2][NBK];
 #pragma unroll
-    for (int u = 0; u < NGR; ++u)
+    for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
-      for (int vi = 0; vi < 2; ++vi)
+      for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc_all[u][vi][rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 (&acc)[2][2][4] = acc_all[0];
-    if (MODE == 2) {
-      const int ng = min(NGR, g_end - gi);
-      const size_t gstride = (size_t)a.HKp * 64, nstride = (size_t)a.n_gran * gstride;
-      const float* __restrict__ yg = a.Yg + (size_t)gi * gstride;
-      fc_mainloop_load(acc_all, yg, gstride, nstride, ng, stab, NG8, hb_tile, wave, lane, vne, vslot, ybuf, tid, lr, lq);
-      // bias row (k = H, h = 1) of every (granule, slot) -> row 0 of buffer 0
-      {
-        const int bu = tid >> 7, bs = (tid >> 4) & 7;
-        if (tid < 256 && bu < ng && bs < stab[32])
-          *reinterpret_cast<float4*>(ybuf + (bu * 8 + bs) * FC_YVN + 4 * (tid & 15)) =
-              nt_load4(yg + (size_t)bu * gstride + (size_t)stab[bs] * nstride + (size_t)H * 64 + 4 * (tid & 15));
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < NGR; ++u)
-#pragma unroll
-        for (int vi = 0; vi < 2; ++vi) {
-          const float* __restrict__ yb = ybuf + (u * 8 + vslot[vi]) * FC_YVN + lr;
-          const float b0 = yb[0], b1 = yb[16], b2 = yb[32], b3 = yb[48];
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              acc_all[u][vi][rt][0][r] += b0; acc_all[u][vi][rt][1][r] += b1;
-              acc_all[u][vi][rt][2][r] += b2; acc_all[u][vi][rt][3][r] += b3;
-            }
+        for (int c = 0; c < NBK; ++c) acc[vi][rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!Gd.empty && !DDMI_ABL(a.dbg, 128)) {
+      if (PACK && packed) {
+        const FcPackRt P = fc_pack_setup(Gd, xbuf, lr, lq);
+        FC_STAMP(pf, 1);
+        constexpr bool DN = MODE == 3;
+#define FC_MLP(S0_, NG_) fc_mainloop_packed<NBK, S0_, NG_, DN>(acc, P, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr0, yrd, pf)
+        if constexpr (NBK >= 5) { if (Gd.shape == 4) FC_MLP(12, 2); }
+        if (Gd.shape == 5) FC_MLP(0, 2);
+        else if (Gd.shape == 6) FC_MLP(12, 1);
+#undef FC_MLP
+        // ---- bias row (k = H, h = 1): wave s contracts slot s
+        if (wave < Gd.nslot && !DDMI_ABL(a.dbg, 64)) {
+          const FcSlotRt sb = fc_slot_setup(Gd.slot[wave], a.wpack, xbuf, 0, lr, lq);
+          const f32x4 rb = fc_direct(sb, (size_t)H * a.KS);
+          const int col = lr < 8 ? 8 * wave + lr : lr < 10 ? 16 * (NB - 1) + 2 * wave + lr - 8 : 16 * NBK + lr - 10;
+          fc_store<NBK>(ybuf + (4 * lq) * FC_YVN + col, 0, rb);    // row 0 of buffer 0
         }
-    } else if (!Gd.empty && !DDMI_ABL(a.dbg, 128)) {
+      } else {
       const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
@@ -1260,7 +1347,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         constexpr bool DN = MODE == 3;
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
         FC_STAMP(pf, 1);
-#define FC_ML(S0_, SN_, DUP_, NLV_) fc_mainloop_dense<S0_, SN_, DN, DUP_, NLV_>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd, pf)
+#define FC_ML(S0_, SN_, DUP_, NLV_) fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd, pf)
         int dup, nlv;
         fc_variant(Gd, dup, nlv);
         if (Gd.shape == 1 && dup == 1 && nlv == 3) FC_ML(12, 3, 1, 3);
@@ -1292,7 +1379,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
           r0 = fc_apply<FC_CAP0>(s0, koff, pre.b0); r1 = fc_apply<FC_CAPN>(s1, koff, pre.b1);
           r2 = fc_apply<FC_CAPN>(s2, koff, pre.b2); r3 = fc_apply<FC_CAPN>(s3, koff, pre.b3);
         }
-        fc_store(yw, 0, r0); fc_store(yw, 1, r1); fc_store(yw, 2, r2); fc_store(yw, 3, r3);
+        fc_store<NBK>(yw, 0, r0); fc_store<NBK>(yw, 16, r1); fc_store<NBK>(yw, 32, r2); fc_store<NBK>(yw, 48, r3);
       };
       // edge GEMM of this wave's 2 virtual nodes on the group in buffer `buf` (two k-steps: sub = 0, 1)
       auto edge_gemm = [&](int buf, const float2 (&hA)[2][2]) __attribute__((always_inline)) {
@@ -1350,115 +1437,167 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       }
       // ---- bias row (k = H, h = 1): waves 0..3 contract one slot each, every edge row receives the node's bias row
       if (wave < 4 && !DDMI_ABL(a.dbg, 64)) {
-        const FcSlotRt& sb = wave == 0 ? s0 : wave == 1 ? s1 : wave == 2 ? s2 : s3;
+        const FcSlotRt sb = fc_slot_setup(Gd.slot[wave], a.wpack, xbuf, Gd.w0, lr, lq);   // (set up again: nothing of the main loop's slots stays live)
         const f32x4 rb = fc_direct(sb, (size_t)H * a.KS);
-        fc_store(ybuf + (4 * lq) * FC_YVN + lr, wave, rb);    // row 0 of buffer 0
+        fc_store<NBK>(ybuf + (4 * lq) * FC_YVN + lr, 16 * wave, rb);    // row 0 of buffer 0
+      }
       }
       __syncthreads();
 #pragma unroll
       for (int vi = 0; vi < 2; ++vi) {
         const float* __restrict__ yb = ybuf + (2 * wave + vi) * FC_YVN + lr;
-        const float b0 = yb[0], b1 = yb[16], b2 = yb[32], b3 = yb[48];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int c = 0; c < NBK; ++c) {
+          if (c >= NB) break;
+          const float b = yb[16 * c];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            acc[vi][rt][0][r] += b0; acc[vi][rt][1][r] += b1; acc[vi][rt][2][r] += b2; acc[vi][rt][3][r] += b3;
-          }
+          for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[vi][rt][c][r] += b;
+        }
       }
     }
     FC_STAMP(pf, 4);
     __syncthreads();   // the coupling phase stages message rows in the (now idle) chunk buffers
     FC_STAMP(pf, 5);
-    // ---- coupling with the spherical harmonics and message stores (wave-local: no workgroup barrier)
-#pragma unroll
-    for (int u = 0; u < NGR; ++u) {
-    if (gi + u >= g_end) break;
-    const FGran& Gd = gran_l[gi + u];
-    f32x4 (&acc)[2][2][4] = acc_all[u];
-    const float* __restrict__ cg = cgt + (gi + u - g_begin) * CGN;
+    // ---- coupling with the spherical harmonics and message stores, 16 edge rows at a time (wave-local: no workgroup barrier)
+    // (the lane id is made opaque here: every per-lane address of the epilogue is then recomputed per granule instead of being
+    // hoisted out of the granule loop, where it would stay live across the register-tight main loops)
+    int lane_e = lane;
+    DDMI_OPAQUE(lane_e);
+    const int lr_e = lane_e & 15, lq_e = lane_e >> 4;
+    const float* __restrict__ cg = cgt + (gi - g_begin) * CGN;
+    float* stg = ybuf + wave * ((2 * FC_YB) / FC_WAVES);   // the chunk buffers are idle during the coupling phase: [16][RS] message rows
+    float* tT = stg + 16 * 16 * MAXD;                      // packed: [16 rows][2 channels][8 slots] accumulators of the tail block
+    const int RS = 16 * Gd.dout, L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
+    const int V = ((c0 | L) & 3) == 0 ? 4 : ((c0 | L) & 1) == 0 ? 2 : 1;
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi) {
       const int ne = vne[vi];
       if (ne == 0 || DDMI_ABL(a.dbg, 32)) continue;
       const float* __restrict__ erow = ew_ + vi * 32 * ES;
-      DDMI_WAVE_SYNC();
-      {   // G[el][s][k'] = we_el * sum_j cg[s][k'][j] * sh_el[j] : lane = (edge row, slot pair); the edge weight rides along
-        const int el = lane & 31, half = lane >> 5;
-        float sh[SHD];
-        if constexpr (SHD == 4) {
-          const float4 s4 = *reinterpret_cast<const float4*>(erow + el * ES);
-          sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
-        } else {
 #pragma unroll
-          for (int j = 0; j < SHD; ++j) sh[j] = erow[el * ES + j];
-        }
-        const float we = erow[el * ES + SHD];
+      for (int rt = 0; rt < 2; ++rt) {
+        if (ne <= 16 * rt) break;
+        DDMI_WAVE_SYNC();
+        {   // G[row][s][k'] = we_row * sum_j cg[s][k'][j] * sh_row[j] : lane = (edge row, quarter of the slots); the edge weight rides along
+          const int row = lane_e & 15, part = lane_e >> 4, el = 16 * rt + row;
+          float sh[SHD];
+          if constexpr (SHD == 4) {
+            const float4 s4 = *reinterpret_cast<const float4*>(erow + el * ES);
+            sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
+          } else {
 #pragma unroll
-        for (int k = 0; k < MAXD; ++k) {
-          float2 v = make_float2(0.f, 0.f);
-#pragma unroll
-          for (int j = 0; j < SHD; ++j) {
-            v.x = fmaf(cg[((2 * half) * MAXD + k) * SHD + j], sh[j], v.x);
-            v.y = fmaf(cg[((2 * half + 1) * MAXD + k) * SHD + j], sh[j], v.y);
+            for (int j = 0; j < SHD; ++j) sh[j] = erow[el * ES + j];
           }
-          v.x *= we; v.y *= we;
-          *reinterpret_cast<float2*>(gw + el * GS2 + 4 * k + 2 * half) = v;   // the four slots of (row, k') side by side
-        }
-      }
-      DDMI_WAVE_SYNC();
-      FC_STAMP(pf, 6);
-      {
-        float* stg = ybuf + wave * ((2 * FC_YB) / FC_WAVES);   // the chunk buffers are idle during the coupling phase
-        const int RS = 16 * Gd.dout, L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
-        const int V = ((c0 | L) & 3) == 0 ? 4 : ((c0 | L) & 1) == 0 ? 2 : 1;
-        // message value of (row, k') from the lane's four slot accumulators
-        auto couple = [&](const float* __restrict__ G, int k, float t0, float t1, float t2, float t3) __attribute__((always_inline)) {
-          const float4 g4 = *reinterpret_cast<const float4*>(G + 4 * k);
-          float v = g4.x * t0;
-          v = fmaf(g4.y, t1, v);
-          v = fmaf(g4.z, t2, v);
-          return fmaf(g4.w, t3, v);
-        };
+          const float we = erow[el * ES + SHD];
+          auto gval = [&](int s_, int k) __attribute__((always_inline)) {
+            float v = 0.f;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          if (ne <= 16 * rt) break;
+            for (int j = 0; j < SHD; ++j) v = fmaf(cg[(s_ * MAXD + k) * SHD + j], sh[j], v);
+            return v * we;
+          };
+          if (PACK && packed) {   // slots 2*part (even half, position part) and 2*part + 1 (odd half, position part)
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k) {
+              gw[row * GS2 + 8 * k + part] = gval(2 * part, k);
+              gw[row * GS2 + 8 * k + 4 + part] = gval(2 * part + 1, k);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k) gw[row * GS2 + 4 * k + part] = gval(part, k);   // the four slots of (row, k') side by side
+          }
+        }
+        DDMI_WAVE_SYNC();
+        FC_STAMP(pf, 6);
+        if (PACK && packed) {
+          if constexpr (PACK) {
+            const int hi = lr_e >> 3, NS = Gd.nslot;
+            // pair blocks: lanes lr_e and lr_e + 8 hold the even / odd slots of channel lr_e & 7; their partial sums meet by a row rotate
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 4 * lq_e + r;
+              const float* __restrict__ G = gw + row * GS2 + 4 * hi;
+              float m[MAXD];
+#pragma unroll
+              for (int k = 0; k < MAXD; ++k) {
+                const float4 g4 = *reinterpret_cast<const float4*>(G + 8 * k);
+                const float gq[4] = {g4.x, g4.y, g4.z, g4.w};
+                float v = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)   // pair block c: slot 2c + hi (a slot past the last one is a padding column: not read)
+                  if (c < NB - 1) v = fmaf(gq[c], 2 * c + hi < NS ? acc[vi][rt][c][r] : 0.f, v);
+                m[k] = v + DDMI_ROW_XOR8(v);
+              }
+              if (lr_e < 8) {
+#pragma unroll
+                for (int k = 0; k < MAXD; ++k) stg[row * RS + lr_e * MAXD + k] = m[k];   // (packed granules: dout = MAXD = 3)
+              }
+              // tail block: lane_e lr_e = 2*slot + (channel - 8) -> transposed through LDS
+              float tv = 0.f;
+#pragma unroll
+              for (int c = 2; c < NBK; ++c) if (c == NB - 1) tv = acc[vi][rt][c][r];
+              tT[row * 16 + (lr_e & 1) * 8 + (lr_e >> 1)] = (lr_e >> 1) < NS ? tv : 0.f;
+            }
+            DDMI_WAVE_SYNC();
+            if (lane_e < 32) {   // lane_e = (row, channel 8 + wb): all slots of one output channel
+              const int row = lane_e >> 1, wb = lane_e & 1;
+              const float4 ta = *reinterpret_cast<const float4*>(tT + row * 16 + wb * 8), tb = *reinterpret_cast<const float4*>(tT + row * 16 + wb * 8 + 4);
+#pragma unroll
+              for (int k = 0; k < MAXD; ++k) {
+                const float4 ge = *reinterpret_cast<const float4*>(gw + row * GS2 + 8 * k), go_ = *reinterpret_cast<const float4*>(gw + row * GS2 + 8 * k + 4);
+                float v = ge.x * ta.x;           // slots 0, 2, 4, 6 = ge.xyzw; 1, 3, 5, 7 = go_.xyzw; tT holds slot order 0..7
+                v = fmaf(go_.x, ta.y, v); v = fmaf(ge.y, ta.z, v); v = fmaf(go_.y, ta.w, v);
+                v = fmaf(ge.z, tb.x, v); v = fmaf(go_.z, tb.y, v); v = fmaf(ge.w, tb.z, v); v = fmaf(go_.w, tb.w, v);
+                if (8 + wb < Gd.n_w) stg[row * RS + (8 + wb) * MAXD + k] = v;
+              }
+            }
+          }
+        } else {
+          // message value of (row, k') from the lane_e's four slot accumulators
+          auto couple = [&](const float* __restrict__ G, int k, float t0, float t1, float t2, float t3) __attribute__((always_inline)) {
+            const float4 g4 = *reinterpret_cast<const float4*>(G + 4 * k);
+            float v = g4.x * t0;
+            v = fmaf(g4.y, t1, v);
+            v = fmaf(g4.z, t2, v);
+            return fmaf(g4.w, t3, v);
+          };
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 4 * lq + r, el = rt * 16 + row;
-            const float* __restrict__ G = gw + el * GS2;
+            const int row = 4 * lq_e + r;
+            const float* __restrict__ G = gw + row * GS2;
             const float t0 = acc[vi][rt][0][r], t1 = acc[vi][rt][1][r], t2 = acc[vi][rt][2][r], t3 = acc[vi][rt][3][r];
             if (Gd.dout == 1) {          // scalar output blocks
-              stg[row * 16 + lr] = couple(G, 0, t0, t1, t2, t3);
+              stg[row * 16 + lr_e] = couple(G, 0, t0, t1, t2, t3);
             } else if (Gd.dout == 3) {   // vector output blocks: the three components of (row, w) side by side
-              float* __restrict__ o = stg + row * 48 + lr * 3;
+              float* __restrict__ o = stg + row * 48 + lr_e * 3;
               o[0] = couple(G, 0, t0, t1, t2, t3); o[1] = couple(G, 1, t0, t1, t2, t3); o[2] = couple(G, 2, t0, t1, t2, t3);
             } else {
 #pragma unroll
               for (int k = 0; k < MAXD; ++k)
-                if (k < Gd.dout) stg[row * RS + lr * Gd.dout + k] = couple(G, k, t0, t1, t2, t3);
+                if (k < Gd.dout) stg[row * RS + lr_e * Gd.dout + k] = couple(G, k, t0, t1, t2, t3);
             }
           }
-          DDMI_WAVE_SYNC();
-          FC_STAMP(pf, 7);
-          if (!DDMI_ABL(a.dbg, 256)) {
-            const int nrows = min(16, ne - 16 * rt);
-            const float* __restrict__ er = erow + rt * 16 * ES;
-            if (V == 4) fc_store_rows<4>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, Gd.accumulate, lane);
-            else if (V == 2) fc_store_rows<2>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, Gd.accumulate, lane);
-            else fc_store_rows<1>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, Gd.accumulate, lane);
-          }
-          DDMI_WAVE_SYNC();
-          FC_STAMP(pf, 8);
         }
+        DDMI_WAVE_SYNC();
+        FC_STAMP(pf, 7);
+        if (!DDMI_ABL(a.dbg, 256)) {
+          const int nrows = min(16, ne - 16 * rt);
+          const float* __restrict__ er = erow + rt * 16 * ES;
+          const int accum = DDMI_ABL(a.dbg, 8192) ? 0 : Gd.accumulate;   // (timing-only: later granules of a unit overwrite instead of adding)
+          if (V == 4) fc_store_rows<4>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
+          else if (V == 2) fc_store_rows<2>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
+          else fc_store_rows<1>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
+        }
+        DDMI_WAVE_SYNC();
+        FC_STAMP(pf, 8);
       }
-    }
     }
     FC_STAMP(pf, 7);
     __syncthreads();   // chunk buffers / coupling scratch are reused by the next granule
     FC_STAMP(pf, 9);
   }
-#ifdef DDMI_PROFILING
+#ifdef DDMI_PHASE_CLOCKS
   pf.acc[10] = pf.t - pf_t0;
   pf.acc[15] = 1;
   if (lane == 0 && a.prof_slot >= 0 && a.prof_slot < FC_PROF_SLOTS) {
@@ -1468,28 +1607,22 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 #endif
 }
 
-template <int MAXD, int SHD>
-static void launch_conv_fused_t(const FusedConvArgs& a, hipStream_t s) {
-  constexpr int GS2 = 4 * MAXD + 8, ES = SHD == 4 ? 8 : SHD + 3, CGN = 4 * MAXD * SHD;   // ES: edge-row stride (sh, weight, message row); 8 keeps 4 harmonics one 16-B read
+template <int MAXD, int SHD, int MODE, int NBK>
+static void launch_conv_fused_k(const FusedConvArgs& a, hipStream_t s) {
+  constexpr bool PACK = MODE != 1 && MAXD == 3 && SHD == 4;
+  constexpr int GS2 = PACK ? 8 * MAXD + 12 : 4 * MAXD + 8, ES = SHD == 4 ? 8 : SHD + 3, CGN = FC_MAXSLOT * MAXD * SHD;
   int max_local = 0;
   for (int y = 0; y < a.ysplit; ++y) max_local = std::max(max_local, a.gsplit[y + 1] - a.gsplit[y]);
   if (max_local > FC_MAXG) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: more granules per workgroup than descriptor slots (raise DDMI_FUSED_YS)");
-  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FC_YB + FC_WAVES * 32 * GS2 + FC_WAVES * 2 * 32 * ES + FC_MAXG * FC_GWORDS + FC_MAXG + max_local * CGN) * sizeof(float);
+  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FcDim<NBK>::YB + FC_WAVES * 16 * GS2 + FC_WAVES * 2 * 32 * ES + FC_MAXG * FC_GWORDS + FC_MAXG + max_local * CGN) * sizeof(float);
   if (smem > 160 * 1024) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: LDS budget exceeded (raise DDMI_FUSED_YS)");
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per instantiation)
   if (!lds_opt_in) {
-    const int cap = 160 * 1024;
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, MODE, NBK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     lds_opt_in = true;
   }
   dim3 grid(cdiv(a.vcap, FC_VN), a.ysplit);
-  if (a.Yg) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 2>), grid, dim3(64 * FC_WAVES), smem, s, a);
-  else if (a.generic) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 1>), grid, dim3(64 * FC_WAVES), smem, s, a);
-  else if (a.dense) hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 3>), grid, dim3(64 * FC_WAVES), smem, s, a);
-  else hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, 0>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, MODE, NBK>), grid, dim3(64 * FC_WAVES), smem, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -1497,9 +1630,19 @@ void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
   if (a_in.vcap <= 0 || a_in.ysplit <= 0) return;
   FusedConvArgs a = a_in;
   a.dbg = ablate_mask();
-  if (a.maxd <= 3 && a.sh_lmax <= 1) launch_conv_fused_t<3, 4>(a, s);
-  else if (a.maxd <= 3) launch_conv_fused_t<3, 9>(a, s);
-  else launch_conv_fused_t<5, 9>(a, s);
+  if (a.maxd <= 3 && a.sh_lmax <= 1) {   // the l <= 1 tensor product (FasterTensorProduct structure): static chain shapes, packed granules
+    if (a.generic) launch_conv_fused_k<3, 4, 1, 4>(a, s);
+    else if (a.max_nb > 4) { if (a.dense) launch_conv_fused_k<3, 4, 3, 5>(a, s); else launch_conv_fused_k<3, 4, 0, 5>(a, s); }
+    else { if (a.dense) launch_conv_fused_k<3, 4, 3, 4>(a, s); else launch_conv_fused_k<3, 4, 0, 4>(a, s); }
+  } else if (a.maxd <= 3) {
+    if (a.generic) launch_conv_fused_k<3, 9, 1, 4>(a, s);
+    else if (a.dense) launch_conv_fused_k<3, 9, 3, 4>(a, s);
+    else launch_conv_fused_k<3, 9, 0, 4>(a, s);
+  } else {
+    if (a.generic) launch_conv_fused_k<5, 9, 1, 4>(a, s);
+    else if (a.dense) launch_conv_fused_k<5, 9, 3, 4>(a, s);
+    else launch_conv_fused_k<5, 9, 0, 4>(a, s);
+  }
 }
 
 // ---------------------------------------------------------------------- reduce + BN

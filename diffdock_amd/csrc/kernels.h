@@ -39,14 +39,11 @@ struct NcSlot { int x_off, din, comp, mul_in, u_pad, w_pad, wk_off; };   // one 
 struct NcUnit {     // one (output block, 16-wide w tile) unit of the node contraction: n_w items x itemw columns
   int col_base, itemw, w0, n_w;
   NcSlot slot[16];  // slot[s].din == 0 -> padding column (written as 0)
-  int gran[4];      // granule-major output (k_conv_fused load mode): granule of quad q, -1 = padding quad (not stored)
-  int perm[16];     // ... and the position of unit slot 4q + c inside that granule (column 16*perm + w)
 };
 
 // Y[node][st][k][64] (st = 64-column super-tile) = sum_u x[node][x_off + u*din + i] * W2pack[k][path][u][w]
-// n_gran > 0: granule-major output Y[node][granule][k][64] (column 16*slot + w) for the load mode of k_conv_fused
 void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcUnit* units, int n_units,
-                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s, int n_gran = 0);
+                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s);
 
 struct EdgeConvArgs {
   int gcount;            // gather nodes
@@ -70,26 +67,36 @@ struct EdgeConvArgs {
 };
 void launch_edge_conv(const EdgeConvArgs& a, hipStream_t s);
 
-// ---- fused form for gather nodes with few edges each (receptor residues): the contracted rows never leave the CU.
+// ---- fused form: the contracted rows never leave the CU.
 // A VIRTUAL NODE = one gather node with up to 32 of its edges (nodes with more edges appear several times, nodes
-// without edges not at all).  A workgroup owns 16 virtual nodes and walks GRANULES of 64 fused columns
-// (w = w0 + lane%16, slot 4q + s): per 8-row k chunk it contracts the 16 x rows with the packed second-layer weights
-// into LDS (v_mfma_f32_16x16x4_f32, M = nodes) and immediately multiplies the chunk into the edge accumulators
-// (M = edges), then couples with the spherical harmonics and writes the message columns of the granule.
+// without edges not at all).  A workgroup owns 16 virtual nodes and walks GRANULES of fused columns: per 8-row k chunk it
+// contracts the 16 x rows with the packed second-layer weights into LDS (v_mfma_f32_16x16x4_f32, M = nodes) and
+// immediately multiplies the chunk into the edge accumulators (M = edges), then couples with the spherical harmonics and
+// writes the message columns of the granule.
+// CLASSIC granule: 4 slots (= (path, input component) columns) of one 16-channel tile, column 16*slot + w; an output block
+// fed by more than 4 slots takes several granules whose message columns add up.
+// PACKED granule (output blocks of <= 10 channels, e.g. the 10 vector channels): ALL slots (<= 8) of the block in one
+// granule -- channels 0..7 of slots 2b and 2b+1 share column block b (column 8*slot + w), channels 8, 9 of every slot sit
+// in one tail block (column 16*(nb-1) + 2*slot + w - 8): 7 slots x 10 channels take 5 column blocks instead of two
+// classic granules with 7, one pass and no add.
+constexpr int FC_MAXSLOT = 8;
 struct FGran {
-  NcSlot slot[4];        // the 4 (path, input component) columns of this granule; din == 0 -> padding (zero)
-  int w0, n_w;           // lanes lr < n_w carry output channel w0 + lr
+  NcSlot slot[FC_MAXSLOT];   // classic: 4 entries, din == 0 -> padding (zero); packed: nslot entries
+  int w0, n_w;           // lanes lr < n_w carry output channel w0 + lr (classic)
   int o_off, dout;       // message columns o_off + w*dout + k'
-  int g[4];              // slot s couples through gmap[g[s] .. g[s]+dout), -1 = padding
+  int g[FC_MAXSLOT];     // slot s couples through gmap[g[s] .. g[s]+dout), -1 = padding
   int accumulate;        // 0: first granule of its (output block, w tile) unit writes, later ones add
   int empty;             // no path reaches this granule: the message columns are zero
-  int shape;             // chain-length class of the 4 slots: 1 = (12,3,3,3), 2 = (3,3,3,3), 3 = (12,-,-,-), 0 = generic
-  int nlive;             // live (non-padding) slots among 1..3; padding slots trail after the host's sort
-  int dup;               // slots whose packed weights coincide (the components of one path share their weights; a padding slot may
-                         // borrow any): 0 none, 1 = slots 1..3 use slot 1's fragments, 2 = slots 0..2 use slot 0's, 3 = all use slot 0's
+  int shape;             // chain-length class: classic 1 = (12,3,3,3), 2 = (3,3,3,3), 3 = (12,-,-,-), 0 = generic;
+                         // packed 4 = 12 | 3x3 | 3x3 (7 slots), 5 = 3x3 | 3x3 (6 slots), 6 = 12 | 3x3 (4 slots): a 12-step chain, then
+                         // groups of three 3-step chains (the components of one path, sharing their weights)
+  int nlive;             // classic: live (non-padding) slots among 1..3; padding slots trail after the host's sort
+  int dup;               // classic: slots whose packed weights coincide (the components of one path share their weights; a padding slot
+                         // may borrow any): 0 none, 1 = slots 1..3 use slot 1's fragments, 2 = slots 0..2 use slot 0's, 3 = all use slot 0's
+  int nslot;             // live slots (packed), 4 (classic)
+  int nb;                // column blocks of the edge product: packed ceil(nslot / 2) + 1, classic 4
 };
-void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s,
-                     int pad_even = 0);
+void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s);
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                         const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
                         float* Hb, hipStream_t s);
@@ -119,10 +126,11 @@ struct FusedConvArgs {
   const float* X; int gbase;             // node table (stride XS), first gather node
   const float* wpack; int KS, HK;        // packed second layer [HK][KS]
   const float* Hb; int NG8;              // hidden rows in A-fragment order [vcap][2][NG8][64][2], NG8 = ceil(H / 8)
-  const float* Yg; int HKp, n_gran;      // load mode (gather nodes with many edges): contracted rows [node][granule][HKp][64]
   const float* nvec; const float* ew; float sgn; int sh_lmax;
   const FGran* gran; int ysplit; int gsplit[9];   // blockIdx.y walks granules [gsplit[y], gsplit[y+1])
-  const GEntry* gmap; const float* ctab; int maxd;
+  const float* cgt;                      // dense coupling rows [granule][FC_MAXSLOT][MAXD][SHD] (host-built, weights.cpp)
+  int max_nb;                            // widest granule of the layer, in column blocks (4 classic, 5 = a packed 7-slot granule)
+  int maxd;
   int generic;                           // some granule has no static chain shape: predicated kernel variant
   int dense;                             // most virtual nodes hold > 16 edges: multiply both row tiles unconditionally
   int n_units; short ustart[48];         // first granule of every (output block, w tile) unit: workgroups rotate their visiting order by units
@@ -130,7 +138,7 @@ struct FusedConvArgs {
   int dbg = 0;
   int prof_slot = 0;                     // profiling builds: edge-group slot of the in-kernel phase clocks
 };
-#ifdef DDMI_PROFILING
+#if defined(DDMI_PROFILING) && DDMI_PROFILING >= 2
 void fc_prof_report();                   // prints and clears the phase clocks of k_conv_fused (stderr)
 #endif
 void launch_conv_fused(const FusedConvArgs& a, hipStream_t s);

@@ -47,6 +47,7 @@ struct ConvW {  // one TensorProductConvLayer
   std::vector<float*> W1p, b1p;   // first layer with the hidden units of every block of 16 in the order k_edge_hidden_mm emits them
   NcUnit* nc_units = nullptr; int n_nc = 0, KS = 0;          // node-contraction work list, k-slab size of wpack
   FGran* fgran = nullptr; int n_fgran = 0, HKq = 0; bool fgran_generic = false;          // fused form: granule list, padded hidden-row length
+  float* cgt = nullptr; int max_nb = 4;                      // dense coupling rows per granule; widest granule in column blocks
   std::vector<int> fgran_unit;                               // unit id of every granule (split points of the grid)
   ObInfo* obs = nullptr; int n_ob = 0; QuadDesc* qdesc = nullptr; GEntry* gmap = nullptr; int GN = 0, maxd = 1;
   DevPath* paths = nullptr; float* ctab = nullptr; CgItem* items = nullptr; int n_items = 0;
@@ -92,9 +93,9 @@ struct Model {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cross = nullptr;
   bool two_streams = true;
   bool fused = true;        // receptor-gather edge groups use k_conv_fused (DDMI_FUSED=0: contracted rows through HBM)
-  int fused_lig = 3;        // ligand-gather groups (DDMI_FUSED_LIG): 3 = k_conv_fused contracting per virtual node like every other
-                            // group, 2 = k_conv_fused load mode (rows from k_node_contract), 1 = fused when a node carries
-                            // >= 64 edges, else unfused, 0 = unfused (k_node_contract + k_edge_conv)
+  int fused_lig = 3;        // ligand-gather groups (DDMI_FUSED_LIG): 3 = k_conv_fused like every other group, 0 = unfused
+                            // (k_node_contract + k_edge_conv)
+  bool fused_pack = true;   // packed granules for output blocks of <= 10 channels (DDMI_FUSED_PACK=0: classic granules only)
   bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden
   int fused_dense = 1;      // branch-free dense-row main loop: 0 never, 1 groups with >= 20 edges per gather node, 2 always
   int fused_ysplit = 0;     // workgroups per 16-virtual-node tile (granule ranges); 0 = spread launches with few tiles over the CUs

@@ -390,16 +390,49 @@ static void commit_conv(Model& m, ConvW& L) {
             c += round_up(p.mul_in, 4) / 4;
           }
         }
-        // fused form: one granule per quad of item columns
-        for (int q = 0; q < O.itemw / 4; ++q) {
+        // fused form, packed granule: an output block of <= 10 channels fed by one 12-step chain (a scalar path) and / or
+        // groups of three 3-step chains (the components of a vector path): every slot of the block in ONE granule
+        // (kernels.h, FGran).  Anything else: classic granules, one per quad of item columns.
+        bool packed = false;
+        if (m.fused_pack && L.maxd <= 3 && m.cfg.sh_lmax <= 1 && L.H % 16 == 0 && O.mul > 8 && O.mul <= 10 && O.dout == 3) {
+          auto chain = [&](int t) { return U.slot[t].din == 0 ? 0 : U.slot[t].u_pad / 4; };
+          int c12 = -1, groups[2] = {-1, -1}, ng = 0;
+          bool ok = true;
+          for (int t = 0; t < O.itemw && ok; ) {
+            const NcSlot& S = U.slot[t];
+            if (S.din == 0) { ++t; continue; }
+            if (S.din == 1 && chain(t) == 12 && c12 < 0) { c12 = t; ++t; continue; }
+            if (S.din == 3 && S.comp == 0 && chain(t) == 3 && t + 2 < O.itemw && ng < 2 && U.slot[t + 1].din == 3 &&
+                U.slot[t + 2].din == 3 && U.slot[t + 1].comp == 1 && U.slot[t + 2].comp == 2 &&
+                U.slot[t + 1].wk_off == S.wk_off && U.slot[t + 2].wk_off == S.wk_off && U.slot[t + 1].x_off == S.x_off &&
+                U.slot[t + 2].x_off == S.x_off) { groups[ng++] = t; t += 3; continue; }
+            ok = false;
+          }
+          const int shape = !ok ? 0 : (c12 >= 0 && ng == 2) ? 4 : (c12 < 0 && ng == 2) ? 5 : (c12 >= 0 && ng == 1) ? 6 : 0;
+          if (shape) {
+            FGran G{};
+            G.w0 = 0; G.n_w = U.n_w; G.o_off = O.o_off; G.dout = O.dout; G.shape = shape;
+            int ns_ = 0;
+            auto put = [&](int t) { G.slot[ns_] = U.slot[t]; G.g[ns_] = slot_g[t]; ++ns_; };
+            if (c12 >= 0) put(c12);
+            for (int gq = 0; gq < ng; ++gq) for (int i = 0; i < 3; ++i) put(groups[gq] + i);
+            for (int t = ns_; t < FC_MAXSLOT; ++t) G.g[t] = -1;
+            G.nslot = ns_; G.nb = (ns_ + 1) / 2 + 1;
+            fg.push_back(G);
+            L.fgran_unit.push_back((int)nc.size());
+            packed = true;
+          }
+        }
+        for (int q = 0; q < O.itemw / 4 && !packed; ++q) {
           FGran G{};
           G.w0 = w0; G.n_w = U.n_w; G.o_off = O.o_off; G.dout = O.dout; G.accumulate = q > 0; G.empty = 1;
+          G.nslot = 4; G.nb = 4;
+          for (int sl = 0; sl < FC_MAXSLOT; ++sl) G.g[sl] = -1;
           for (int sl = 0; sl < 4; ++sl) {
             G.slot[sl] = U.slot[4 * q + sl];
             G.g[sl] = slot_g[4 * q + sl];
             if (G.slot[sl].din != 0) G.empty = 0;
           }
-          U.gran[q] = -1;
           if (G.empty && q > 0) continue;   // padding quad of a wider item: contributes nothing
           // longest chain first: k_conv_fused prefetches 12 weight fragments for slot 0 and 4 for the others
           int orig[4] = {0, 1, 2, 3};
@@ -410,8 +443,7 @@ static void commit_conv(Model& m, ConvW& L) {
                 std::swap(G.slot[j], G.slot[j - 1]); std::swap(G.g[j], G.g[j - 1]); std::swap(orig[j], orig[j - 1]);
               }
             }
-          U.gran[q] = (int)fg.size();
-          for (int j = 0; j < 4; ++j) U.perm[4 * q + orig[j]] = j;
+          (void)orig;
           {
             auto st = [&](int t) { return G.slot[t].din == 0 ? 0 : G.slot[t].u_pad / 4; };
             auto fits = [&](int t, int n) { return st(t) == n || st(t) == 0; };
@@ -441,6 +473,28 @@ static void commit_conv(Model& m, ConvW& L) {
     if (L.H % 16 != 0) L.fgran_generic = true;   // the static loops walk whole pairs of 8-k groups
     L.fgran = m.wpool.upload(fg);
     L.n_fgran = (int)fg.size();
+    L.max_nb = 4;
+    for (auto& G : fg) L.max_nb = std::max(L.max_nb, G.nb);
+    if (getenv("DDMI_DEBUG_GRAN")) {   // granule list of the layer (shape / slots / column blocks), for tests and debugging
+      fprintf(stderr, "ddmi granules %s:", L.name.c_str());
+      for (auto& G : fg) fprintf(stderr, " [shape %d slots %d nb %d w %d%s]", G.shape, G.nslot, G.nb, G.n_w, G.accumulate ? " acc" : "");
+      fprintf(stderr, "\n");
+    }
+    {   // dense coupling rows of every granule, in the (MAXD, SHD) shape of the kernel instantiation that runs this layer
+        // (k_conv.hip, launch_conv_fused): cgt[g][slot][k'][j] = C_path(slot)[comp(slot)][j - s_off][k'], 0 outside the path's sh block
+      const int MD = L.maxd <= 3 ? 3 : 5, SD = (L.maxd <= 3 && m.cfg.sh_lmax <= 1) ? 4 : 9;
+      std::vector<float> cgt(fg.size() * (size_t)FC_MAXSLOT * MD * SD, 0.f);
+      for (size_t gi = 0; gi < fg.size(); ++gi)
+        for (int sl = 0; sl < FC_MAXSLOT; ++sl)
+          for (int k = 0; k < MD; ++k) {
+            const FGran& G = fg[gi];
+            if (G.g[sl] < 0 || k >= G.dout) continue;
+            const GEntry& E = gmap[G.g[sl] + k];
+            for (int j = E.s_off; j < E.s_off + E.ds && j < SD; ++j)
+              cgt[((gi * FC_MAXSLOT + sl) * MD + k) * SD + j] = ctab[E.c_idx + (j - E.s_off) * E.dout];
+          }
+      L.cgt = m.wpool.upload(cgt);
+    }
     L.HKq = (int)round_up(L.H, 8);   // hidden width padded to the 8-k groups of the fused kernel
     std::vector<int> order(nc.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;

@@ -213,8 +213,9 @@ def test_crop_with_embedding_layers_matches_oracle(emu_lib):
 @pytest.mark.parametrize("lmax", [1, 2])
 def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
     """DDL-synth channel widths (ns=48, nv=10) on a small complex: the statically-shaped main loop of k_conv_fused
-    (chain shapes (12,3,3,3)/(3,3,3,3)/(12,-,-,-)), the generic variant at sh_lmax=2, receptor residues with more than 32
-    ligand neighbours (two virtual nodes per residue, accumulate granules), against the oracle and the unfused kernels."""
+    (chain shapes (12,3,3,3)/(3,3,3,3)/(12,-,-,-) and the packed 12|3x3 granule of the second layer), the generic variant at
+    sh_lmax=2, receptor residues with more than 32 ligand neighbours (two virtual nodes per residue), against the oracle and
+    the unfused kernels."""
     from dataclasses import replace
     from diffdock_amd.config import DDL_SYNTH
     from diffdock_amd.synth import make_complex, make_pose_list
@@ -231,16 +232,46 @@ def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
     outs = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("DDMI_FUSED", fused)
-        monkeypatch.setenv("DDMI_FUSED_LIG", "2" if lmax == 1 else "0")   # lmax 1 also forces both ligand-gather groups into load mode
+        monkeypatch.setenv("DDMI_FUSED_LIG", "3" if lmax == 1 else "0")   # lmax 2: the ligand-gather groups through the unfused pair
         m = make_model(cfg, sd, emu_lib)
         m.set_kernel_timing(True)
         outs[fused] = m(b)[:3]
         launched = m.kernel_timings()
         assert ("k_conv_fused" in launched) == (fused == "1")
-        assert ("k_conv_fused_load" in launched) == (fused == "1" and lmax == 1)
         if fused == "1":
             assert int(m.debug_buffer("vn_off_cross")[-1]) == 2 * b["receptor"].pos.shape[0]   # 40 neighbours -> 2 virtual nodes
         for o, r in zip(outs[fused], ref):
+            assert rel_err(o, r) < 1e-4
+    for a_, b_ in zip(outs["1"], outs["0"]):
+        assert rel_err(a_, b_) < 1e-5
+
+
+def test_packed_granules_match_oracle_and_classic_granules(emu_lib, monkeypatch, capfd):
+    """Four interaction layers at the DDL-synth widths: from the third layer on the 10-channel vector blocks are fed by 6 or 7
+    (path, component) slots and run as ONE packed granule each (12 | 3x3 | 3x3 in 5 column blocks, 3x3 | 3x3 in 4; the second
+    layer's 12 | 3x3 in 3) instead of two classic granules whose message columns add up.  Against the oracle and against
+    the classic granules (DDMI_FUSED_PACK=0)."""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = replace(DDL_SYNTH, num_conv_layers=4, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_max=5.0)
+    sd = init_state_dict(cfg, seed=3)
+    g = make_complex(seed=1, n_res=12, n_lig=20, lm_dim=0)
+    b = HeteroBatch.from_data_list(make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.3))
+    set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+    ref = CGModelOracle(cfg, sd, *tables())(b)[:3]
+    outs = {}
+    monkeypatch.setenv("DDMI_DEBUG_GRAN", "1")
+    for pack in ("1", "0"):
+        monkeypatch.setenv("DDMI_FUSED_PACK", pack)
+        capfd.readouterr()
+        m = make_model(cfg, sd, emu_lib)
+        listing = capfd.readouterr().err
+        assert ("shape 4 slots 7 nb 5" in listing) == (pack == "1") and ("shape 5 slots 6 nb 4" in listing) == (pack == "1")
+        assert ("shape 6 slots 4 nb 3" in listing) == (pack == "1") and (" acc]" in listing) == (pack == "0")
+        outs[pack] = m(b)[:3]
+        for o, r in zip(outs[pack], ref):
             assert rel_err(o, r) < 1e-4
     for a_, b_ in zip(outs["1"], outs["0"]):
         assert rel_err(a_, b_) < 1e-5
@@ -265,7 +296,7 @@ def test_ligand_atoms_with_many_receptor_neighbours(emu_lib):
     m.set_kernel_timing(True)
     out = m(b)[:3]
     launched = m.kernel_timings()
-    assert "k_conv_fused" in launched and "k_edge_conv" not in launched and "k_conv_fused_load" not in launched
+    assert "k_conv_fused" in launched and "k_edge_conv" not in launched
     assert int(m.debug_buffer("vn_off_rl")[-1]) == 3 * b["ligand"].pos.shape[0]     # ceil(70 / 32) virtual nodes per ligand atom
     assert int(m.debug_buffer("vn_off_cross")[-1]) == b["receptor"].pos.shape[0]    # 5 ligand neighbours: one sparse tile each
     for o, r in zip(out, ref):
