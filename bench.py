@@ -14,10 +14,14 @@ Workloads (--config; BASELINE.json `configs`, default = the one `metric` is quot
                       40 poses each, sampled one complex after the other (one model handle per complex, all resident)
   configs4            large-pocket stress: 1500 residues / 80 atoms, 40 poses, 4.8 M cross edges per direction
 
-Multi-GPU (--scaling): "weak" (default; the driver's contract) = every rank samples its own 40 poses of the complex;
-"strong" = BASELINE configs[3] / north_star: the SAME 40 poses sharded in contiguous blocks over the ranks (5 per GPU at 8).
-Either way the only collective is one RCCL all_gather of the final coordinates per step, as the reference's sampler
+Multi-GPU (--scaling): "strong" (default) = BASELINE configs[3] / north_star: the SAME 40 poses sharded in contiguous blocks
+over the ranks (5 per GPU at 8); "weak" = every rank samples its own 40 poses of the complex.  At N = 1 both are the headline
+run.  Either way the only collective is one RCCL all_gather of the final coordinates per step, as the reference's sampler
 would hand them to the confidence model.
+
+Timing: the K timed steps run with the library's per-kernel HIP-event timers OFF (plain production path); the per-phase
+milliseconds and the roofline objects come from one extra, untimed step with the timers on (and, for the dominant kernel, one
+more on a single stream: with two streams the launch durations overlap).
 
 Cross graph: the untrained (random-weight) score model cannot keep the ligand in the pocket, and with the
 reference's dynamic cutoff 3*sigma_tr+20 A the ligand would drift out of range and the cross graph would
@@ -180,8 +184,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="configs2", choices=sorted(WORKLOADS))
     ap.add_argument("--samples", type=int, default=None, help="poses per complex (per GPU with weak scaling); default: the workload's")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="multi-GPU: weak = 40 poses per GPU; strong = the same 40 poses sharded over the GPUs (BASELINE configs[3])")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="multi-GPU: strong (default) = the same 40 poses sharded over the GPUs (BASELINE configs[3]); weak = 40 poses per GPU")
+    ap.add_argument("--no-serialised-pass", action="store_true",
+                    help="skip the extra one-stream pass behind roofline.serialised (kernel-trace profiles: one launch regime only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lib", default=None, help="path of an alternative libddmi build (kernel A/B experiments)")
     ap.add_argument("--all-atoms", action="store_true",
@@ -228,9 +234,9 @@ def main():
         gathered = [torch.empty(cap * n_lig, 3, device=dev) for _ in range(world)] if world > 1 else None
         jobs.append(dict(model=model, g=g, batch=batch, ids=ids, n_res=n_res, n_lig=n_lig, gathered=gathered, cap=cap))
 
-    def one_step(seed):
+    def one_step(seed, jobs_=None):
         last = None
-        for j in jobs:
+        for j in (jobs if jobs_ is None else jobs_):
             if j["batch"] is not None:
                 pos = j["model"].sample_batch(j["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=seed, sample_ids=j["ids"],
                                               no_final_step_noise=True, **TEMP)
@@ -245,30 +251,53 @@ def main():
             last = pos
         return last
 
+    def timed(steps, jobs_=None):
+        """K steps bracketed by barrier + synchronize on both sides; MAX over the ranks."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for k in range(steps):
+            last = one_step(100 + k, jobs_)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax)
+        return dt_, last
+
     for w in range(args.warmup):
         one_step(w)
+    dt, pos = timed(args.steps)           # the timed region: per-kernel timers off
+    weak_extra = None
+    if strong:
+        # extra key: the weak-scaling figure (every rank its own S poses of each complex), one warm-up + one timed step
+        wjobs = []
+        for j in jobs:
+            dlw = make_pose_list(j["g"], S, tr_sigma_max=cfg.tr_sigma_max, seed=1000 + rank, initial_noise_std_proportion=0.3)
+            wjobs.append(dict(j, batch=HeteroBatch.from_data_list(dlw).to(dev), ids=list(range(rank * S, (rank + 1) * S)), cap=S,
+                              gathered=[torch.empty(S * j["n_lig"], 3, device=dev) for _ in range(world)]))
+        one_step(7, wjobs)
+        dtw, _ = timed(1, wjobs)
+        weak_extra = {"value": world * S * len(jobs) / dtw, "unit": "poses/s", "poses_per_gpu": S * len(jobs), "steps": 1,
+                      "note": "weak scaling: every rank samples its own poses (not the BASELINE configs[3] partition)"}
+        del wjobs
+    # one more, untimed step with the per-kernel HIP-event timers on: phase table and kernel-level roofline figures
     for j in jobs:
         j["model"].set_kernel_timing(True)
-    if world > 1:
-        dist.barrier()
+    one_step(999)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        pos = one_step(100 + k)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
     timings = {}
     for j in jobs:
         for k, (ms, n) in j["model"].kernel_timings().items():
             a = timings.get(k, (0.0, 0))
             timings[k] = (a[0] + ms, a[1] + n)
         j["model"].set_kernel_timing(False)
+    timed_steps = 1                       # steps behind `timings`
     assert os.environ.get("DDMI_BENCH_NOCHECK") or torch.isfinite(pos).all()   # NOCHECK: timing-only ablation builds
 
     if rank == 0:
@@ -285,11 +314,14 @@ def main():
                                   "atom_rec_each_direction": int(m.debug_buffer("ar_goff")[-1]),
                                   "atoms": int(j["batch"]["atom"].pos.shape[0])} if args.all_atoms else {})))
             work += conv_work(cfg, B * j["n_lig"], B * j["n_res"], e_ll, e_lr, e_rr, fused=fused, fused_lig=fused_lig)
-        n_forwards = args.steps * INFERENCE_STEPS * len(jobs)
-        # ---- roofline of the dominant kernel (by HIP-event time inside the timed region)
+        n_forwards = timed_steps * INFERENCE_STEPS * len(jobs)                  # forwards behind `timings`
+        n_forwards_timed = args.steps * INFERENCE_STEPS * len(jobs)             # forwards inside the timed region
+        # ---- roofline of the dominant kernel.  Headline `frac` = the kernel's algorithmic flops of all forwards of the TIMED
+        # region / the region's wall clock / peak: the one figure a driver's own clock can check.  The kernel-level views (launch
+        # durations from the extra timed-with-events step: overlapping with two streams; serialised on one stream) are sub-objects.
         kern = {k: v for k, v in timings.items() if k.startswith("k_") or k == "conv_fc1_gemms"}
         dom = max(kern, key=lambda k: kern[k][0]) if kern else None
-        roof = None
+        roof, roof_scatter = None, None
         if dom in ("k_edge_conv", "k_node_contract", "k_conv_fused") and not args.all_atoms:
             ms, n = kern[dom]
             avg_s = ms / max(n, 1) * 1e-3
@@ -298,45 +330,40 @@ def main():
             flops = sum(w["flops"] for w in w_dom) / n_launch
             ref_flops = sum(w["ref_flops"] for w in w_dom) / n_launch
             bytes_ = sum(w["bytes"] for w in w_dom) / n_launch
-            ridge = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-            traffic, traffic_src = None, None
+            traffic, traffic_src, l2_hit = None, None, None
             if os.path.exists(TRAFFIC_RECORD):        # counter bytes are collected by a separate rocprofv3 --pmc pass (tools/round_profile.sh)
                 rec = json.load(open(TRAFFIC_RECORD))
                 if rec.get("kernel") == dom and rec.get("config") == args.config and args.samples is None and world == 1:
-                    traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
-            if flops / bytes_ > ridge:
-                ach = flops / avg_s / 1e12
-                roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic}
-            else:
-                ach = bytes_ / avg_s / 1e9
-                roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic}
+                    traffic, traffic_src, l2_hit = rec["bytes_per_launch"], rec["source"], rec.get("l2_hit_rate")
+            conv_flops_fwd = sum(w["flops"] for w in w_dom) / len(jobs)                     # per forward of one complex
+            wall_ach = conv_flops_fwd * n_forwards_timed / dt / 1e12                         # TFLOP/s over the timed region
             fwd_ms = timings.get("forward_total", (0.0, 0))[0] / max(n_forwards, 1)
-            conv_flops_fwd = sum(w["flops"] for w in w_dom) / len(jobs)
-            roof.update({"traffic_source": traffic_src, "traffic_unit": "bytes per launch (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE)",
-                         "avg_launch_ms": avg_s * 1e3, "launches": n, "launches_per_forward": n_launch // len(jobs),
-                         "alg_flops_per_launch": flops, "alg_bytes_per_launch": bytes_,
-                         "alg_flops_reference_assoc": ref_flops,
-                         "frac_if_priced_by_reference_assoc": ref_flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         # wall-clock view: this kernel's algorithmic flops of one forward / the forward's HIP-event duration
-                         "wall_frac": (conv_flops_fwd / (fwd_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if fwd_ms > 0 else None,
-                         "forward_ms": fwd_ms,
-                         "concurrent_streams": 1 if os.environ.get("DDMI_STREAMS") == "1" else 2,
-                         "alg_definition": "mean over the launches of this kernel in one forward -- all four edge groups of every "
-                                           "layer (exact f32 on v_mfma_f32_16x16x4_f32, peak = dense f32 MFMA); "
-                                           "k_conv_fused: 2*145*sum(mul_in*mul_out*din) flop per gather node "
-                                           "+ 2*145*NT flop per edge (the re-associated contraction, DESIGN 2: 13x fewer flops than the "
-                                           "reference's association, which alg_flops_reference_assoc prices by SURVEY 8d's formula), "
-                                           "bytes = x rows + 576 B hidden row + 624 B message per edge; "
-                                           "k_edge_conv: 2*145*NT flop/edge, bytes = contracted rows Y (145*NT*4 B per gather node) + "
-                                           "hidden + message rows; k_node_contract: node flops, Y written once.  With 2 streams the "
-                                           "ligand-gather launches run concurrently with the receptor-gather ones, so the launch "
-                                           "durations overlap (their sum exceeds the wall time): `serialised` times the same kernel on "
-                                           "one stream, `wall_frac` uses the forward's own duration"})
-            if roof["concurrent_streams"] == 2 and dom == "k_conv_fused" and world == 1 and len(jobs) == 1:
-                # the same kernel timed with the launches serialised on ONE stream (untimed extra pass, second handle):
-                # with two streams the launch durations overlap, so the figures above understate the kernel alone
+            streams = 1 if os.environ.get("DDMI_STREAMS") == "1" else 2
+            roof = {"kernel": dom, "bound": "mfma", "achieved": wall_ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": wall_ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                    "frac_definition": "algorithmic flops of this kernel in every forward of the timed region / wall clock of the timed "
+                                       "region (all kernels, both streams) / dense f32 MFMA peak",
+                    "traffic_source": traffic_src, "traffic_unit": "bytes per launch (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE)",
+                    "l2_hit_rate": l2_hit,
+                    "launches_per_forward": n_launch // len(jobs), "alg_flops_per_launch": flops, "alg_bytes_per_launch": bytes_,
+                    "alg_flops_reference_assoc": ref_flops,
+                    "forward_ms_timed_region": dt / n_forwards_timed * 1e3, "forward_ms_event_pass": fwd_ms,
+                    "kernel_two_streams" if streams == 2 else "kernel_one_stream": {
+                        "avg_launch_ms": avg_s * 1e3, "launches": n, "achieved": flops / avg_s / 1e12,
+                        "frac": flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                        "note": "HIP events around every launch of one extra untimed step" +
+                                ("; the two streams run launches concurrently, so these durations overlap (their sum exceeds the forward)"
+                                 if streams == 2 else "")},
+                    "alg_definition": "mean over the launches of this kernel in one forward -- all four edge groups of every "
+                                      "layer (exact f32 on v_mfma_f32_16x16x4_f32, peak = dense f32 MFMA); "
+                                      "k_conv_fused: 2*145*sum(mul_in*mul_out*din) flop per gather node "
+                                      "+ 2*145*NT flop per edge (the re-associated contraction, DESIGN 2: 13x fewer flops than the "
+                                      "reference's association, which alg_flops_reference_assoc prices by SURVEY 8d's formula), "
+                                      "bytes = x rows + 576 B hidden row + 624 B message per edge; "
+                                      "k_edge_conv: 2*145*NT flop/edge, bytes = contracted rows Y (145*NT*4 B per gather node) + "
+                                      "hidden + message rows; k_node_contract: node flops, Y written once"}
+            if streams == 2 and dom == "k_conv_fused" and world == 1 and len(jobs) == 1 and not args.no_serialised_pass:
+                # the same kernel timed with the launches serialised on ONE stream (untimed extra pass, second handle)
                 j = jobs[0]
                 os.environ["DDMI_STREAMS"] = "1"
                 m1 = MIScoreModel(cfg, device=str(dev), lib_path=args.lib)
@@ -353,7 +380,34 @@ def main():
                 roof["serialised"] = {"avg_launch_ms": ms1 / max(n1, 1), "launches": n1, "achieved": ach1,
                                       "frac": ach1 / MFMA_F32_PEAK_TFLOPS,
                                       "forward_ms": t1["forward_total"][0] / max(t1["forward_total"][1], 1)}
+                if "k_reduce_bn" in t1:
+                    timings.setdefault("k_reduce_bn_serialised", t1["k_reduce_bn"])
                 del m1
+        if "k_reduce_bn" in timings and not args.all_atoms:
+            # the scatter stage of the path (north_star: HBM GB/s on the gather / scatter): k_reduce_bn reads every message row once
+            # (624 B per edge, fp32), adds the residual row and writes the node row
+            L_ = cfg.num_conv_layers
+            sc_bytes = 0.0
+            for e, j in zip(edges, jobs):
+                nl_, nr_ = B * j["n_lig"], B * j["n_res"]
+                for l in range(L_):
+                    a_, b_ = cfg.layer_irreps(cfg.num_prot_emb_layers + l)
+                    from diffdock_amd.irreps import parse_irreps
+                    d_in, d_out = sum(x.dim for x in parse_irreps(a_)), sum(x.dim for x in parse_irreps(b_))
+                    full = l < L_ - 1
+                    n_edges = e["lig_lig"] + e["cross_each_direction"] * (2 if full else 1) + (e["rec_rec"] if full else 0)
+                    n_nodes = nl_ + (nr_ if full else 0)
+                    sc_bytes += 4.0 * (n_edges * d_out + n_nodes * (d_in + d_out))
+            ms_s, n_s = timings.get("k_reduce_bn_serialised", timings["k_reduce_bn"])
+            per_launch_s = ms_s / max(n_s, 1) * 1e-3
+            per_launch_b = sc_bytes / (L_ * len(jobs))
+            roof_scatter = {"kernel": "k_reduce_bn", "bound": "hbm", "achieved": per_launch_b / per_launch_s / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": per_launch_b / per_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_launch": per_launch_b,
+                            "alg_definition": "per interaction layer: 4 B x (D_out per incoming message of every edge group + D_in + D_out per "
+                                              "target node); mean over the layers; launch durations from HIP events"
+                                              + (" (one stream)" if "k_reduce_bn_serialised" in timings else "")}
+            timings.pop("k_reduce_bn_serialised", None)
         cpu = None
         if not (args.no_cpu_baseline or args.all_atoms or world > 1):     # N = 1 only
             cpu = cpu_baseline(cfg, sd, so3_t, tor_t, jobs[len(jobs) // 2]["g"])
@@ -367,7 +421,7 @@ def main():
                       "poses/sec (20 steps x 40 samples, all-atom score model -- secondary workload)",
             "value": total_poses * args.steps / dt,
             "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl['label']}: DDL-synth score model (ns=48 nv=10 6 layers sh_lmax=1), "
                                    f"{INFERENCE_STEPS} steps x {S} poses per complex, {shape}, cross graph pinned at its upper bound "
@@ -378,7 +432,7 @@ def main():
                        "parallelism": ("single GPU" if world == 1 else
                                        f"strong: the {S} poses of a complex sharded in blocks over {world} GPUs, 1 all_gather per complex" if strong else
                                        f"weak: {S} poses per GPU x {world} GPUs (pose-sharded, 1 all_gather per complex)")},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_scatter": roof_scatter, "cpu_baseline": cpu, "weak_scaling": weak_extra,
             "phase_ms_per_forward": {k: v[0] / max(n_forwards, 1) for k, v in timings.items()},
         }
         print(json.dumps(out))

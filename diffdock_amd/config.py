@@ -172,7 +172,12 @@ def config_from_args(args) -> ModelConfig:
         raise NotImplementedError("get_model arguments outside the built path: " + "; ".join(unsupported))
     # norm_by_sigma is stored by the reference classes and never read in forward (cg_model.py:44): accepted, no effect
     if get("num_prot_emb_layers", 0) > 0 and not get("embed_also_ligand", False):
-        # the reference asserts the same in embedding() (models/cg_model.py:263 "otherwise reimplement padding")
+        if get("all_atoms", False):
+            # AAModel runs this (receptor / atom rows through the embedding layers, ligand rows zero-padded to their width,
+            # models/aa_model.py:351-357); the padded-ligand variant is not built here
+            raise NotImplementedError("all_atoms with num_prot_emb_layers > 0 and embed_also_ligand=False (zero-padded ligand rows, "
+                                      "models/aa_model.py:356) is not built; set embed_also_ligand")
+        # CGModel asserts the same on every forward (models/cg_model.py:263 "otherwise reimplement padding")
         raise NotImplementedError("num_prot_emb_layers > 0 requires embed_also_ligand (models/cg_model.py:263 asserts it)")
     cut = get("rmsd_classification_cutoff", None)
     acut = get("atom_rmsd_classification_cutoff", None)

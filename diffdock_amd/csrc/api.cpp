@@ -192,6 +192,29 @@ int ddmi_wigner_3j(int l1, int l2, int l3, double* out) {
   });
 }
 
+int ddmi_debug_philox(const uint32_t* counters, const uint32_t* keys, int n, uint32_t* host_out) {
+  return guard([&] {
+    DDMI_REQUIRE(counters && keys && host_out && n > 0, DDMI_ERR_ARG, "null argument");
+    unsigned *c = nullptr, *k = nullptr, *o = nullptr;
+    DDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&c), (size_t)n * 16));
+    DDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&k), (size_t)n * 8));
+    DDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&o), (size_t)n * 16));
+    DDMI_CHECK_HIP(hipMemcpy(c, counters, (size_t)n * 16, hipMemcpyHostToDevice));
+    DDMI_CHECK_HIP(hipMemcpy(k, keys, (size_t)n * 8, hipMemcpyHostToDevice));
+    launch_debug_philox(c, k, n, o, nullptr);
+    DDMI_CHECK_HIP(hipDeviceSynchronize());
+    DDMI_CHECK_HIP(hipMemcpy(host_out, o, (size_t)n * 16, hipMemcpyDeviceToHost));
+    (void)hipFree(c); (void)hipFree(k); (void)hipFree(o);
+  });
+}
+
+int ddmi_debug_normal(uint64_t seed, int64_t sample0, int n_samples, int step, int n_comp, float* dev_out, ddmi_stream s) {
+  return guard([&] {
+    DDMI_REQUIRE(dev_out && n_samples > 0 && n_comp > 0, DDMI_ERR_ARG, "bad argument");
+    launch_debug_normal(seed, sample0, n_samples, step, n_comp, dev_out, (hipStream_t)s);
+  });
+}
+
 int ddmi_set_kernel_timing(ddmi_model* h, int enabled) {
   if (!h) return DDMI_ERR_ARG;
   resolve_timings(h->m);

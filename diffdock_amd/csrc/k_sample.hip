@@ -34,6 +34,29 @@ __device__ __forceinline__ float normal_draw(unsigned long long seed, long long 
   return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
+// test entry points: the generator exactly as k_perturb uses it
+__global__ void k_debug_philox(const unsigned* __restrict__ ctr, const unsigned* __restrict__ key, int n, unsigned* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned o[4];
+  philox4x32(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key[2 * i], key[2 * i + 1], o);
+  for (int j = 0; j < 4; ++j) out[4 * i + j] = o[j];
+}
+__global__ void k_debug_normal(unsigned long long seed, long long sample0, int n_samples, int step, int n_comp, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n_samples * n_comp) return;
+  const long long s = i / n_comp;
+  out[i] = normal_draw(seed, sample0 + s, step, (int)(i - s * n_comp));
+}
+void launch_debug_philox(const unsigned* ctr, const unsigned* key, int n, unsigned* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_philox, dim3(cdiv(n, 256)), dim3(256), 0, s, ctr, key, n, out);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+void launch_debug_normal(unsigned long long seed, long long sample0, int n_samples, int step, int n_comp, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_normal, dim3(cdiv((long)n_samples * n_comp, 256)), dim3(256), 0, s, seed, sample0, n_samples, step, n_comp, out);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 __device__ __forceinline__ float mul_add_rn(float cs, float s, float cz, float z) {
 #ifdef DDMI_HIPEMU
   volatile float a = cs * s, b = cz * z;

@@ -263,6 +263,9 @@ struct PerturbArgs {
   int use_rng; unsigned long long seed; const long long* sample_ids; int step;
 };
 void launch_perturb(const PerturbArgs& a, hipStream_t s);
+// test entry points of the noise generator (ddmi_debug_philox / ddmi_debug_normal)
+void launch_debug_philox(const unsigned* ctr, const unsigned* key, int n, unsigned* out, hipStream_t s);
+void launch_debug_normal(unsigned long long seed, long long sample0, int n_samples, int step, int n_comp, float* out, hipStream_t s);
 // t[0..B) = t_tr, t[B..2B) = t_rot, t[2B..3B) = t_tor: the per-graph time vectors of one step (set_time, utils/diffusion_utils.py:35-57)
 void launch_fill_times(float* t, int B, float t_tr, float t_rot, float t_tor, hipStream_t s);
 void launch_modify_conformer(float* pos, int B, int Nl, int R, const int* rot_u, const int* rot_v,

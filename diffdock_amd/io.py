@@ -34,33 +34,53 @@ _Z = {e.upper(): i + 1 for i, e in enumerate(_ELEMENTS)}
 BOND_TYPES = {1: 0, 2: 1, 3: 2, 4: 3}     # SDF bond order -> index in {SINGLE, DOUBLE, TRIPLE, AROMATIC} (process_mols.py:21)
 
 
-def read_pdb_calpha(path):
-    """-> (coords float64 [n,3], residue type index int64 [n], chain ids list[str]) for every residue with a CA atom, in
-    file order; alternate locations other than ' ' / 'A' and HETATM records are skipped."""
-    coords, types, chains, seen = [], [], [], set()
+# modified residues that ProDy's protein selection keeps although they are written as HETATM records
+_HET_RESIDUES = {"MSE", "SEP", "TPO", "PTR", "CSO", "HYP", "MLY", "KCX", "CME", "CSD", "SEC", "PYL"}
+
+
+def _pdb_residues(path):
+    """Residues with a CA atom, in file order: {name, chain, N, CA, C}; alternate locations other than ' ' / 'A' are
+    skipped; HETATM records count only for the modified amino acids ProDy's `protein` selection keeps (MSE, SEP, ...)."""
+    res, order = {}, []
     with open(path) as f:
         for line in f:
-            if not line.startswith("ATOM"):
+            het = line.startswith("HETATM")
+            if not (line.startswith("ATOM") or (het and line[17:20].strip() in _HET_RESIDUES)):
                 continue
-            if line[12:16].strip() != "CA" or line[16] not in (" ", "A"):
+            atom = line[12:16].strip()
+            if atom not in ("N", "CA", "C") or line[16] not in (" ", "A"):
                 continue
             key = (line[21], line[22:27])
-            if key in seen:
-                continue
-            seen.add(key)
-            res = line[17:20].strip()
-            # the reference goes through one-letter codes (pdb.ca.getSequence -> aa_short2long): anything ProDy does not map
-            # to one of the 20 letters becomes 'misc'
-            types.append(POSSIBLE_AMINO_ACIDS.index(res) if res in _STANDARD else len(POSSIBLE_AMINO_ACIDS) - 1)
-            coords.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
-            chains.append(line[21])
-    return np.asarray(coords, dtype=np.float64), np.asarray(types, dtype=np.int64), chains
+            if key not in res:
+                res[key] = {"name": line[17:20].strip(), "chain": line[21]}
+                order.append(key)
+            res[key].setdefault(atom, [float(line[30:38]), float(line[38:46]), float(line[46:54])])
+    return [res[k] for k in order if "CA" in res[k]]
+
+
+def read_pdb_calpha(path):
+    """-> (coords float64 [n,3], residue type index int64 [n], chain ids list[str]) for every residue with a CA atom, in
+    file order."""
+    rs = _pdb_residues(path)
+    # the reference goes through one-letter codes (pdb.ca.getSequence -> aa_short2long): anything ProDy does not map
+    # to one of the 20 letters becomes 'misc'
+    types = [POSSIBLE_AMINO_ACIDS.index(r["name"]) if r["name"] in _STANDARD else len(POSSIBLE_AMINO_ACIDS) - 1 for r in rs]
+    return (np.asarray([r["CA"] for r in rs], dtype=np.float64).reshape(-1, 3), np.asarray(types, dtype=np.int64),
+            [r["chain"] for r in rs])
+
+
+def read_pdb_backbone(path):
+    """-> (N / CA / C coordinates float64 [n, 3, 3] (nan where an atom is missing), residue names) of the same residues."""
+    rs = _pdb_residues(path)
+    nan = [float("nan")] * 3
+    return np.asarray([[r.get("N", nan), r["CA"], r.get("C", nan)] for r in rs], dtype=np.float64).reshape(-1, 3, 3), [r["name"] for r in rs]
 
 
 def receptor_graph(coords, neighbor_cutoff=15.0, max_neighbors=24):
-    """process_mols.py:171-192 (non-kNN branch) on float32 coordinates, scipy-cdist distances in float64 like the reference."""
-    c = np.asarray(coords, dtype=np.float32).astype(np.float64)
-    d = np.sqrt(((c[:, None, :] - c[None, :, :]) ** 2).sum(-1))
+    """process_mols.py:171-192 (non-kNN branch): `torch.cdist` distances in float32 on the float32 (uncentred) coordinates,
+    exactly the reference's call -- neighbour sets at the cutoff and the order of near-ties follow that arithmetic."""
+    d = torch.cdist(torch.as_tensor(np.asarray(coords), dtype=torch.float32), torch.as_tensor(np.asarray(coords), dtype=torch.float32)).numpy()
+    c = d
     src_list, dst_list = [], []
     for i in range(len(c)):
         dst = list(np.where(d[i] < neighbor_cutoff)[0])
@@ -152,15 +172,19 @@ def complex_graph(pdb_path, sdf_path, receptor_radius=15.0, c_alpha_max_neighbor
     inputs (ESM, RDKit); zeros / atomic number only when absent."""
     rc, rtype, _ = read_pdb_calpha(pdb_path)
     lc, z, bonds = read_sdf(sdf_path)
-    center = rc.mean(0, keepdims=True)
     g = HeteroData()
-    rpos = torch.from_numpy((rc - center).astype(np.float32))
+    # the reference builds the graph on the uncentred float32 coordinates (process_mols.py:167-192) and centres afterwards
+    # with a float32 mean (datasets/pdbbind.py:405-416)
+    rpos = torch.from_numpy(rc.astype(np.float32))
+    if lm_embeddings is not None and len(lm_embeddings) != len(rc):
+        raise ValueError(f"{len(lm_embeddings)} language-model embedding rows for {len(rc)} residues with a CA atom")
     lm = torch.zeros(len(rc), lm_dim) if lm_embeddings is None else torch.as_tensor(lm_embeddings, dtype=torch.float32)
     g["receptor"].x = torch.cat([torch.from_numpy(rtype.astype(np.float32))[:, None], lm], 1)
-    g["receptor"].pos = rpos
     g["receptor"].side_chain_vecs = torch.zeros(len(rc), 10)
     g["receptor", "rec_contact", "receptor"].edge_index = torch.from_numpy(
         receptor_graph(rpos.numpy(), receptor_radius, c_alpha_max_neighbors))
+    center = torch.mean(rpos, dim=0, keepdim=True)
+    g["receptor"].pos = rpos - center
     ei, attr = ligand_bond_arrays(bonds)
     if atom_features is None:
         feats = np.zeros((len(z), 16), dtype=np.int64)
@@ -169,11 +193,11 @@ def complex_graph(pdb_path, sdf_path, receptor_radius=15.0, c_alpha_max_neighbor
         feats = np.asarray(atom_features, dtype=np.int64)
     mask_edges, mask_rotate = transformation_mask(len(z), ei)
     g["ligand"].x = torch.from_numpy(feats)
-    g["ligand"].pos = torch.from_numpy((lc - center).astype(np.float32))
+    g["ligand"].pos = torch.from_numpy(lc.astype(np.float32)) - center
     g["ligand"].edge_mask = torch.from_numpy(mask_edges)
     g["ligand"].mask_rotate = [mask_rotate]
     g["ligand", "lig_bond", "ligand"].edge_index = torch.from_numpy(ei)
     g["ligand", "lig_bond", "ligand"].edge_attr = torch.from_numpy(attr)
     g.name = name or "complex"
-    g.original_center = torch.from_numpy(center.astype(np.float32))
+    g.original_center = center
     return g

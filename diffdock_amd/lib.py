@@ -85,6 +85,8 @@ _DECLS = {
     "ddmi_debug_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ddmi_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddmi_wigner_3j": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ddmi_debug_philox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ddmi_debug_normal": (C.c_int, [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ddmi_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ddmi_kernel_timings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

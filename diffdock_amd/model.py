@@ -127,7 +127,7 @@ class MIScoreModel:
         bond, rr = data["ligand", "ligand"], data["receptor", "receptor"]
         ts = [rec.x, rec.pos, lig.x, lig.batch, rec.batch, lig.edge_mask, bond.edge_index, bond.edge_attr, rr.edge_index]
         if self.cfg.all_atoms:
-            ts += [data["atom"].x, data["atom"].pos, data["atom", "atom"].edge_index, data["atom", "receptor"].edge_index]
+            ts += [data["atom"].x, data["atom"].pos, data["atom"].batch, data["atom", "atom"].edge_index, data["atom", "receptor"].edge_index]
         return ts
 
     def _ensure_complex(self, data):
@@ -138,7 +138,10 @@ class MIScoreModel:
         lig, rec = data["ligand"], data["receptor"]
         bond, rr = data["ligand", "ligand"], data["receptor", "receptor"]
         static = self._static_tensors(data)
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in static) + (int(data.num_graphs),)
+        # (tensors created under torch.inference_mode() carry no version counter: their slot of the key is 0)
+        key = tuple((t.data_ptr(), 0 if t.is_inference() else t._version, tuple(t.shape)) for t in static) + (int(data.num_graphs),)
+        mr_obj = getattr(lig, "mask_rotate", None) if hasattr(lig, "mask_rotate") else None
+        key = key + (id(mr_obj), len(mr_obj) if hasattr(mr_obj, "__len__") else -1)    # rotatable-bond masks: identity + length
         same_obj = self._complex_ref is not None and self._complex_ref() is data
         if same_obj and key == self._complex_key:
             return
@@ -334,9 +337,11 @@ def get_model(args, device, t_to_sigma=None, no_parallel=True, confidence_mode=F
         if not cfg.use_old_atom_encoder:
             raise NotImplementedError("CGOldModel with the new AtomEncoder cannot be constructed by the reference either "
                                       "(AtomEncoder has no lm_embedding_type argument)")
-    elif not cfg.embed_also_ligand:
-        # CGModel / AAModel.ligand_embedding asserts it on every forward (models/cg_model.py:263, "otherwise reimplement padding")
-        raise AssertionError("embed_also_ligand must be set for the CGModel / AAModel classes (models/cg_model.py:263)")
+    elif not cfg.embed_also_ligand and not cfg.all_atoms:
+        # CGModel.ligand_embedding asserts it on every forward (models/cg_model.py:263, "otherwise reimplement padding").
+        # AAModel has no such assert: without ligand embedding layers it zero-pads the ligand rows to the receptor width
+        # (models/aa_model.py:351-357) -- a no-op when num_prot_emb_layers == 0, which is the case accepted here (config.py)
+        raise AssertionError("embed_also_ligand must be set for the CGModel class (models/cg_model.py:263)")
     if confidence_mode != cfg.confidence_mode:
         cfg = cfg.replace(confidence_mode=bool(confidence_mode))
     return MIScoreModel(cfg, device=device, lib_path=lib_path)

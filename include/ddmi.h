@@ -179,6 +179,13 @@ int ddmi_debug_shape(ddmi_model* m, const char* name, int64_t shape[4], int* ndi
 int ddmi_debug_read(ddmi_model* m, const char* name, void* host_dst, size_t bytes, ddmi_stream stream);
 /* Real-basis Wigner-3j tensor used for weight pre-packing (host double [(2l1+1)(2l2+1)(2l3+1)]). */
 int ddmi_wigner_3j(int l1, int l2, int l3, double* host_out);
+/* The in-library noise generator of ddmi_sample / ddmi_perturb (noise pointers NULL), exposed for tests: the DEVICE code's
+ * Philox4x32-10 block for `n` (counter[4], key[2]) pairs (host arrays in, host uint32 [n][4] out; Random123 known-answer
+ * vectors), and the standard-normal draws of samples [sample0, sample0 + n_samples) x components [0, n_comp) at one step, as
+ * ddmi_perturb keys them (seed, sample id, step, component) -> device float [n_samples][n_comp].
+ * Replaces torch.normal at utils/sampling.py:140-154 when the caller supplies no draws. */
+int ddmi_debug_philox(const uint32_t* counters, const uint32_t* keys, int n, uint32_t* host_out);
+int ddmi_debug_normal(uint64_t seed, int64_t sample0, int n_samples, int step, int n_comp, float* dev_out, ddmi_stream stream);
 /* Name / duration table of the kernels launched by the last ddmi_forward when timing is on. */
 int ddmi_set_kernel_timing(ddmi_model* m, int enabled);
 int ddmi_kernel_timings(ddmi_model* m, int i, const char** name, double* ms, int64_t* launches);

@@ -16,6 +16,9 @@ input checksums, and the reference's outputs:
                     free-running parity).  Wall time of the reference run is written to profiles/ as the
                     reference-executed CPU baseline of this container.
   fwd_1500_80.pt    one CGModel.forward of BASELINE configs[4] (1500 residues / 80 atoms, every pair a cross edge), NB poses.
+  fwd_300_30_b40.pt one CGModel.forward at bench.py's EXACT default batch (BASELINE configs[2]: 40 poses of the 300-residue /
+                    30-atom complex, seeds of bench.py, static 80 A cross cutoff, default = batch-index-dependent centre
+                    convolution models/cg_model.py:371-374).
   randpos.pt        utils/sampling.randomize_position with its scipy / numpy / torch draws recorded.
 """
 import copy
@@ -79,21 +82,21 @@ def ref_model(cfg, sd):
     return model, args, t_to_sigma
 
 
-def case_traj(n_poses=4, steps=20):
+def case_traj(n_poses=4, steps=20, spec_over=None, out="traj_300_30.pt", profile_json=True):
     from utils import sampling as ref_sampling
     from utils.diffusion_utils import get_t_schedule
     from diffdock_amd.config import DDL_SYNTH
     from diffdock_amd.synth import make_complex, make_pose_list
     from diffdock_amd.weights import init_state_dict
-    from oracle.cg_model import CGModelOracle
     from oracle.sampling import sampling as oracle_sampling
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from util import split_draws, tables
+    from util import oracle_model, split_draws, tables
     spec = dict(cfg_replace=dict(dynamic_max_cross=False, cross_max_distance=80.0), n_res=300, n_lig=30, complex_seed=0,
                 pose_seed=1000, noise_prop=0.3, weight_seed=1234, n_poses=n_poses, steps=steps)
+    spec.update(spec_over or {})
     cfg = DDL_SYNTH.replace(**spec["cfg_replace"])
     sd = init_state_dict(cfg, seed=spec["weight_seed"])
-    g = make_complex(seed=spec["complex_seed"], n_res=spec["n_res"], n_lig=spec["n_lig"])
+    g = make_complex(seed=spec["complex_seed"], n_res=spec["n_res"], n_lig=spec["n_lig"], all_atoms=cfg.all_atoms)
     dl = make_pose_list(g, n_poses, tr_sigma_max=cfg.tr_sigma_max, seed=spec["pose_seed"],
                         initial_noise_std_proportion=spec["noise_prop"])
     model, args, t_to_sigma = ref_model(cfg, sd)
@@ -126,8 +129,9 @@ def case_traj(n_poses=4, steps=20):
               init_pos=torch.stack([d["ligand"].pos for d in dl]),
               checks=dict(state_dict=checksum(sd), graph=checksum(graph_tensors(g))),
               reference_wall_s=wall, reference_cores=os.cpu_count(), torch=torch.__version__)
-    torch.save(fx, os.path.join(HERE, "traj_300_30.pt"))     # reference part first; the float64 yardstick is added below
-    with open(os.path.join(ROOT, "profiles", "r02_cpu_reference_executed.json"), "w") as f:
+    torch.save(fx, os.path.join(HERE, out))     # reference part first; the float64 yardstick is added below
+    if profile_json:
+      with open(os.path.join(ROOT, "profiles", "r02_cpu_reference_executed.json"), "w") as f:
         json.dump({"what": "reference utils/sampling.sampling + models/cg_model.CGModel (FasterTensorProduct conv layers) executed "
                            "under tests/golden/make_golden.py's third-party stand-ins, DDL-synth width, 300 residues / 30 atoms, "
                            "all-pairs cross graph", "poses": n_poses, "steps": steps, "wall_s": wall,
@@ -137,11 +141,13 @@ def case_traj(n_poses=4, steps=20):
     R = int(dl[0]["ligand"].edge_mask.sum())
     noise = split_draws(draws, steps, n_poses, R)
     so3_t, tor_t = tables()
-    o64 = CGModelOracle(cfg, sd, so3_t, tor_t, dtype=torch.float64)
+    o64 = oracle_model(cfg, sd, so3_t, tor_t, dtype=torch.float64)
     dl64 = copy.deepcopy(dl)
     for d in dl64:
         d["ligand"].pos = d["ligand"].pos.double()
         d["receptor"].pos = d["receptor"].pos.double()
+        if cfg.all_atoms:
+            d["atom"].pos = d["atom"].pos.double()
     n64 = tuple(z.double() for z in noise)
     rec64 = []
     out64 = oracle_sampling(dl64, o64, steps, cfg, n64, schedules=(sched, sched, sched), batch_size=n_poses,
@@ -150,17 +156,18 @@ def case_traj(n_poses=4, steps=20):
     rmsd64 = ((final64 - final.double()) ** 2).sum(-1).mean(-1).sqrt()
     print("final-pose RMSD float32 reference vs float64 oracle:", rmsd64.tolist(), flush=True)
     fx.update(final_pos_f64=final64, steps_f64=[dict(pos_in=r["pos_in"], tr=r["tr"], rot=r["rot"], tor=r["tor"]) for r in rec64])
-    torch.save(fx, os.path.join(HERE, "traj_300_30.pt"))
+    torch.save(fx, os.path.join(HERE, out))
 
 
-def case_big(n_poses=1):
+def case_big(n_poses=1, spec=None, out="fwd_1500_80.pt"):
     from utils.diffusion_utils import set_time
     from diffdock_amd.config import DDL_SYNTH
     from diffdock_amd.hetero import HeteroBatch
     from diffdock_amd.synth import make_complex, make_pose_list
     from diffdock_amd.weights import init_state_dict
-    spec = dict(cfg_replace=dict(dynamic_max_cross=False, cross_max_distance=80.0), n_res=1500, n_lig=80, complex_seed=8,
-                pose_seed=9, noise_prop=0.1, weight_seed=1234, n_poses=n_poses, t=0.5)
+    spec = spec or dict(cfg_replace=dict(dynamic_max_cross=False, cross_max_distance=80.0), n_res=1500, n_lig=80, complex_seed=8,
+                        pose_seed=9, noise_prop=0.1, weight_seed=1234, n_poses=n_poses, t=0.5)
+    n_poses = spec["n_poses"]
     cfg = DDL_SYNTH.replace(**spec["cfg_replace"])
     sd = init_state_dict(cfg, seed=spec["weight_seed"])
     g = make_complex(seed=spec["complex_seed"], n_res=spec["n_res"], n_lig=spec["n_lig"])
@@ -177,10 +184,10 @@ def case_big(n_poses=1):
         tr, rot, tor = model(batch)[:3]
     for h in hooks:
         h.remove()
-    print(f"reference forward 1500/80 x {n_poses}: {time.time() - t0:.1f} s", flush=True)
+    print(f"reference forward {spec['n_res']}/{spec['n_lig']} x {n_poses}: {time.time() - t0:.1f} s", flush=True)
     torch.save(dict(spec=spec, tr=tr, rot=rot, tor=tor, lig_rows=layer_out,
                     checks=dict(state_dict=checksum(sd), graph=checksum(graph_tensors(g))), torch=torch.__version__),
-               os.path.join(HERE, "fwd_1500_80.pt"))
+               os.path.join(HERE, out))
     print("tr", tr.tolist(), "tor[:4]", tor[:4].tolist())
 
 
@@ -235,5 +242,18 @@ if __name__ == "__main__":
         case_randpos()
     if "traj" in which:
         case_traj(n_poses=int(os.environ.get("TRAJ_POSES", 4)))
+    if "aatraj" in which:   # all-atom model (models/aa_model.py): 20-step trajectory, 100 residues with their heavy atoms, 30-atom ligand;
+                            # sh_lmax = 2: the reference FasterTensorProduct cannot run a step in which no ligand atom has a receptor atom in reach
+        case_traj(n_poses=int(os.environ.get("TRAJ_POSES", 4)), out="traj_aa_100_30.pt", profile_json=False,
+                  spec_over=dict(cfg_replace=dict(dynamic_max_cross=False, cross_max_distance=80.0, all_atoms=True, sh_lmax=2), n_res=100, n_lig=30,
+                                 complex_seed=3, pose_seed=1003))
     if "big" in which:
         case_big(n_poses=int(os.environ.get("BIG_POSES", 1)))
+    if "b40" in which:   # bench.py's default workload: same seeds (complex 0, poses 1000, weights 1234), 40 poses, one forward
+        case_big(spec=dict(cfg_replace=dict(dynamic_max_cross=False, cross_max_distance=80.0), n_res=300, n_lig=30, complex_seed=0,
+                           pose_seed=1000, noise_prop=0.3, weight_seed=1234, n_poses=40, t=0.7), out="fwd_300_30_b40.pt")
+        fx = torch.load(os.path.join(HERE, "fwd_300_30_b40.pt"), weights_only=False)     # keep the ligand rows of the first and the last pose only
+        rows = torch.cat([torch.arange(0, 30), torch.arange(39 * 30, 40 * 30)])
+        fx["lig_rows_idx"] = rows
+        fx["lig_rows"] = [r[rows].clone() for r in fx["lig_rows"]]
+        torch.save(fx, os.path.join(HERE, "fwd_300_30_b40.pt"))

@@ -54,7 +54,14 @@ def test_load_state_dict_accepts_the_reference_modules_unfiltered_keys(make):
     for k in ("confidence_predictor.1.num_batches_tracked", "confidence_predictor.5.num_batches_tracked",
               "atom_confidence_predictor.1.num_batches_tracked", "atom_confidence_predictor.5.num_batches_tracked"):
         full[k] = torch.tensor(123)
-    full["conv_layers.0.tp.output_mask"] = torch.ones(4)
+    # e3nn 0.5 o3.TensorProduct registers `output_mask` on the module and its w3j constants on the code-generated
+    # submodules (`_compiled_main_left_right`, `_compiled_main_right`), here for every TensorProduct the class owns
+    for mod, d_out in (("conv_layers.0.tp", 20), ("conv_layers.2.tp", 28), ("final_conv.tp", 12), ("tor_bond_conv.tp", 2 * cfg.ns),
+                       ("final_tp_tor", 20)):
+        full[f"{mod}.output_mask"] = torch.ones(d_out)
+        full[f"{mod}._compiled_main_left_right._w3j_1_1_0"] = torch.ones(3, 3, 1)
+        full[f"{mod}._compiled_main_left_right._w3j_1_1_2"] = torch.ones(3, 3, 5)
+        full[f"{mod}._compiled_main_right._w3j_0_1_1"] = torch.ones(1, 3, 3)
     full["final_tp_tor.w3j_0_1_2"] = torch.ones(3)
     m = MIScoreModel(cfg, device="cpu", lib_path=EMU)
     m.load_state_dict(full, strict=True)

@@ -85,6 +85,40 @@ def test_twenty_step_free_running_rmsd_to_reference_execution(traj):
     assert float(rmsd(pos2, pos).max()) <= max(3.0 * float(yard.max()), 1e-3)
 
 
+def test_all_atom_twenty_step_trajectory_matches_reference_execution():
+    """models/aa_model.py through the reference's own sampling(): 20 steps x 4 poses, 100 residues with their heavy atoms
+    (~750 atom nodes), 30-atom ligand, DDL-synth widths with sh_lmax = 2 (the reference FasterTensorProduct cannot run a step
+    in which no ligand atom has a receptor atom within reach).  Teacher-forced scores of every step within the 1e-4 bound, the
+    free-running final poses within 3x the trajectory's own float32 / float64 rounding yardstick."""
+    fx = load_fixture("traj_aa_100_30")
+    cfg, sd, g, dl = seeded_case(fx["spec"])
+    check_seeded_inputs(fx, sd, g)
+    assert cfg.all_atoms and g["atom"].pos.shape[0] > 500
+    assert torch.equal(torch.stack([d["ligand"].pos for d in dl]), fx["init_pos"])
+    m = gpu_model(cfg, sd)
+    B, steps = fx["spec"]["n_poses"], fx["spec"]["steps"]
+    sched = get_t_schedule(steps)
+    batch = place(HeteroBatch.from_data_list(dl))
+    worst = {"tr": 0.0, "rot": 0.0, "tor": 0.0}
+    for k, rec in enumerate(fx["steps"]):
+        set_time(batch, sched[k], sched[k], sched[k], B, device=DEV)
+        batch["ligand"].pos = rec["pos_in"].to(DEV)
+        out = m(batch)[:3]
+        assert_scores_close(out, (rec["tr"], rec["rot"], rec["tor"]), what=f"all-atom step {k}")
+        for o, n in zip(out, ("tr", "rot", "tor")):
+            worst[n] = max(worst[n], elem_excess(o.cpu(), rec[n]))
+    print("all-atom teacher-forced worst element-wise excess (1.0 = at the 1e-4 bound):", worst)
+    R = int(dl[0]["ligand"].edge_mask.sum())
+    noise = split_draws(fx["draws"], steps, B, R)
+    yard = rmsd(fx["final_pos_f64"], fx["final_pos"])
+    pos = m.sample_batch(place(HeteroBatch.from_data_list(dl)), steps, (sched, sched, sched), noise=noise,
+                         no_final_step_noise=True, **fx["temp"]).cpu().reshape(B, -1, 3)
+    r = rmsd(pos, fx["final_pos"])
+    print("all-atom final-pose RMSD to the reference run [A]:", [f"{x:.2e}" for x in r.tolist()],
+          " yardstick:", [f"{x:.2e}" for x in yard.tolist()])
+    assert torch.isfinite(pos).all() and float(r.max()) <= max(3.0 * float(yard.max()), 5e-4)
+
+
 def test_large_pocket_forward_matches_reference_execution():
     """BASELINE configs[4] shape: 1500 residues / 80 atoms, 120 000 cross edges per pose and direction, through the
     reference's own CGModel.forward (its per-edge weights [E, 6928] materialised on the host, 2 poses)."""
@@ -101,6 +135,28 @@ def test_large_pocket_forward_matches_reference_execution():
     nl = B * 80
     for l, ref_rows in enumerate(fx["lig_rows"]):             # ligand rows of every interaction layer
         mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))[:nl, :ref_rows.shape[1]]
+        assert rel_err(mine, ref_rows) < 1e-4 and elem_excess(mine, ref_rows) <= 1.0, l
+
+
+def test_bench_batch_forward_matches_reference_execution():
+    """bench.py's EXACT default batch (BASELINE configs[2]: 40 poses of the 300-residue / 30-atom complex, bench.py's seeds,
+    static 80 A cross cutoff, the default batch-index-dependent centre convolution of models/cg_model.py:371-374) through
+    the reference's own CGModel.forward: scores of all 40 poses and the ligand rows of every interaction layer for the first
+    and the last pose."""
+    fx = load_fixture("fwd_300_30_b40")
+    cfg, sd, g, dl = seeded_case(fx["spec"])
+    check_seeded_inputs(fx, sd, g)
+    B, t = fx["spec"]["n_poses"], fx["spec"]["t"]
+    assert B == 40 and not cfg.fixed_center_conv
+    m = gpu_model(cfg, sd)
+    batch = HeteroBatch.from_data_list(dl)
+    set_time(batch, t, t, t, B)
+    out = m(place(batch))[:3]
+    assert int(m.debug_buffer("offs_l")[-1]) == B * 30 * 300
+    assert_scores_close(out, (fx["tr"], fx["rot"], fx["tor"]), what="300/30 x 40")
+    rows = fx["lig_rows_idx"]
+    for l, ref_rows in enumerate(fx["lig_rows"]):
+        mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))[rows, :ref_rows.shape[1]]
         assert rel_err(mine, ref_rows) < 1e-4 and elem_excess(mine, ref_rows) <= 1.0, l
 
 

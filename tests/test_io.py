@@ -31,12 +31,18 @@ def test_fixture_has_the_documented_sizes():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="the reference's data directory exists only in the build container")
-def test_parsing_the_reference_files_reproduces_the_fixture():
+def test_io_reproduces_the_reference_executed_fixture_bit_for_bit():
+    """diffdock_amd.io against the fixture whose receptor graph / features / positions and rotatable-bond masks were produced
+    by EXECUTING the reference (datasets/process_mols.py new_extract_receptor_structure, utils/torsion.py
+    get_transformation_mask, the centring of datasets/pdbbind.py; tests/golden/make_1a0q.py)."""
     g = complex_graph(f"{REF_DATA}/1a0q_protein_processed.pdb", f"{REF_DATA}/1a0q_ligand.sdf", lm_dim=0)
     d = load_fixture("1a0q_graph")
+    assert "process_mols.py new_extract_receptor_structure executed" in d["provenance"]
     assert torch.equal(g["receptor"].pos, d["rec_pos"]) and torch.equal(g["receptor", "receptor"].edge_index, d["rec_edge_index"])
+    assert torch.equal(g["receptor"].x, d["rec_x"]) and torch.equal(g.original_center, d["original_center"])
     assert torch.equal(g["ligand"].pos, d["lig_pos"]) and torch.equal(g["ligand", "ligand"].edge_index, d["bond_index"])
     assert torch.equal(g["ligand"].edge_mask, d["edge_mask"])
+    assert np.array_equal(np.asarray(g["ligand"].mask_rotate[0]), d["mask_rotate"].numpy())
     xyz, z, bonds = read_sdf(f"{REF_DATA}/1a0q_ligand.sdf", remove_hs=False)
     assert len(z) == 45 and int((z == 1).sum()) == 22 and len(bonds) == 45
 
@@ -50,7 +56,7 @@ def test_graph_builders_agree_with_the_synthetic_generators():
         me, mr = transformation_mask(22 + seed, ei)
         assert np.array_equal(me, c["ligand"].edge_mask.numpy()) and np.array_equal(mr, c["ligand"].mask_rotate[0])
         rc = c["receptor"].pos.numpy()
-        a, b = receptor_graph(rc, 15.0, 24), receptor_contact_graph(rc, 15.0, 24)   # float64 (scipy cdist) vs float32 distances
+        a, b = receptor_graph(rc, 15.0, 24), receptor_contact_graph(rc, 15.0, 24)   # torch.cdist float32 vs the generator's distances
         assert a.shape == b.shape and np.array_equal(a[1], b[1])
         sets = lambda e: [frozenset(e[0][e[1] == i]) for i in range(len(rc))]     # order inside exact ties (3.8 A chain steps) is free
         assert sum(x != y for x, y in zip(sets(a), sets(b))) <= 1

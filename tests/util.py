@@ -115,7 +115,7 @@ def seeded_case(spec):
     from diffdock_amd.weights import init_state_dict
     cfg = DDL_SYNTH.replace(**spec["cfg_replace"])
     sd = init_state_dict(cfg, seed=spec["weight_seed"])
-    g = make_complex(seed=spec["complex_seed"], n_res=spec["n_res"], n_lig=spec["n_lig"])
+    g = make_complex(seed=spec["complex_seed"], n_res=spec["n_res"], n_lig=spec["n_lig"], all_atoms=cfg.all_atoms)
     dl = make_pose_list(g, spec["n_poses"], tr_sigma_max=cfg.tr_sigma_max, seed=spec["pose_seed"],
                         initial_noise_std_proportion=spec["noise_prop"])
     return cfg, sd, g, dl

@@ -9,18 +9,20 @@ cd $GRAFT_REPO_ROOT
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/${tag}_smoke.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 # counters first (the default bench line then picks up profiles/traffic_latest.json of THIS build)
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/kt.log 2>&1
+# (one launch regime in the kernel stats: the extra one-stream pass behind roofline.serialised is switched off here)
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-serialised-pass > /tmp/kt.log 2>&1
 python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/prof_kt -name "*.db" | head -1) > $out/${tag}_rocprof_kernel_stats.txt 2>&1
 tail -1 /tmp/kt.log >> $out/${tag}_rocprof_kernel_stats.txt
 : > $out/${tag}_pmc_summary.txt
 i=0
-for p in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
+for p in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  DDMI_STREAMS=1 rocprofv3 --kernel-trace --pmc $p -d /tmp/pmc$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/pmc$i.log 2>&1
+  DDMI_STREAMS=1 rocprofv3 --kernel-trace --pmc $p -d /tmp/pmc$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-serialised-pass > /tmp/pmc$i.log 2>&1
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(find /tmp/pmc$i -name "*.db" | head -1) >> $out/${tag}_pmc_summary.txt 2>&1
 done
 python $GRAFT_REPO_ROOT/tools/traffic_json.py $(find /tmp/pmc3 -name "*.db" | head -1) $(find /tmp/pmc4 -name "*.db" | head -1) k_conv_fused configs2 \
-  "profiles/${tag}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernels serialised on one stream)" > $out/${tag}_traffic.json 2>> $out/${tag}_pmc_summary.txt
+  "profiles/${tag}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT+TCC_MISS passes, kernels serialised on one stream)" \
+  $(find /tmp/pmc5 -name "*.db" | head -1) > $out/${tag}_traffic.json 2>> $out/${tag}_pmc_summary.txt
 cp $out/${tag}_traffic.json $GRAFT_REPO_ROOT/profiles/traffic_latest.json
 cd $GRAFT_REPO_ROOT
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
