@@ -647,6 +647,7 @@ constexpr int FC_MAXG = 24;                    // granule descriptors kept in LD
 // (YROW = 8 mod 16, YVN = 4 mod 8).
 template <int NBK> struct FcDim {
   static constexpr int YROW = 16 * NBK + 8, YVN = FC_KC * YROW + 4, YB = FC_VN * YVN;
+  static constexpr int BST = 16 * NBK + 12;   // row stride of the bias rows [16 nodes][16 * NBK] (kept in the coupling scratch during a main loop)
 };
 
 // k-invariant per-lane part of one slot chain: uniform weight base + 32-bit lane offset (scalar-base global loads)
@@ -824,8 +825,8 @@ template <int NBK, int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3>
 __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
                                                   int KS, int HK, int NG8, int wave, int lane,
                                                   const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr,
-                                                  const float* yrd, FcProf& pf) {
-  constexpr int FC_YROW = FcDim<NBK>::YROW, FC_YVN = FcDim<NBK>::YVN, FC_YB = FcDim<NBK>::YB;
+                                                  const float* yrd, FcProf& pf, float* brow) {
+  constexpr int FC_YROW = FcDim<NBK>::YROW, FC_YVN = FcDim<NBK>::YVN, FC_YB = FcDim<NBK>::YB, BST = FcDim<NBK>::BST;
   // sparse rows (!DENSE): the second 16-row tile of a virtual node with <= 16 edges is neither fetched nor multiplied
   const bool two[2] = {DENSE || vne[0] > 16, DENSE || vne[1] > 16};
   using O = FcOrder<S0, SN, NLV>;
@@ -949,9 +950,49 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   fc_sfor<0, NL>(loadw);
 #pragma unroll
   for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
+  // The bias row of the packed second layer (k = H, hidden value 1 for every edge) rides along with the prologue: wave t
+  // contracts slot t with it and leaves the 16 x 16 result in the bias rows; after the barrier every accumulator STARTS from
+  // its node's bias value.  (No separate phase behind the main loop: that one exposed an L2 round trip, a dependent MFMA chain
+  // and two barriers per granule.)
+  constexpr int NSLOT = SN == 0 ? 1 : 1 + NLV;                       // live slots
+  int lane_b = lane;
+  DDMI_OPAQUE(lane_b);                                               // (addresses of the bias rows are not hoisted out of the granule loop)
+  float bb[S0 > 3 ? S0 : 3];
+  const unsigned hrow = (unsigned)(HK - 1) * (unsigned)KS * 4u - (unsigned)wave * (unsigned)KS * 4u;   // row H instead of row `wave`
+  fc_sfor<0, NSLOT>([&](auto tc) {
+    constexpr int t = decltype(tc)::value, ws = wsl(t);
+    if (wave == t) {
+      if constexpr (ws == 0 && S0 >= 4) {
+#pragma unroll
+        for (int i = 0; i < S0 / 4; ++i) {
+          const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0] + hrow);
+          bb[4 * i] = v.x; bb[4 * i + 1] = v.y; bb[4 * i + 2] = v.z; bb[4 * i + 3] = v.w;
+        }
+      } else {
+        const float3 v = fc_buf_ld3(wbuf, lo[ws], woff[ws] + hrow);
+        bb[0] = v.x; bb[1] = v.y; bb[2] = v.z;
+      }
+    }
+  });
 #pragma unroll
   for (int t = 0; t < 4; ++t) woff[t] += gstep;
   hoff += 1024u;
+  fc_sfor<0, NSLOT>([&](auto tc) {   // bias chains (two accumulators for the long one: a dependent f32 MFMA waits 40 cycles)
+    constexpr int t = decltype(tc)::value, LEN = t == 0 ? S0 : SN;
+    if (wave == t) {
+      f32x4 ba = f32x4{0.f, 0.f, 0.f, 0.f}, bq = f32x4{0.f, 0.f, 0.f, 0.f};
+      fc_sfor<0, NC>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (O::slot(i) == t) {
+          constexpr int j = O::step(i);
+          if constexpr (LEN > 3 && (j & 1)) bq = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bb[j], bq, 0, 0, 0);
+          else ba = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bb[j], ba, 0, 0, 0);
+        }
+      });
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) brow[(4 * (lane_b >> 4) + rr) * BST + 16 * t + (lane_b & 15)] = ba[rr] + bq[rr];
+    }
+  });
 #pragma unroll
   for (int t = 0; t < 4; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   fc_sfor<0, NC>([&](auto ic) {
@@ -965,6 +1006,16 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
 #pragma unroll
   for (int t = 0; t < 4; ++t) woff[t] += gstep;
   __syncthreads();
+#pragma unroll
+  for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      const float b = brow[(2 * wave + vi) * BST + 16 * c + (lane_b & 15)];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[vi][rt][c][rr] += b;
+    }
   FC_STAMP(pf, 2);
   for (int g = 0; g + 2 < NG8; g += 2) {   // pairs with a successor pair
     step(T{}, T{}, T{}, Even{});
@@ -1026,8 +1077,8 @@ template <int NBK, int S0, int NG, bool DENSE>
 __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], const FcPackRt& P, const float* __restrict__ wpack,
                                                    int KS, int HK, int NG8, int wave, int lane,
                                                    const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr0,
-                                                   const float* yrd, FcProf& pf) {
-  constexpr int FC_YROW = FcDim<NBK>::YROW, FC_YVN = FcDim<NBK>::YVN, FC_YB = FcDim<NBK>::YB;
+                                                   const float* yrd, FcProf& pf, float* brow) {
+  constexpr int FC_YROW = FcDim<NBK>::YROW, FC_YVN = FcDim<NBK>::YVN, FC_YB = FcDim<NBK>::YB, BST = FcDim<NBK>::BST;
   using O = FcPackOrder<S0, NG>;
   constexpr int C0 = O::C0, NS = C0 + 3 * NG, NB = (NS + 1) / 2 + 1, NC = O::NC;
   static_assert(NB <= NBK, "column blocks of the granule exceed the chunk buffer");
@@ -1171,9 +1222,51 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
   fc_sfor<0, NL>(loadw);
 #pragma unroll
   for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
+  // bias row (k = H) with the prologue: wave t contracts slot t, every accumulator starts from its node's bias (fc_mainloop_dense)
+  float bb[S0 > 3 ? S0 : 3];
+  int lane_b = lane;
+  DDMI_OPAQUE(lane_b);
+  const int lr_b = lane_b & 15;
+  const int cb_b = lr_b < 8 ? lr_b : lr_b < 10 ? 16 * (NB - 1) + lr_b - 8 : 16 * NBK + lr_b - 10, cs_b = lr_b < 8 ? 8 : lr_b < 10 ? 2 : 0;
+  const unsigned hrow = (unsigned)(HK - 1) * (unsigned)KS * 4u - (unsigned)wave * (unsigned)KS * 4u;
+  fc_sfor<0, NS>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if (wave == t) {
+      if constexpr (C0 == 1 && t == 0) {
+#pragma unroll
+        for (int i = 0; i < S0 / 4; ++i) {
+          const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0] + hrow);
+          bb[4 * i] = v.x; bb[4 * i + 1] = v.y; bb[4 * i + 2] = v.z; bb[4 * i + 3] = v.w;
+        }
+      } else {
+        constexpr int g = (t - C0) / 3;
+        const float3 v = fc_buf_ld3(wbuf, lo[1 + g], woff[1 + g] + hrow);
+        bb[0] = v.x; bb[1] = v.y; bb[2] = v.z;
+      }
+    }
+  });
 #pragma unroll
   for (int t = 0; t < 1 + NG; ++t) woff[t] += gstep;
   hoff += 1024u;
+  fc_sfor<0, NS>([&](auto tc) {   // bias chains
+    constexpr int t = decltype(tc)::value;
+    if (wave == t) {
+      f32x4 ba = f32x4{0.f, 0.f, 0.f, 0.f}, bq = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (C0 == 1 && t == 0) {
+#pragma unroll
+        for (int j = 0; j < S0; j += 2) {
+          ba = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0[j], bb[j], ba, 0, 0, 0);
+          bq = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0[j + 1], bb[j + 1], bq, 0, 0, 0);
+        }
+      } else {
+        constexpr int g = (t - C0) / 3, comp = (t - C0) % 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ba = __builtin_amdgcn_mfma_f32_16x16x4f32(P.xg[g][comp + 12 * j], bb[j], ba, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) brow[(4 * (lane_b >> 4) + rr) * BST + cb_b + cs_b * t] = ba[rr] + bq[rr];
+    }
+  });
 #pragma unroll
   for (int t = 0; t < NS; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   fc_sfor<0, XW>(xread);
@@ -1187,6 +1280,16 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
   for (int t = 0; t < 1 + NG; ++t) woff[t] += gstep;
   fc_sfor<0, XW>(xread);   // window of the first in-loop contraction
   __syncthreads();
+#pragma unroll
+  for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const float b = brow[(2 * wave + vi) * BST + 16 * c + (lane_b & 15)];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[vi][rt][c][rr] += b;
+    }
   FC_STAMP(pf, 2);
   for (int g = 0; g + 2 < NG8; g += 2) {
     step(T{}, T{}, T{}, Even{});
@@ -1326,18 +1429,11 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         const FcPackRt P = fc_pack_setup(Gd, xbuf, lr, lq);
         FC_STAMP(pf, 1);
         constexpr bool DN = MODE == 3;
-#define FC_MLP(S0_, NG_) fc_mainloop_packed<NBK, S0_, NG_, DN>(acc, P, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr0, yrd, pf)
+#define FC_MLP(S0_, NG_) fc_mainloop_packed<NBK, S0_, NG_, DN>(acc, P, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr0, yrd, pf, gscr)
         if constexpr (NBK >= 5) { if (Gd.shape == 4) FC_MLP(12, 2); }
         if (Gd.shape == 5) FC_MLP(0, 2);
         else if (Gd.shape == 6) FC_MLP(12, 1);
 #undef FC_MLP
-        // ---- bias row (k = H, h = 1): wave s contracts slot s
-        if (wave < Gd.nslot && !DDMI_ABL(a.dbg, 64)) {
-          const FcSlotRt sb = fc_slot_setup(Gd.slot[wave], a.wpack, xbuf, 0, lr, lq);
-          const f32x4 rb = fc_direct(sb, (size_t)H * a.KS);
-          const int col = lr < 8 ? 8 * wave + lr : lr < 10 ? 16 * (NB - 1) + 2 * wave + lr - 8 : 16 * NBK + lr - 10;
-          fc_store<NBK>(ybuf + (4 * lq) * FC_YVN + col, 0, rb);    // row 0 of buffer 0
-        }
       } else {
       const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq);
       const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
@@ -1347,7 +1443,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         constexpr bool DN = MODE == 3;
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
         FC_STAMP(pf, 1);
-#define FC_ML(S0_, SN_, DUP_, NLV_) fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd, pf)
+#define FC_ML(S0_, SN_, DUP_, NLV_) fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd, pf, gscr)
         int dup, nlv;
         fc_variant(Gd, dup, nlv);
         if (Gd.shape == 1 && dup == 1 && nlv == 3) FC_ML(12, 3, 1, 3);
@@ -1435,26 +1531,27 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
           for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
       }
       }
-      // ---- bias row (k = H, h = 1): waves 0..3 contract one slot each, every edge row receives the node's bias row
-      if (wave < 4 && !DDMI_ABL(a.dbg, 64)) {
-        const FcSlotRt sb = fc_slot_setup(Gd.slot[wave], a.wpack, xbuf, Gd.w0, lr, lq);   // (set up again: nothing of the main loop's slots stays live)
-        const f32x4 rb = fc_direct(sb, (size_t)H * a.KS);
-        fc_store<NBK>(ybuf + (4 * lq) * FC_YVN + lr, 16 * wave, rb);    // row 0 of buffer 0
-      }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int vi = 0; vi < 2; ++vi) {
-        const float* __restrict__ yb = ybuf + (2 * wave + vi) * FC_YVN + lr;
-#pragma unroll
-        for (int c = 0; c < NBK; ++c) {
-          if (c >= NB) break;
-          const float b = yb[16 * c];
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[vi][rt][c][r] += b;
+      if (MODE == 1) {   // generic loop: the bias row (k = H, h = 1) behind the main loop -- waves 0..3 contract one slot each,
+                         // every edge row receives the node's bias row (the static loops take it along in their prologue)
+        if (wave < 4) {
+          const FcSlotRt sb = fc_slot_setup(Gd.slot[wave], a.wpack, xbuf, Gd.w0, lr, lq);
+          const f32x4 rb = fc_direct(sb, (size_t)H * a.KS);
+          fc_store<NBK>(ybuf + (4 * lq) * FC_YVN + lr, 16 * wave, rb);    // row 0 of buffer 0
         }
+        __syncthreads();
+#pragma unroll
+        for (int vi = 0; vi < 2; ++vi) {
+          const float* __restrict__ yb = ybuf + (2 * wave + vi) * FC_YVN + lr;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float b = yb[16 * c];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[vi][rt][c][r] += b;
+          }
+        }
+      }
       }
     }
     FC_STAMP(pf, 4);
