@@ -893,7 +893,15 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   static_assert(NCB <= NBK, "column blocks of the granule exceed the chunk buffer");
   // one chunk step (chunk g = 2 * pair + ODD): contraction of chunk g+1 into buffer ODD ^ 1 (DO_C), weight requests for
   // chunk g+2 (DO_W), hidden rows of the next pair of chunks (DO_H), edge product of chunk g out of buffer ODD
-  auto step = [&](auto do_c, auto do_w, auto do_h, auto odd) __attribute__((always_inline)) {
+  auto roll = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+  };
+  // (do_roll: the hidden rows requested during the previous pair become the current ones BEHIND this step's contraction --
+  // the copy is where the compiler waits for those slow requests, and the contraction does not need them)
+  auto step = [&](auto do_c, auto do_w, auto do_h, auto odd, auto do_roll) __attribute__((always_inline)) {
     constexpr bool DO_C = decltype(do_c)::value, DO_W = decltype(do_w)::value, DO_H = decltype(do_h)::value;
     constexpr int ODD = decltype(odd)::value, eb = ODD, cb = ODD ^ 1;
     if constexpr (DO_C) {
@@ -909,6 +917,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
     } else {
       readq(0, eb, 0);
     }
+    if constexpr (decltype(do_roll)::value) { roll(); DDMI_SCHED_FENCE(); }
     static_assert(NE >= 2 * NL && NE >= NP + 2, "edge-product slots for the weight requests and the row stores");
     fc_sfor<0, NE>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
@@ -935,12 +944,6 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       for (int t = 0; t < 4; ++t) woff[t] += gstep;
     }
     if constexpr (DO_H) hoff += 1024u;
-  };
-  auto roll = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int vi = 0; vi < 2; ++vi)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -1017,22 +1020,26 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
         for (int rr = 0; rr < 4; ++rr) acc[vi][rt][c][rr] += b;
     }
   FC_STAMP(pf, 2);
-  for (int g = 0; g + 2 < NG8; g += 2) {   // pairs with a successor pair
-    step(T{}, T{}, T{}, Even{});
+  // first pair (hidden rows of pair 0 came with the prologue), pairs with a successor pair, last pair
+  step(T{}, T{}, T{}, Even{}, F{});
+  __syncthreads();
+  step(T{}, T{}, F{}, Odd{}, F{});
+  __syncthreads();
+  for (int g = 2; g + 2 < NG8; g += 2) {
+    step(T{}, T{}, T{}, Even{}, T{});
     FC_STAMP_FINE(pf, 3);
     __syncthreads();
     FC_STAMP_FINE(pf, 11);
-    step(T{}, T{}, F{}, Odd{});
+    step(T{}, T{}, F{}, Odd{}, F{});
     FC_STAMP_FINE(pf, 3);
     __syncthreads();
     FC_STAMP_FINE(pf, 11);
-    roll();
   }
-  step(T{}, F{}, F{}, Even{});             // last pair: one contraction left, nothing to request
+  step(T{}, F{}, F{}, Even{}, T{});        // last pair: one contraction left, nothing to request
   FC_STAMP_FINE(pf, 3);
   __syncthreads();
   FC_STAMP_FINE(pf, 11);
-  step(F{}, F{}, F{}, Odd{});
+  step(F{}, F{}, F{}, Odd{}, F{});
   FC_STAMP_FINE(pf, 3);
   __syncthreads();
   FC_STAMP(pf, 3 + 8 * (DDMI_PROF_FINE));
@@ -1089,19 +1096,19 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
   const int cb = lr < 8 ? lr : lr < 10 ? 16 * (NB - 1) + lr - 8 : 16 * NBK + lr - 10;
   const int cs = lr < 8 ? 8 : lr < 10 ? 2 : 0;
   float* const ywr = ywr0 + cb;
-  // x fragments: the long chain's stay in registers; the short chains' are re-read from the (read-only) x tile in LDS a few
-  // MFMAs ahead of their use -- 18 registers less than keeping them, for one LDS read per short-chain MFMA
+  // x fragments are re-read from the (read-only) x tile in LDS a few MFMAs ahead of their use -- 30 registers less than
+  // keeping them, for one LDS read per contraction MFMA
   constexpr int XW = 5;          // read-ahead distance of the window, in contraction positions
-  float xa0[S0 > 0 ? S0 : 1], xw[NC];
-  if constexpr (S0 > 0) {
-#pragma unroll
-    for (int j = 0; j < S0; ++j) xa0[j] = P.xp0[4 * j];                    // scalar input: u = 4 * step + lane / 16
-  }
+  float xw[NC];
   auto xread = [&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    if constexpr (i < NC && !O::is_c0(i < NC ? i : 0)) {
-      constexpr int t = O::slot(i) - C0;                                     // component t % 3 of group t / 3, vector input (3 floats per u)
-      xw[i] = P.xg[t / 3][t % 3 + 12 * O::step(i)];
+    if constexpr (i < NC) {
+      if constexpr (O::is_c0(i)) {
+        xw[i] = P.xp0[4 * O::step(i)];                                       // scalar input: u = 4 * step + lane / 16
+      } else {
+        constexpr int t = O::slot(i) - C0;                                   // component t % 3 of group t / 3, vector input (3 floats per u)
+        xw[i] = P.xg[t / 3][t % 3 + 12 * O::step(i)];
+      }
     }
   };
   float bw0[S0 > 0 ? S0 : 1], bwg[NG][3];   // weight fragments: the long chain, one 3-step set per group
@@ -1160,7 +1167,8 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
     constexpr int t = O::slot(i), j = O::step(i);
     xread(std::integral_constant<int, i + XW>{});
     float b, x;
-    if constexpr (C0 == 1 && t == 0) { b = bw0[j]; x = xa0[j]; } else { b = bwg[(t - C0) / 3][j]; x = xw[i]; }
+    x = xw[i];
+    if constexpr (C0 == 1 && t == 0) b = bw0[j]; else b = bwg[(t - C0) / 3][j];
     r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b, r[t], 0, 0, 0);
     if constexpr (NEARLY > 0 && i >= EARLY0) {
       if (stores) {
@@ -1170,7 +1178,13 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
       }
     }
   };
-  auto step = [&](auto do_c, auto do_w, auto do_h, auto odd) __attribute__((always_inline)) {
+  auto roll = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int vi = 0; vi < 2; ++vi)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+  };
+  auto step = [&](auto do_c, auto do_w, auto do_h, auto odd, auto do_roll) __attribute__((always_inline)) {
     constexpr bool DO_C = decltype(do_c)::value, DO_W = decltype(do_w)::value, DO_H = decltype(do_h)::value;
     constexpr int ODD = decltype(odd)::value, eb = ODD, cb_ = ODD ^ 1;
     if constexpr (DO_C) {
@@ -1184,6 +1198,7 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
     } else {
       readq(0, eb, 0);
     }
+    if constexpr (decltype(do_roll)::value) { roll(); DDMI_SCHED_FENCE(); }   // (see fc_mainloop_dense)
     fc_sfor<0, NE>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       constexpr int grp = m / (2 * NB), t8 = m % (2 * NB), vi = grp >> 1, sub = grp & 1, rt = t8 / NB, c = t8 % NB;
@@ -1207,12 +1222,6 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
       for (int t = 0; t < 1 + NG; ++t) woff[t] += gstep;
     }
     if constexpr (DO_H) hoff += 1024u;
-  };
-  auto roll = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int vi = 0; vi < 2; ++vi)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -1255,8 +1264,8 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
       if constexpr (C0 == 1 && t == 0) {
 #pragma unroll
         for (int j = 0; j < S0; j += 2) {
-          ba = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0[j], bb[j], ba, 0, 0, 0);
-          bq = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0[j + 1], bb[j + 1], bq, 0, 0, 0);
+          ba = __builtin_amdgcn_mfma_f32_16x16x4f32(P.xp0[4 * j], bb[j], ba, 0, 0, 0);
+          bq = __builtin_amdgcn_mfma_f32_16x16x4f32(P.xp0[4 * j + 4], bb[j + 1], bq, 0, 0, 0);
         }
       } else {
         constexpr int g = (t - C0) / 3, comp = (t - C0) % 3;
@@ -1291,16 +1300,19 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
         for (int rr = 0; rr < 4; ++rr) acc[vi][rt][c][rr] += b;
     }
   FC_STAMP(pf, 2);
-  for (int g = 0; g + 2 < NG8; g += 2) {
-    step(T{}, T{}, T{}, Even{});
-    __syncthreads();
-    step(T{}, T{}, F{}, Odd{});
-    __syncthreads();
-    roll();
-  }
-  step(T{}, F{}, F{}, Even{});
+  step(T{}, T{}, T{}, Even{}, F{});
   __syncthreads();
-  step(F{}, F{}, F{}, Odd{});
+  step(T{}, T{}, F{}, Odd{}, F{});
+  __syncthreads();
+  for (int g = 2; g + 2 < NG8; g += 2) {
+    step(T{}, T{}, T{}, Even{}, T{});
+    __syncthreads();
+    step(T{}, T{}, F{}, Odd{}, F{});
+    __syncthreads();
+  }
+  step(T{}, F{}, F{}, Even{}, T{});
+  __syncthreads();
+  step(F{}, F{}, F{}, Odd{}, F{});
   __syncthreads();
   FC_STAMP(pf, 3);
 }
