@@ -939,11 +939,15 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
       DDMI_SCHED_FENCE();
     });
+#ifndef FCV_SAMEW
     if constexpr (DO_W) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) woff[t] += gstep;
     }
+#endif
+#ifndef FCV_SAMEH
     if constexpr (DO_H) hoff += 1024u;
+#endif
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -1021,16 +1025,16 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
     }
   FC_STAMP(pf, 2);
   // first pair (hidden rows of pair 0 came with the prologue), pairs with a successor pair, last pair
-  step(T{}, T{}, T{}, Even{}, F{});
+  step(T{}, T{}, F{}, Even{}, F{});
   __syncthreads();
-  step(T{}, T{}, F{}, Odd{}, F{});
+  step(T{}, T{}, T{}, Odd{}, F{});
   __syncthreads();
   for (int g = 2; g + 2 < NG8; g += 2) {
-    step(T{}, T{}, T{}, Even{}, T{});
+    step(T{}, T{}, F{}, Even{}, T{});
     FC_STAMP_FINE(pf, 3);
     __syncthreads();
     FC_STAMP_FINE(pf, 11);
-    step(T{}, T{}, F{}, Odd{}, F{});
+    step(T{}, T{}, T{}, Odd{}, F{});
     FC_STAMP_FINE(pf, 3);
     __syncthreads();
     FC_STAMP_FINE(pf, 11);
@@ -1217,11 +1221,15 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
       if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
       DDMI_SCHED_FENCE();
     });
+#ifndef FCV_SAMEW
     if constexpr (DO_W) {
 #pragma unroll
       for (int t = 0; t < 1 + NG; ++t) woff[t] += gstep;
     }
+#endif
+#ifndef FCV_SAMEH
     if constexpr (DO_H) hoff += 1024u;
+#endif
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -1300,14 +1308,14 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
         for (int rr = 0; rr < 4; ++rr) acc[vi][rt][c][rr] += b;
     }
   FC_STAMP(pf, 2);
-  step(T{}, T{}, T{}, Even{}, F{});
+  step(T{}, T{}, F{}, Even{}, F{});
   __syncthreads();
-  step(T{}, T{}, F{}, Odd{}, F{});
+  step(T{}, T{}, T{}, Odd{}, F{});
   __syncthreads();
   for (int g = 2; g + 2 < NG8; g += 2) {
-    step(T{}, T{}, T{}, Even{}, T{});
+    step(T{}, T{}, F{}, Even{}, T{});
     __syncthreads();
-    step(T{}, T{}, F{}, Odd{}, F{});
+    step(T{}, T{}, T{}, Odd{}, F{});
     __syncthreads();
   }
   step(T{}, F{}, F{}, Even{}, T{});
