@@ -32,7 +32,10 @@ namespace ddmi {
 // B = the k-th slab of the packed second-layer weights (L2-resident, 4 MB per edge group), v_mfma_f32_16x16x4_f32,
 // results scattered into an LDS row image in the item-major column order and then streamed out as 256-B runs
 // Y[node][super-tile][k][64] -- the exact order k_edge_conv reads them back.
-constexpr int NC_NODES = 32, NC_KC = 15, NC_XS = XS + 1;
+// x tile rows in LDS: stride 162 = 2 (mod 32).  An A fragment read has lane (node lr, quarter lq) at lr * stride + din * lq + c
+// (din = 1 or 3: odd): the 16 nodes land on 16 distinct EVEN banks and the next quarter on the odd ones -- conflict-free per
+// 32-lane half; an odd stride (161) put (lr, lq) and (lr + din, lq - 1) on one bank (2-way on almost every read).
+constexpr int NC_NODES = 32, NC_KC = 15, NC_XS = XS + 2;
 
 // Profiling builds only (-DDDMI_PROFILING, tools/build_variant.sh): DDMI_ABLATE switches individual kernel phases off
 // (garbage scores, timing only) and k_conv_fused accumulates per-phase cycle counts (fc_prof_report).  The shipped library
