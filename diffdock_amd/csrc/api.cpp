@@ -32,6 +32,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     if (const char* e = getenv("DDMI_FUSED")) h->m.fused = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_LIG")) h->m.fused_lig = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_PACK")) h->m.fused_pack = atoi(e) != 0;
+    if (const char* e = getenv("DDMI_FUSED_SHARED")) h->m.fused_shared = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_DENSE")) h->m.fused_dense = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_YS")) h->m.fused_ysplit = std::max(0, atoi(e));

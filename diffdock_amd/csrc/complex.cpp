@@ -43,7 +43,8 @@ struct Model::Cx {
   float *HE_b, *P_b, *Q_b, *Y_b, *rowbias_b;   // second scratch set: ligand-gather groups on the side stream
   // fused form (k_conv_fused): virtual-node lists of the two receptor-gather topologies (0 = lig<-rec cross, 1 = rec-rec),
   // rebuilt when the edge list they were built for changes (once per forward), and the hidden-row scratch
-  struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr;
+  struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr, *ne = nullptr;
+                 float* rows = nullptr;   // per-edge rows of k_conv_fused (k_vn_rows)
                  const int* built_goff = nullptr; long epoch = -1; };
   VnSet vn[9];           // + 2 = ligand-ligand, 3 = rec<-lig (ligand gather nodes: load mode); all_atoms: 4 la, 5 ra, 6 aa, 7 al, 8 ar
   // ---- all_atoms (models/aa_model.py): receptor heavy atoms = third node type, node rows [nL + nR, N)
@@ -201,7 +202,10 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       Cx::VnSet& vs = c.vn[g.vn];
       if (vs.built_goff != g.goff || vs.epoch != c.epoch) {
         PhaseTimer t(m, "vn_build", gs);
-        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, gs);
+        VnRowsArgs vr{};
+        vr.arow = g.arow; vr.nvec = g.nvec; vr.ew = g.ew; vr.tslot = g.tslot; vr.sgn = g.sgn; vr.sh_lmax = m.cfg.sh_lmax;
+        vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
+        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs);
         vs.built_goff = g.goff; vs.epoch = c.epoch;
       }
       const int* nvn = vs.voff + g.gcount;
@@ -220,11 +224,13 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs);
       }
       FusedConvArgs f{};
-      f.nvn = nvn; f.vcap = vs.vcap; f.vn_node = vs.node; f.vn_e0 = vs.e0; f.goff = g.goff; f.tslot = g.tslot; f.arow = g.arow;
+      f.nvn = nvn; f.vcap = vs.vcap; f.vn_node = vs.node; f.vrows = vs.rows; f.vn_ne = vs.ne;
       f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
-      f.nvec = g.nvec; f.ew = g.ew; f.sgn = g.sgn; f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.cgt = L.cgt;
+      f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.cgt = L.cgt;
       f.max_nb = L.max_nb; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
       f.dense = dense_rows ? 1 : 0;
+      // ligand gather nodes with >= 2 virtual nodes on average (rec<-lig): a tile of 16 virtual nodes holds few distinct nodes
+      f.shared = (dense_rows && (m.fused_shared == 2 || (m.fused_shared == 1 && g.load && (long)g.ea_rows >= 48L * std::max(1, g.gcount)))) ? 1 : 0;
       f.prof_slot = (int)gi;
       // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
       int ys_req = m.fused_ysplit;
@@ -245,6 +251,11 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       f.n_units = 0;
       for (int gq = 0; gq < L.n_fgran && f.n_units < 48; ++gq)
         if (gq == 0 || L.fgran_unit[gq] != L.fgran_unit[gq - 1]) f.ustart[f.n_units++] = (short)gq;
+      for (int y = 0; y < ys; ++y) {   // units of every granule range (ranges start at unit boundaries)
+        f.ufirst[y] = 0; f.ucount[y] = 0;
+        for (int u = 0; u < f.n_units; ++u)
+          if (f.ustart[u] >= f.gsplit[y] && f.ustart[u] < f.gsplit[y + 1]) { if (f.ucount[y] == 0) f.ufirst[y] = (short)u; ++f.ucount[y]; }
+      }
       static const bool per_group = getenv("DDMI_TIME_GROUPS") != nullptr;   // profiling: one timing row per edge group
       if (m.timing && per_group) {
         const std::string tname = "k_conv_fused:g" + std::to_string(gi);
@@ -566,6 +577,9 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
       vs.vcap = (lig_v[i] ? 2 : 1) * gn_v[i] + ecap_v[i] / 32 + 2;
       vs.cnt = dalloc<int>(m, nullptr, {gn_v[i] + 1}); vs.voff = dalloc<int>(m, names[i], {gn_v[i] + 1});
       vs.node = dalloc<int>(m, nullptr, {vs.vcap}); vs.e0 = dalloc<int>(m, nullptr, {vs.vcap});
+      const int shd = (cfg.sh_lmax + 1) * (cfg.sh_lmax + 1);
+      vs.ne = dalloc<int>(m, nullptr, {round_up(vs.vcap, 16)});
+      vs.rows = dalloc<float>(m, nullptr, {round_up(vs.vcap, 16), 32, shd == 4 ? 8 : shd + 3});
       vmax = std::max(vmax, vs.vcap);
       if (lig_v[i]) vmax_b = std::max(vmax_b, vs.vcap);
     }

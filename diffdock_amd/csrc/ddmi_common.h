@@ -34,6 +34,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DDMI_WAIT_VMEM() ((void)0)
 #define DDMI_ROW_XOR8(v) __shfl_xor((v), 8, 64)
 #define DDMI_OPAQUE(x) ((void)0)
+#define DDMI_SWAP32(a, b, WAIT)                                                        \
+  do {                                                                                 \
+    const float ta_ = __shfl_xor((a), 32, 64), tb_ = __shfl_xor((b), 32, 64);          \
+    const bool up_ = (threadIdx.x & 32) != 0;                                          \
+    const float na_ = up_ ? tb_ : (a), nb_ = up_ ? (b) : ta_;                          \
+    (a) = na_; (b) = nb_;                                                              \
+  } while (0)
+#define DDMI_SWAP16(a, b, WAIT)                                                        \
+  do {                                                                                 \
+    const float ta_ = __shfl_xor((a), 16, 64), tb_ = __shfl_xor((b), 16, 64);          \
+    const bool odd_ = (threadIdx.x & 16) != 0;                                         \
+    const float na_ = odd_ ? tb_ : (a), nb_ = odd_ ? (b) : ta_;                        \
+    (a) = na_; (b) = nb_;                                                              \
+  } while (0)
 #else
 // the compiler may not assume anything about x past this point (keeps loop-invariant address arithmetic inside the loop)
 #define DDMI_OPAQUE(x) asm volatile("" : "+v"(x))
@@ -53,6 +67,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // value of lane ^ 8 (the other half of the lane's row of 16): DPP row rotate by 8, no LDS traffic
 #define DDMI_ROW_XOR8(v) \
   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), 0x128, 0xf, 0xf, false))
+// gfx950 half / row swaps of two registers (v_permlane32_swap / v_permlane16_swap; semantics checked on the MI355X,
+// tools/probe/mfma4x4.hip, rsc_probe.hip).  SWAP32: a <- [a.lanes 0-31 | b.lanes 0-31], b <- [a.lanes 32-63 | b.lanes 32-63].
+// SWAP16 (rows of 16 lanes): a <- [a.row0 | b.row0 | a.row2 | b.row2], b <- [a.row1 | b.row1 | a.row3 | b.row3].
+// Inline assembly: the two-result builtins of this toolchain (__builtin_amdgcn_permlane16_swap / 32_swap) hand back the first
+// result twice.  The hazard recognizer does not look inside; WAIT = wait states the operands' producers still need
+// (7 covers a 2-pass MFMA result, 1 a VALU result).
+#define DDMI_SWAP32(a, b, WAIT) asm volatile("s_nop " #WAIT "\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b))
+#define DDMI_SWAP16(a, b, WAIT) asm volatile("s_nop " #WAIT "\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b))
 #define DDMI_NT_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
 #define DDMI_NT_LOAD(ptr) __builtin_nontemporal_load((ptr))
 #endif

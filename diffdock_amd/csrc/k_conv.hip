@@ -479,11 +479,49 @@ __global__ void k_vn_fill(const int* __restrict__ goff, const int* __restrict__ 
   const int v0 = voff[d], n = voff[d + 1] - v0, e0 = goff[d], e1 = goff[d + 1];
   for (int b = 0; b < n; ++b) { vn_node[v0 + b] = d; vn_e0[v0 + b] = min(e0 + 32 * b, e1); }
 }
-void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s) {
+// Per-edge rows of the fused kernel, once per forward and edge group (the six layers share the graph): virtual node v, edge
+// row r -> [spherical harmonics (SHD) | edge weight | message row | pad] at stride ES, zero rows behind the node's last edge
+// and for the dead virtual nodes of the last 16-node tile; vn_ne[v] = edges of the virtual node.  The tile prologue of
+// k_conv_fused then is one coalesced copy instead of the chain vn_e0 -> arow -> nvec / weight / slot.
+template <int SHD, int ES>
+__global__ __launch_bounds__(256) void k_vn_rows(VnRowsArgs a) {
+  const int v = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
+  const int nvn = *a.nvn;
+  if (v >= ((nvn + 15) & ~15)) return;   // whole 16-node tiles (FC_VN)
+  int ne = 0, e0 = 0;
+  if (v < nvn) { e0 = a.vn_e0[v]; ne = min(32, a.goff[a.vn_node[v] + 1] - e0); }
+  float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float we = 0.f;
+  int ts = 0;
+  if (r < ne) {
+    const int e = e0 + r;
+    const int ar = a.arow ? a.arow[e] : e;
+    edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
+    we = a.ew ? a.ew[ar] : 1.f;
+    ts = a.tslot[e];
+  }
+  float* er = a.rows + ((size_t)v * 32 + r) * ES;
+#pragma unroll
+  for (int j = 0; j < SHD; ++j) er[j] = sh[j];
+  er[SHD] = we;
+  reinterpret_cast<int*>(er)[SHD + 1] = ts;
+#pragma unroll
+  for (int j = SHD + 2; j < ES; ++j) er[j] = 0.f;
+  if (r == 0) a.vn_ne[v] = ne;
+}
+void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, const VnRowsArgs& rows_in,
+                     hipStream_t s) {
   if (gcount <= 0) return;
   hipLaunchKernelGGL(k_vn_count, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, gcount, cnt_tmp);
   launch_exclusive_scan(cnt_tmp, voff, gcount, s);
   hipLaunchKernelGGL(k_vn_fill, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, voff, gcount, vn_node, vn_e0);
+  if (rows_in.rows) {
+    VnRowsArgs r = rows_in;
+    r.nvn = voff + gcount; r.vn_node = vn_node; r.vn_e0 = vn_e0; r.goff = goff;
+    const dim3 grid((unsigned)cdiv(round_up(r.vcap, 16), 8));
+    if (r.sh_lmax <= 1) hipLaunchKernelGGL((k_vn_rows<4, 8>), grid, dim3(256), 0, s, r);
+    else hipLaunchKernelGGL((k_vn_rows<9, 12>), grid, dim3(256), 0, s, r);
+  }
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -642,6 +680,7 @@ void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {
 }
 
 constexpr int FC_VN = 16, FC_KC = 8, FC_WAVES = 8, FC_CAP0 = 12, FC_CAPN = 4;
+static_assert(FC_VN == 16, "k_vn_rows pads the per-edge rows to whole 16-node tiles");
 constexpr int FC_GWORDS = sizeof(FGran) / 4;   // granule descriptor, in 32-bit words
 constexpr int FC_MAXG = 24;                    // granule descriptors kept in LDS per workgroup (launches split larger ranges)
 // chunk buffer in LDS: [16 nodes][8 rows][16 * NBK columns] (NBK = column blocks of the widest granule of the launch: 4, or 5
@@ -656,13 +695,13 @@ template <int NBK> struct FcDim {
 // k-invariant per-lane part of one slot chain: uniform weight base + 32-bit lane offset (scalar-base global loads)
 struct FcSlotRt { const float* wb; const float* xp; int loff, xstride, steps, ps; };
 __device__ __forceinline__ FcSlotRt fc_slot_setup(const NcSlot S, const float* __restrict__ wpack, const float* __restrict__ xbuf,
-                                                  int w0, int lr, int lq) {
+                                                  int w0, int lr, int lq, int xr) {   // xr: the lane's row of the x tile
   FcSlotRt R;
   R.steps = S.din == 0 ? 0 : (S.u_pad >> 2);
   R.wb = wpack + S.wk_off;
   R.loff = nc_lane_off(S, w0, lr, lq);
   R.ps = nc_pstride(S.u_pad >> 2);
-  R.xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
+  R.xp = xbuf + xr * NC_XS + S.x_off + lq * S.din + S.comp;
   R.xstride = 4 * S.din;
   return R;
 }
@@ -824,11 +863,17 @@ struct FcOrder {   // issue order of the slot chains: slot 0 alternating with th
 };
 // DUP: slots sharing one set of weight fragments (FGran::dup): they are requested once and feed several chains.
 // NLV: live slots among 1..3 (FGran::nlive; padding slots trail): a padding slot is neither contracted nor multiplied.
-template <int NBK, int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3>
+// SH (shared-node tiles, ligand gather nodes with several virtual nodes each): the x tile holds the DISTINCT gather nodes of
+// the 16 virtual nodes (slot dsl[vi] of this wave's virtual node vi; at most four -- tiles with more take the 16-row form) and the contraction runs on the 4x4x1
+// MFMA (16 blocks of 4 nodes x 4 columns, block = 4 * channel-in-quad + column quad with the SAME weight fragments as the
+// 16x16x4 form): a quarter of the matrix-core time per pass.  The four channel partials of a column sit in the four lane
+// rows; a reduce-scatter by row / half swaps leaves node slot lq in lane row lq, stored with one request per chain.
+// ywr: SH ? chunk row `wave` of node slot lq, column lr : of node 4lq (+r); yrd: SH ? without the node term : node 2*wave.
+template <int NBK, int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3, bool SH = false>
 __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
                                                   int KS, int HK, int NG8, int wave, int lane,
                                                   const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr,
-                                                  const float* yrd, FcProf& pf, float* brow) {
+                                                  const float* yrd, FcProf& pf, float* brow, const int (&dsl)[2]) {
   constexpr int FC_YROW = FcDim<NBK>::YROW, FC_YVN = FcDim<NBK>::YVN, FC_YB = FcDim<NBK>::YB, BST = FcDim<NBK>::BST;
   // sparse rows (!DENSE): the second 16-row tile of a virtual node with <= 16 edges is neither fetched nor multiplied
   const bool two[2] = {DENSE || vne[0] > 16, DENSE || vne[1] > 16};
@@ -868,6 +913,23 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       bw[t][0] = v.x; bw[t][1] = v.y; bw[t][2] = v.z;
     }
   };
+  auto cmma = [](float av, float bv, f32x4 c) __attribute__((always_inline)) -> f32x4 {   // contraction MFMA
+#ifdef FCV_NOCMMA   // timing-only: no contraction MFMAs (the weight requests stay alive)
+    c[0] += bv; (void)av;
+    if (true) return c;
+#endif
+    if constexpr (SH) return __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c, 0, 0, 0);
+  };
+  auto rsc = [](const f32x4& v) __attribute__((always_inline)) {   // SH: lane row lq <- node slot lq summed over the four lane rows
+    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+    DDMI_SWAP16(a0, a1, 1);   // (operands: copies of MFMA results that are at least two MFMAs old)
+    DDMI_SWAP16(a2, a3, 1);
+    float x = a0 + a1, y = a2 + a3;
+    DDMI_SWAP32(x, y, 1);
+    return x + y;
+  };
+  const int ynoff[2] = {SH ? dsl[0] * FC_YVN : 0, SH ? dsl[1] * FC_YVN : FC_YVN};   // chunk rows of this wave's two virtual nodes
   float4 hC[2][2], hN[2][2];   // hidden-row fragments of the current / next PAIR of chunks: [virtual node][row tile]
 #pragma unroll
   for (int pc = 0; pc < 4; ++pc) hC[pc >> 1][pc & 1] = hN[pc >> 1][pc & 1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -880,18 +942,22 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   };
   f32x4 r[4];
   // live 16-column blocks of the granule: a (12,-,-,-) granule (one item column) multiplies only block 0 in the edge product
-  constexpr int NCB = SN == 0 ? 1 : 1 + NLV, NE = 8 * NCB, NP = (SN == 0 || NLV == 1) ? 4 : 8;
+  constexpr int NCB = SN == 0 ? 1 : 1 + NLV, NE = 8 * NCB, NP = SH ? NCB : (SN == 0 || NLV == 1) ? 4 : 8;
   float q[2][NCB];             // B fragments of the edge product: [parity of the (virtual node, k pair) group][column block]
   auto readq = [&](int par, int buf, int grp) __attribute__((always_inline)) {
-    const float* __restrict__ yb = yrd + buf * FC_YB + (grp >> 1) * FC_YVN + (grp & 1) * FC_YROW;
+    const float* __restrict__ yb = yrd + buf * FC_YB + ynoff[grp >> 1] + (grp & 1) * FC_YROW;
 #pragma unroll
     for (int c = 0; c < NCB; ++c) q[par][c] = yb[16 * c];
   };
   auto store_piece = [&](int buf, int piece) __attribute__((always_inline)) {   // rows of node quarter `rr`, slots 2h and 2h+1
     float* yw = ywr + buf * FC_YB;
-    const int rr = piece & 3, h = piece >> 2;
-    if (2 * h < NCB) yw[rr * FC_YVN + 16 * (2 * h)] = r[2 * h][rr];
-    if (2 * h + 1 < NCB) yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
+    if constexpr (SH) {   // one chain per piece
+      yw[16 * piece] = rsc(r[piece]);
+    } else {
+      const int rr = piece & 3, h = piece >> 2;
+      if (2 * h < NCB) yw[rr * FC_YVN + 16 * (2 * h)] = r[2 * h][rr];
+      if (2 * h + 1 < NCB) yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
+    }
   };
   static_assert(NCB <= NBK, "column blocks of the granule exceed the chunk buffer");
   // one chunk step (chunk g = 2 * pair + ODD): contraction of chunk g+1 into buffer ODD ^ 1 (DO_C), weight requests for
@@ -910,13 +976,17 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
     if constexpr (DO_C) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 r0b = f32x4{0.f, 0.f, 0.f, 0.f};   // second accumulator of the long chain: its last three steps are consecutive, and a dependent
+                                               // MFMA waits 40 (4x4x1) / 44-64 (16x16x4, one / two waves per SIMD) cycles instead of 12 / 33
       fc_sfor<0, NC>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int t = O::slot(i);
-        r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[wsl(t)][O::step(i)], r[t], 0, 0, 0);
+        if constexpr (t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa[i], bw[wsl(t)][O::step(i)], r0b);
+        else r[t] = cmma(xa[i], bw[wsl(t)][O::step(i)], r[t]);
         if (i == NC - 3) readq(0, eb, 0);
         DDMI_SCHED_FENCE();
       });
+      if constexpr (S0 > 3) r[0] += r0b;
     } else {
       readq(0, eb, 0);
     }
@@ -995,21 +1065,30 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
         constexpr int i = decltype(ic)::value;
         if constexpr (O::slot(i) == t) {
           constexpr int j = O::step(i);
-          if constexpr (LEN > 3 && (j & 1)) bq = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bb[j], bq, 0, 0, 0);
-          else ba = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bb[j], ba, 0, 0, 0);
+          if constexpr (LEN > 3 && (j & 1)) bq = cmma(xa[i], bb[j], bq);
+          else ba = cmma(xa[i], bb[j], ba);
         }
       });
+      if constexpr (SH) {
+        brow[(lane_b >> 4) * BST + 16 * t + (lane_b & 15)] = rsc(ba + bq);
+      } else {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) brow[(4 * (lane_b >> 4) + rr) * BST + 16 * t + (lane_b & 15)] = ba[rr] + bq[rr];
+        for (int rr = 0; rr < 4; ++rr) brow[(4 * (lane_b >> 4) + rr) * BST + 16 * t + (lane_b & 15)] = ba[rr] + bq[rr];
+      }
     }
   });
 #pragma unroll
   for (int t = 0; t < 4; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  fc_sfor<0, NC>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr int t = O::slot(i);
-    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[wsl(t)][O::step(i)], r[t], 0, 0, 0);
-  });
+  {
+    f32x4 r0b = f32x4{0.f, 0.f, 0.f, 0.f};
+    fc_sfor<0, NC>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int t = O::slot(i);
+      if constexpr (t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa[i], bw[wsl(t)][O::step(i)], r0b);
+      else r[t] = cmma(xa[i], bw[wsl(t)][O::step(i)], r[t]);
+    });
+    if constexpr (S0 > 3) r[0] += r0b;
+  }
 #pragma unroll
   for (int pc = 0; pc < NP; ++pc) store_piece(0, pc);
   fc_sfor<0, NL>(loadw);
@@ -1020,7 +1099,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
-      const float b = brow[(2 * wave + vi) * BST + 16 * c + (lane_b & 15)];
+      const float b = brow[(SH ? dsl[vi] : 2 * wave + vi) * BST + 16 * c + (lane_b & 15)];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -1058,16 +1137,16 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
 // k-invariant per-lane part of a packed granule: x fragments of the long chain at xp0[4 * step], of group g, component i
 // at xg[g][i + 12 * step]; packed weights of request source t (0 = long chain, 1 + g = group g) at wk[t] (uniform) + loff[t]
 struct FcPackRt { const float* xp0; const float* xg[2]; int wk[3], loff[3]; };
-__device__ __forceinline__ FcPackRt fc_pack_setup(const FGran& G, const float* __restrict__ xbuf, int lr, int lq) {
+__device__ __forceinline__ FcPackRt fc_pack_setup(const FGran& G, const float* __restrict__ xbuf, int lr, int lq, int xr) {
   FcPackRt P;
   const int c0 = G.shape == 5 ? 0 : 1, ng = G.shape == 6 ? 1 : 2;
   const NcSlot& S0_ = G.slot[0];
-  P.xp0 = xbuf + lr * NC_XS + S0_.x_off + lq;
+  P.xp0 = xbuf + xr * NC_XS + S0_.x_off + lq;
   P.wk[0] = S0_.wk_off; P.loff[0] = nc_lane_off(S0_, 0, lr, lq);
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const NcSlot& S = G.slot[g < ng ? c0 + 3 * g : 0];
-    P.xg[g] = xbuf + lr * NC_XS + S.x_off + 3 * lq;
+    P.xg[g] = xbuf + xr * NC_XS + S.x_off + 3 * lq;
     P.wk[1 + g] = S.wk_off; P.loff[1 + g] = nc_lane_off(S, 0, lr, lq);
   }
   return P;
@@ -1339,7 +1418,9 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
 // (wave-local).
 // MODE 0: static chain shapes, sparse rows (the second 16-edge tile of a virtual node with <= 16 edges is skipped),
 // 1: generic (predicated, compiler-scheduled) contraction of classic granules, 3: static shapes, dense rows (both row tiles of
-// every virtual node are multiplied: straight-line chunk body).  NBK = column blocks of the chunk buffer (widest granule).
+// every virtual node are multiplied: straight-line chunk body), 4: mode 3 for gather nodes with several virtual nodes each
+// (ligand atoms in the rec<-lig group): the x tile holds the tile's DISTINCT gather nodes and the classic granules contract
+// them on the 4x4x1 MFMA (fc_mainloop_dense<SH>).  NBK = column blocks of the chunk buffer (widest granule).
 template <int MAXD, int SHD, int MODE, int NBK>
 __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   DDMI_DYN_SMEM(float, smem);
@@ -1368,9 +1449,41 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   const unsigned pf_t0 = pf.t;
 #endif
   const int nv_live = min(FC_VN, nvn - v0);
-  for (int idx = tid; idx < FC_VN * XS; idx += 64 * FC_WAVES) {
-    const int nl = idx / XS, c = idx - nl * XS;
-    xbuf[nl * NC_XS + c] = nl < nv_live ? a.X[(size_t)(a.gbase + a.vn_node[v0 + nl]) * XS + c] : 0.f;
+  constexpr bool SHM = MODE == 4;
+  int dsl[2] = {2 * wave, 2 * wave + 1};   // x-tile / chunk-buffer row of this wave's two virtual nodes
+  int xr = lr;                             // the lane's x-tile row in the 16-row forms
+  bool sh_tile = false;                    // SHM: at most four distinct gather nodes -> 4-row x tile, 4x4x1 contraction
+  if constexpr (SHM) {
+    // Distinct gather nodes of the tile (virtual nodes of a node are consecutive): slot of virtual node j = number of node
+    // changes up to j.  Every wave derives the same map; the node of every slot goes through wave-private scratch.
+    const int vv = v0 + lr;
+    const int nd_ = vv < nvn ? a.vn_node[vv] : -1;
+    const int prev = __shfl(nd_, (lane & 48) + ((lr + 15) & 15));
+    const bool first = lr == 0 || (nd_ >= 0 && nd_ != prev);
+    const unsigned bal = (unsigned)(__ballot(first) & 0xffffull);
+    auto slot_of = [&](int j) { return __popcll((unsigned long long)(bal & ((2u << j) - 1u))) - 1; };
+    xr = slot_of(lr);
+    dsl[0] = DDMI_UNIFORM(slot_of(2 * wave));
+    dsl[1] = DDMI_UNIFORM(slot_of(2 * wave + 1));
+    const int ndist = __popcll((unsigned long long)bal);
+    sh_tile = DDMI_UNIFORM(ndist) <= 4;
+    if (sh_tile) {
+      int* wsn = reinterpret_cast<int*>(gscr + wave * 16 * GS2);
+      if (lane < 16 && first) wsn[xr] = nd_;
+      DDMI_WAVE_SYNC();
+      for (int idx = tid; idx < 4 * XS; idx += 64 * FC_WAVES) {
+        const int nl = idx / XS, c = idx - nl * XS;
+        xbuf[nl * NC_XS + c] = nl < ndist ? a.X[(size_t)(a.gbase + wsn[nl]) * XS + c] : 0.f;
+      }
+    } else {   // more than four distinct nodes: the tile runs in the 16-row form of mode 3
+      xr = lr; dsl[0] = 2 * wave; dsl[1] = 2 * wave + 1;
+    }
+  }
+  if (!sh_tile) {
+    for (int idx = tid; idx < FC_VN * XS; idx += 64 * FC_WAVES) {
+      const int nl = idx / XS, c = idx - nl * XS;
+      xbuf[nl * NC_XS + c] = nl < nv_live ? a.X[(size_t)(a.gbase + a.vn_node[v0 + nl]) * XS + c] : 0.f;
+    }
   }
   const int g_begin = a.gsplit[blockIdx.y], g_end = a.gsplit[blockIdx.y + 1];
   // The granule descriptors are copied to LDS before the first message store: on gfx9-family parts loads and stores share
@@ -1382,46 +1495,23 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   // Visiting order of the granules, rotated by whole units per workgroup: tiles start together and take equal time, so with
   // one common order all 256 CUs would issue their message stores (98 KB per tile and granule) in the same microseconds and
   // then wait for that burst to drain; rotated, the stores of the chip spread over the whole granule period.
-  if (tid == 0) {   // (unit starts come with the kernel arguments: no global loads on this path)
-    const int n = g_end - g_begin;
-    int n_units = 0;
-    for (int u = 0; u < a.n_units; ++u) n_units += a.ustart[u] >= g_begin && a.ustart[u] < g_end;
-    const int want = DDMI_ABL(a.dbg, 2048) || n_units == 0 ? 0 : (int)(blockIdx.x % (unsigned)n_units);
-    int start = 0;
-    for (int u = 0, k = 0; u < a.n_units; ++u)
-      if (a.ustart[u] >= g_begin && a.ustart[u] < g_end) { if (k == want) start = a.ustart[u] - g_begin; ++k; }
-    for (int i = 0; i < n; ++i) gorder[i] = g_begin + (start + i) % n;
+  if (tid < g_end - g_begin) {   // (unit starts and the units of this granule range come with the kernel arguments: no global loads)
+    const int n = g_end - g_begin, nu = a.ucount[blockIdx.y];
+    const int want = DDMI_ABL(a.dbg, 2048) || nu == 0 ? 0 : (int)(blockIdx.x % (unsigned)nu);
+    const int start = nu == 0 ? 0 : a.ustart[a.ufirst[blockIdx.y] + want] - g_begin;
+    gorder[tid] = g_begin + (start + tid) % n;
   }
   // dense coupling rows of this workgroup's granules (host-built, weights.cpp): cgt[g][s][k'][j]
   for (int idx = tid; idx < (g_end - g_begin) * CGN; idx += 64 * FC_WAVES) cgt[idx] = a.cgt[(size_t)g_begin * CGN + idx];
-  int ve0[2], vne[2];
+  int vne[2];
   float* gw = gscr + wave * 16 * GS2;
   float* ew_ = escr + wave * 2 * 32 * ES;
+  {   // per-edge rows (harmonics, weight, message row) of the wave's two virtual nodes: prepared by k_vn_rows, one coalesced copy
+    const float4* __restrict__ rsrc = reinterpret_cast<const float4*>(a.vrows + (size_t)(v0 + 2 * wave) * 32 * ES);
 #pragma unroll
-  for (int vi = 0; vi < 2; ++vi) {
-    const int v = v0 + 2 * wave + vi;
-    ve0[vi] = 0; vne[vi] = 0;
-    if (v < nvn) {
-      ve0[vi] = a.vn_e0[v];
-      vne[vi] = min(32, a.goff[a.vn_node[v] + 1] - ve0[vi]);
-    }
-    if (lane < 32) {   // per-edge rows, shared by all granules: spherical harmonics, edge weight, message row
-      float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      float we = 0.f;
-      int ts = 0;
-      if (lane < vne[vi]) {
-        const int e = ve0[vi] + lane;
-        const int ar = a.arow ? a.arow[e] : e;
-        edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
-        we = a.ew ? a.ew[ar] : 1.f;
-        ts = a.tslot[e];
-      }
-      float* er = ew_ + (vi * 32 + lane) * ES;
-#pragma unroll
-      for (int j = 0; j < SHD; ++j) er[j] = sh[j];
-      er[SHD] = we;
-      reinterpret_cast<int*>(er)[SHD + 1] = ts;
-    }
+    for (int idx = lane; idx < 2 * 32 * ES / 4; idx += 64) reinterpret_cast<float4*>(ew_)[idx] = rsrc[idx];
+    vne[0] = a.vn_ne[v0 + 2 * wave];
+    vne[1] = a.vn_ne[v0 + 2 * wave + 1];
   }
   __syncthreads();
   const int H = a.HK - 1;
@@ -1432,6 +1522,9 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   float* const ywr0 = ybuf + (4 * lq) * FC_YVN + wave * FC_YROW;               // node 4lq (+r), row = wave; + the lane's column
   float* const ywr = ywr0 + lr;                                                // classic granules: column 16*slot + lr
   const float* const yrd = ybuf + (2 * wave) * FC_YVN + (2 * lq) * FC_YROW + lr;   // node 2wave (+vi), row 2lq (+sub), column 16c + lr
+  float* const ywr_sh = ybuf + lq * FC_YVN + wave * FC_YROW + lr;                  // shared-node form: node slot lq (+4 per pass)
+  const float* const yrd_sh = ybuf + (2 * lq) * FC_YROW + lr;                      // + the node slot of the virtual node
+  (void)ywr_sh; (void)yrd_sh;
   FC_STAMP(pf, 0);
   for (int go = g_begin; go < g_end; ++go) {
     FC_COUNT(pf, 14);
@@ -1449,24 +1542,28 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         for (int c = 0; c < NBK; ++c) acc[vi][rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!Gd.empty && !DDMI_ABL(a.dbg, 128)) {
       if (PACK && packed) {
-        const FcPackRt P = fc_pack_setup(Gd, xbuf, lr, lq);
+        const FcPackRt P = fc_pack_setup(Gd, xbuf, lr, lq, xr);
         FC_STAMP(pf, 1);
-        constexpr bool DN = MODE == 3;
+        constexpr bool DN = MODE == 3 || MODE == 4;
 #define FC_MLP(S0_, NG_) fc_mainloop_packed<NBK, S0_, NG_, DN>(acc, P, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr0, yrd, pf, gscr)
         if constexpr (NBK >= 5) { if (Gd.shape == 4) FC_MLP(12, 2); }
         if (Gd.shape == 5) FC_MLP(0, 2);
         else if (Gd.shape == 6) FC_MLP(12, 1);
 #undef FC_MLP
       } else {
-      const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq);
-      const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq);
-      const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq);
-      const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.w0, lr, lq);
-      if (MODE == 0 || MODE == 3) {   // static chain shapes: hand-scheduled loop, dense (3) or sparse (0) rows
-        constexpr bool DN = MODE == 3;
+      const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
+      const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
+      const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
+      const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
+      if (MODE == 0 || MODE == 3 || MODE == 4) {   // static chain shapes: hand-scheduled loop, dense (3, 4) or sparse (0) rows
+        constexpr bool DN = MODE == 3 || MODE == 4;
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
         FC_STAMP(pf, 1);
-#define FC_ML(S0_, SN_, DUP_, NLV_) fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd, pf, gscr)
+#define FC_ML(S0_, SN_, DUP_, NLV_)                                                                                                  \
+  do {                                                                                                                                \
+    if (SHM && sh_tile) fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_, SHM>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr_sh, yrd_sh, pf, gscr, dsl); \
+    else fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_, false>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd, pf, gscr, dsl); \
+  } while (0)
         int dup, nlv;
         fc_variant(Gd, dup, nlv);
         if (Gd.shape == 1 && dup == 1 && nlv == 3) FC_ML(12, 3, 1, 3);
@@ -1557,7 +1654,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       if (MODE == 1) {   // generic loop: the bias row (k = H, h = 1) behind the main loop -- waves 0..3 contract one slot each,
                          // every edge row receives the node's bias row (the static loops take it along in their prologue)
         if (wave < 4) {
-          const FcSlotRt sb = fc_slot_setup(Gd.slot[wave], a.wpack, xbuf, Gd.w0, lr, lq);
+          const FcSlotRt sb = fc_slot_setup(Gd.slot[wave], a.wpack, xbuf, Gd.w0, lr, lq, xr);
           const f32x4 rb = fc_direct(sb, (size_t)H * a.KS);
           fc_store<NBK>(ybuf + (4 * lq) * FC_YVN + lr, 16 * wave, rb);    // row 0 of buffer 0
         }
@@ -1752,8 +1849,15 @@ void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
   a.dbg = ablate_mask();
   if (a.maxd <= 3 && a.sh_lmax <= 1) {   // the l <= 1 tensor product (FasterTensorProduct structure): static chain shapes, packed granules
     if (a.generic) launch_conv_fused_k<3, 4, 1, 4>(a, s);
-    else if (a.max_nb > 4) { if (a.dense) launch_conv_fused_k<3, 4, 3, 5>(a, s); else launch_conv_fused_k<3, 4, 0, 5>(a, s); }
-    else { if (a.dense) launch_conv_fused_k<3, 4, 3, 4>(a, s); else launch_conv_fused_k<3, 4, 0, 4>(a, s); }
+    else if (a.max_nb > 4) {
+      if (a.dense && a.shared) launch_conv_fused_k<3, 4, 4, 5>(a, s);
+      else if (a.dense) launch_conv_fused_k<3, 4, 3, 5>(a, s);
+      else launch_conv_fused_k<3, 4, 0, 5>(a, s);
+    } else {
+      if (a.dense && a.shared) launch_conv_fused_k<3, 4, 4, 4>(a, s);
+      else if (a.dense) launch_conv_fused_k<3, 4, 3, 4>(a, s);
+      else launch_conv_fused_k<3, 4, 0, 4>(a, s);
+    }
   } else if (a.maxd <= 3) {
     if (a.generic) launch_conv_fused_k<3, 9, 1, 4>(a, s);
     else if (a.dense) launch_conv_fused_k<3, 9, 3, 4>(a, s);

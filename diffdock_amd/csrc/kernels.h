@@ -96,7 +96,14 @@ struct FGran {
   int nslot;             // live slots (packed), 4 (classic)
   int nb;                // column blocks of the edge product: packed ceil(nslot / 2) + 1, classic 4
 };
-void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, hipStream_t s);
+// per-edge rows of k_conv_fused (k_vn_rows): [vcap rounded up to 16][32][ES] = harmonics | weight | message row, ES = 8 (l <= 1) or 12
+struct VnRowsArgs {
+  const int* nvn; const int* vn_node; const int* vn_e0; const int* goff;   // filled by launch_vn_build
+  const int* arow; const float* nvec; const float* ew; const int* tslot; float sgn; int sh_lmax;
+  int vcap; float* rows; int* vn_ne;   // rows == nullptr: lists only
+};
+void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, const VnRowsArgs& rows,
+                     hipStream_t s);
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                         const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
                         float* Hb, hipStream_t s);
@@ -120,20 +127,21 @@ void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s);
 
 struct FusedConvArgs {
   const int* nvn; int vcap;              // live virtual nodes (device) and their capacity (grid size)
-  const int* vn_node; const int* vn_e0;  // [vcap] gather node (local), first edge
-  const int* goff;                       // [gcount+1] gather CSR
-  const int* tslot; const int* arow;     // [E] message row, attr row (nullptr = identity)
+  const int* vn_node;                    // [vcap] gather node (local)
+  const float* vrows; const int* vn_ne;  // per-edge rows [vcap16][32][ES] and edge counts of the virtual nodes (k_vn_rows)
   const float* X; int gbase;             // node table (stride XS), first gather node
   const float* wpack; int KS, HK;        // packed second layer [HK][KS]
   const float* Hb; int NG8;              // hidden rows in A-fragment order [vcap][2][NG8][64][2], NG8 = ceil(H / 8)
-  const float* nvec; const float* ew; float sgn; int sh_lmax;
+  int sh_lmax;
   const FGran* gran; int ysplit; int gsplit[9];   // blockIdx.y walks granules [gsplit[y], gsplit[y+1])
   const float* cgt;                      // dense coupling rows [granule][FC_MAXSLOT][MAXD][SHD] (host-built, weights.cpp)
   int max_nb;                            // widest granule of the layer, in column blocks (4 classic, 5 = a packed 7-slot granule)
   int maxd;
   int generic;                           // some granule has no static chain shape: predicated kernel variant
   int dense;                             // most virtual nodes hold > 16 edges: multiply both row tiles unconditionally
+  int shared;                            // gather nodes with several virtual nodes each: contract the distinct nodes of a tile (4x4x1 MFMA)
   int n_units; short ustart[48];         // first granule of every (output block, w tile) unit: workgroups rotate their visiting order by units
+  short ufirst[8], ucount[8];            // units of granule range y: ustart[ufirst[y] .. + ucount[y])
   float* msg;                            // [E][XS]
   int dbg = 0;
   int prof_slot = 0;                     // profiling builds: edge-group slot of the in-kernel phase clocks

@@ -95,6 +95,7 @@ struct Model {
   bool fused = true;        // receptor-gather edge groups use k_conv_fused (DDMI_FUSED=0: contracted rows through HBM)
   int fused_lig = 3;        // ligand-gather groups (DDMI_FUSED_LIG): 3 = k_conv_fused like every other group, 0 = unfused
                             // (k_node_contract + k_edge_conv)
+  int fused_shared = 1;     // 1: rec<-lig group contracts the distinct gather nodes of a tile on the 4x4x1 MFMA; 0: per virtual node; 2: every dense group (tests)
   bool fused_pack = true;   // packed granules for output blocks of <= 10 channels (DDMI_FUSED_PACK=0: classic granules only)
   bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden
   int fused_dense = 1;      // branch-free dense-row main loop: 0 never, 1 groups with >= 20 edges per gather node, 2 always

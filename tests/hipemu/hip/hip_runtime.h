@@ -101,6 +101,9 @@ int __shfl_xor(int v, int mask, int width = 64);
 int __shfl_down(int v, unsigned delta, int width = 64);
 int __shfl(int v, int lane, int width = 64);
 f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_emu c, int, int, int);
+f32x4_emu __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, f32x4_emu c, int, int, int);
+unsigned long long __ballot(int pred);
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int);
 
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

@@ -182,6 +182,31 @@ f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_emu c, in
   return c;
 }
 
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products; block = lane / 4, A row / B column = lane % 4,
+// D[i][j] of block b in register i of lane 4b + j (layout checked on the MI355X: tools/probe/mfma4x4.hip)
+f32x4_emu __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, f32x4_emu c, int, int, int) {
+  Wave& w = waves[cur / 64];
+  int l = lane();
+  w.fa[l] = a;
+  w.fb[l] = b;
+  wave_sync();
+  for (int i = 0; i < 4; ++i) c[i] = fmaf(w.fa[(l & ~3) + i], w.fb[l], c[i]);
+  wave_sync();
+  threadIdx = fibers[cur].tid;
+  return c;
+}
+
+unsigned long long __ballot(int pred) {
+  Wave& w = waves[cur / 64];
+  w.ia[lane()] = pred != 0;
+  wave_sync();
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; ++i) m |= (unsigned long long)(w.ia[i] != 0) << i;
+  wave_sync();
+  threadIdx = fibers[cur].tid;
+  return m;
+}
+
 f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int) {
   Wave& w = waves[cur / 64];
   int l = lane();

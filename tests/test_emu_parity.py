@@ -277,6 +277,34 @@ def test_packed_granules_match_oracle_and_classic_granules(emu_lib, monkeypatch,
         assert rel_err(a_, b_) < 1e-5
 
 
+def test_shared_node_contraction_matches_oracle(emu_lib, monkeypatch):
+    """Shared-node tiles of k_conv_fused (MODE 4: the x tile holds the distinct gather nodes of the 16 virtual nodes, classic
+    granules contract them on the 4x4x1 MFMA, packed granules read their rows through the slot map), forced onto EVERY edge
+    group (DDMI_FUSED_SHARED=2 with dense rows): tiles with 16 distinct nodes (four passes), tiles that mix nodes with one and
+    several virtual nodes, the bias row, against the oracle and against the per-virtual-node form."""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = replace(DDL_SYNTH, num_conv_layers=4, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_max=5.0)
+    sd = init_state_dict(cfg, seed=3)
+    g = make_complex(seed=2, n_res=75, n_lig=7, lm_dim=0)     # 75 receptor neighbours per ligand atom: 32 + 32 + 11 edges
+    b = HeteroBatch.from_data_list(make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.3))
+    set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+    ref = CGModelOracle(cfg, sd, *tables())(b)[:3]
+    monkeypatch.setenv("DDMI_FUSED_DENSE", "2")
+    outs = {}
+    for shared in ("2", "1", "0"):
+        monkeypatch.setenv("DDMI_FUSED_SHARED", shared)
+        m = make_model(cfg, sd, emu_lib)
+        outs[shared] = m(b)[:3]
+        for o, r in zip(outs[shared], ref):
+            assert rel_err(o, r) < 1e-4, shared
+    for k in ("2", "1"):
+        for a_, b_ in zip(outs[k], outs["0"]):
+            assert rel_err(a_, b_) < 1e-5
+
+
 def test_ligand_atoms_with_many_receptor_neighbours(emu_lib):
     """Ligand-gather groups through the fused kernel with several virtual nodes per ligand atom (70 receptor neighbours ->
     32 + 32 + 6 edges: the node term is repeated per virtual node, the last one is a sparse tile) at a width the MFMA first
