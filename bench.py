@@ -80,13 +80,12 @@ def t_schedule(steps):
     return np.linspace(1, 0, steps + 1)[:-1]      # get_t_schedule('expbeta', alpha=beta=1), diffusion_utils.py:138-142
 
 
-def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr, fused=True, fused_lig=True):
+def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr):
     """Algorithmic flops / bytes of every (layer, edge group) launch of the convolution kernels of one forward pass
     (DESIGN.md section 4).  NT = columns of a contracted node row (sum over paths of din*mul_out), K = 3ns + 1.
-    Groups that run k_conv_fused keep the contracted rows in LDS: their HBM bytes are the x rows, the hidden rows and the
-    messages, and their node term is counted once per gather NODE (the kernel repeats it per 32-edge virtual node of a
-    ligand atom -- that repetition is not algorithmic work).  With DDMI_FUSED_LIG=0 the ligand-gather groups run
-    k_node_contract + k_edge_conv with the rows Y in HBM.  `ref_flops` = the same launch priced by SURVEY 8(d)'s formula
+    k_conv_fused keeps the contracted rows in LDS: its HBM bytes are the x rows, the hidden rows and the messages, and the node
+    term is counted once per gather NODE (tiles with more than four distinct nodes repeat it per 32-edge virtual node -- that
+    repetition is not algorithmic work).  `ref_flops` = the same launch priced by SURVEY 8(d)'s formula
     for the REFERENCE's association (per edge 2*(3ns*3ns + 3ns*W) + 6W, W = weight_numel): the re-association removes
     13x of it, so a fraction of peak computed with it would exceed 1."""
     from diffdock_amd.irreps import parse_irreps, sh_irreps
@@ -107,13 +106,8 @@ def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr, fused=True, fused_lig=True):
             H = 3 * cfg.ns
             node_flops, edge_flops = 2.0 * gcount * HK * mac_node, 2.0 * E * HK * NT
             ref_flops = E * (2.0 * (H * H + H * W) + 6.0 * W)
-            if fused and (rec_gather or fused_lig):
-                out.append({"k_conv_fused": {"flops": node_flops + edge_flops, "ref_flops": ref_flops,
-                                             "bytes": gcount * d_in * 4.0 + E * (H * 4.0 + d_out * 4.0)}})
-            else:
-                out.append({"k_edge_conv": {"flops": edge_flops, "ref_flops": ref_flops,
-                                            "bytes": gcount * HK * NT * 4.0 + E * (H * 4.0 + d_out * 4.0) + (gcount + tcount) * H * 4.0},
-                            "k_node_contract": {"flops": node_flops, "ref_flops": 0.0, "bytes": gcount * (HK * NT * 4.0 + d_in * 4.0)}})
+            out.append({"k_conv_fused": {"flops": node_flops + edge_flops, "ref_flops": ref_flops,
+                                         "bytes": gcount * d_in * 4.0 + E * (H * 4.0 + d_out * 4.0)}})
     return out
 
 
@@ -303,8 +297,6 @@ def main():
     if rank == 0:
         # edges actually processed by the last forward of the run, per complex
         edges, work = [], []
-        fused = "k_conv_fused" in timings
-        fused_lig = "k_edge_conv" not in timings
         for j in jobs:
             m = j["model"]
             e_ll, e_lr, e_rr = int(m.debug_buffer("goff_ll")[-1]), int(m.debug_buffer("offs_l")[-1]), int(m.debug_buffer("rr_goff")[-1])
@@ -313,7 +305,7 @@ def main():
                                   "atom_atom": int(m.debug_buffer("aa_goff")[-1]),
                                   "atom_rec_each_direction": int(m.debug_buffer("ar_goff")[-1]),
                                   "atoms": int(j["batch"]["atom"].pos.shape[0])} if args.all_atoms else {})))
-            work += conv_work(cfg, B * j["n_lig"], B * j["n_res"], e_ll, e_lr, e_rr, fused=fused, fused_lig=fused_lig)
+            work += conv_work(cfg, B * j["n_lig"], B * j["n_res"], e_ll, e_lr, e_rr)
         n_forwards = timed_steps * INFERENCE_STEPS * len(jobs)                  # forwards behind `timings`
         n_forwards_timed = args.steps * INFERENCE_STEPS * len(jobs)             # forwards inside the timed region
         # ---- roofline of the dominant kernel.  Headline `frac` = the kernel's algorithmic flops of all forwards of the TIMED
@@ -322,7 +314,7 @@ def main():
         kern = {k: v for k, v in timings.items() if k.startswith("k_") or k == "conv_fc1_gemms"}
         dom = max(kern, key=lambda k: kern[k][0]) if kern else None
         roof, roof_scatter = None, None
-        if dom in ("k_edge_conv", "k_node_contract", "k_conv_fused") and not args.all_atoms:
+        if dom == "k_conv_fused" and not args.all_atoms:
             ms, n = kern[dom]
             avg_s = ms / max(n, 1) * 1e-3
             w_dom = [w[dom] for w in work if dom in w]
@@ -359,9 +351,7 @@ def main():
                                       "k_conv_fused: 2*145*sum(mul_in*mul_out*din) flop per gather node "
                                       "+ 2*145*NT flop per edge (the re-associated contraction, DESIGN 2: 13x fewer flops than the "
                                       "reference's association, which alg_flops_reference_assoc prices by SURVEY 8d's formula), "
-                                      "bytes = x rows + 576 B hidden row + 624 B message per edge; "
-                                      "k_edge_conv: 2*145*NT flop/edge, bytes = contracted rows Y (145*NT*4 B per gather node) + "
-                                      "hidden + message rows; k_node_contract: node flops, Y written once"}
+                                      "bytes = x rows + 576 B hidden row + 624 B message per edge"}
             if streams == 2 and dom == "k_conv_fused" and world == 1 and len(jobs) == 1 and not args.no_serialised_pass:
                 # the same kernel timed with the launches serialised on ONE stream (untimed extra pass, second handle)
                 j = jobs[0]

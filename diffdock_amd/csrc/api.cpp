@@ -29,8 +29,6 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     h->m.device = device;
     try { build_weight_spec(h->m); } catch (...) { delete h; throw; }
     if (const char* e = getenv("DDMI_STREAMS")) h->m.two_streams = atoi(e) != 1;
-    if (const char* e = getenv("DDMI_FUSED")) h->m.fused = atoi(e) != 0;
-    if (const char* e = getenv("DDMI_FUSED_LIG")) h->m.fused_lig = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_PACK")) h->m.fused_pack = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_SHARED")) h->m.fused_shared = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;

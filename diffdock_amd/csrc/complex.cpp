@@ -15,7 +15,6 @@ namespace ddmi {
 struct Model::Cx {
   int B = 0, nL = 0, nR = 0, N = 0, Eb = 0, Err = 0, nT = 0;
   int maxNl = 0, maxNr = 0, Ell_cap = 0, Elr_cap = 0, tor_cap = 32, Et = 0, lig_cap = 33;
-  int y_chunk = 0, esplit_lig = 0;   // tuning knobs (env DDMI_Y_CHUNK / DDMI_ESPLIT); 0 = automatic
   bool uniform = false; int Nl_one = 0, R_one = 0;
   std::vector<int> lig_ptr_h, rec_ptr_h;
   // static
@@ -39,14 +38,14 @@ struct Model::Cx {
   float *ll_dist, *ll_nvec, *ll_ew, *ll_ea;
   int *pairrank, *cnt_l, *cnt_r, *offs_l, *offs_r, *g1_tgt, *g1_tslot, *g3_tgt, *g3_tslot, *pbatch;
   float *pdist, *pnvec, *pew, *cross_ea;
-  float *HE, *P, *Q, *Y; float* msg[4];
-  float *HE_b, *P_b, *Q_b, *Y_b, *rowbias_b;   // second scratch set: ligand-gather groups on the side stream
+  float *HE, *P, *Q; float* msg[4];
+  float *HE_b, *P_b, *Q_b, *rowbias_b;   // second scratch set: ligand-gather groups on the side stream
   // fused form (k_conv_fused): virtual-node lists of the two receptor-gather topologies (0 = lig<-rec cross, 1 = rec-rec),
   // rebuilt when the edge list they were built for changes (once per forward), and the hidden-row scratch
   struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr, *ne = nullptr;
                  float* rows = nullptr;   // per-edge rows of k_conv_fused (k_vn_rows)
                  const int* built_goff = nullptr; long epoch = -1; };
-  VnSet vn[9];           // + 2 = ligand-ligand, 3 = rec<-lig (ligand gather nodes: load mode); all_atoms: 4 la, 5 ra, 6 aa, 7 al, 8 ar
+  VnSet vn[9];           // + 2 = ligand-ligand, 3 = rec<-lig (ligand gather nodes); all_atoms: 4 la, 5 ra, 6 aa, 7 al, 8 ar
   // ---- all_atoms (models/aa_model.py): receptor heavy atoms = third node type, node rows [nL + nR, N)
   int nA = 0, maxNa = 0, Eaa = 0, Ear = 0, Ela_cap = 0;
   int *atom_batch = nullptr, *atom_ptr = nullptr, *atom_x = nullptr;
@@ -136,9 +135,8 @@ struct RunGroup {
   const float* sig; const int* sig_idx;   // optional per-graph vector [B][ns] added to every edge attr row
   const float *nvec, *ew; float sgn;
   float* msg;
-  int esplit = 1;
   int vn = -1;     // >= 0: virtual-node list id -> eligible for the fused kernel
-  bool load = false;   // gather nodes are ligand atoms (few nodes, possibly many edges each): load mode of the fused kernel
+  bool load = false;   // gather nodes are ligand atoms (few nodes, possibly many edges each): candidates for the shared-node tiles of k_conv_fused
   bool swap_pq = false;   // first Linear sees [edge, GATHER node, TARGET node] (legacy lig->rec layer, old_cg_model.py:263)
 };
 
@@ -164,18 +162,17 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     const RunGroup& g = groups[gi];
     const bool side = forked && g.gbase == 0 && g.gcount == c.nL;
     hipStream_t gs = side ? m.side_stream : s;
-    float *HE = side ? c.HE_b : c.HE, *P = side ? c.P_b : c.P, *Q = side ? c.Q_b : c.Q, *Y = side ? c.Y_b : c.Y;
+    float *HE = side ? c.HE_b : c.HE, *P = side ? c.P_b : c.P, *Q = side ? c.Q_b : c.Q;
     float* rowbias = side ? c.rowbias_b : c.rr_rowbias;
     const int wg = std::min<int>((int)gi, L.G - 1);
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
-    // Ligand gather nodes (few nodes, many edges each): the fused kernel contracts per 32-edge virtual node like every other
-    // group (several virtual nodes of an atom repeat its contraction -- cheaper than a round trip of the contracted rows
-    // through HBM); DDMI_FUSED_LIG=0 runs them unfused (k_node_contract + k_edge_conv).
-    const bool lig_ok = !g.load || m.fused_lig != 0;
-    const bool fuse = m.fused && g.vn >= 0 && L.n_fgran > 0 && c.Hb && lig_ok;
+    // Every edge group runs k_conv_fused (a node-contracted layer always has its granule list; ligand gather nodes with many
+    // edges are cut into 32-edge virtual nodes like the others -- several virtual nodes of an atom share its contraction in the
+    // shared-node tiles, mode 4 of the kernel).
+    DDMI_REQUIRE(g.vn >= 0 && L.n_fgran > 0 && c.Hb, DDMI_ERR_STATE, "convolution layer without a granule list / virtual-node set");
     float* Hb = side ? c.Hb_b : c.Hb;
-    const bool fuse_mm = fuse && m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
+    const bool fuse_mm = m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
     if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
       PhaseTimer t(m, "conv_fc1_gemms", gs);
       const float* W1p = L.W1p[wg];
@@ -198,7 +195,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       gemm(Xin + (size_t)g.tbase * XS, XS, W1 + (g.swap_pq ? 2 : 1) * ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
       gemm(Xin + (size_t)g.gbase * XS, XS, W1 + (g.swap_pq ? 1 : 2) * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
     }
-    if (fuse) {
+    {
       Cx::VnSet& vs = c.vn[g.vn];
       if (vs.built_goff != g.goff || vs.epoch != c.epoch) {
         PhaseTimer t(m, "vn_build", gs);
@@ -235,8 +232,20 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
       int ys_req = m.fused_ysplit;
       if (ys_req <= 0) {
-        const long est_tiles = std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16);
-        ys_req = (int)std::min(6L, std::max(1L, 768 / est_tiles));   // (measured at 5 / 10 / 20 / 40 poses: beyond 6 the repeated prologues cost more than the extra workgroups bring)
+        // Small batches (no group of the layer fills the chip once; tiles ~ gather nodes x ceil(mean degree / 32) / 16): up to
+        // one granule per workgroup, 5 poses 94 -> 100 poses/s.  Otherwise the round-2 rule (at most 6 ranges, tiles estimated
+        // from nodes + edges / 32): the small lig-lig launch that runs next to the big groups is sensitive to its split -- 4
+        // ranges at 40 poses; 5-6 cost the headline 2.5 % (profiles/r03_e27..e37_ab.txt).
+        auto tiles_of = [](const RunGroup& q) {
+          const long gn = std::max(1, q.gcount);
+          return std::max(1L, gn * (((long)q.ea_rows / gn + 31) / 32) / 16);
+        };
+        long biggest = 1;
+        for (auto& q : groups) biggest = std::max(biggest, tiles_of(q));
+        if (biggest < 256) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
+        else ys_req = (int)std::min(6L, std::max(1L, 768 / std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16)));
+        static const int ys_small = getenv("DDMI_FUSED_YS_SMALL") ? atoi(getenv("DDMI_FUSED_YS_SMALL")) : 0;   // tuning: split of a small group next to big ones
+        if (ys_small > 0 && biggest >= 256 && tiles_of(g) < 256) ys_req = ys_small;
       }
       ys_req = std::max(ys_req, (L.n_fgran + 19) / 20);   // a workgroup keeps at most 24 granule descriptors in LDS
       const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
@@ -265,25 +274,6 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         PhaseTimer t(m, "k_conv_fused", gs);
         launch_conv_fused(f, gs);
       }
-      continue;
-    }
-    EdgeConvArgs a{};
-    a.tgt = g.tgt; a.tslot = g.tslot; a.arow = g.arow; a.tbase = g.tbase;
-    a.HE = HE; a.P = P; a.Y = Y; a.nvec = g.nvec; a.ew = g.ew; a.sgn = g.sgn;
-    a.H = H; a.HKp = L.HKp; a.NTs = L.NTs; a.sh_lmax = m.cfg.sh_lmax; a.D_out = L.D_out; a.GN = L.GN; a.n_ob = L.n_ob;
-    a.maxd = L.maxd; a.obs = L.obs; a.qdesc = L.qdesc; a.paths = L.paths; a.ctab = L.ctab; a.gmap = L.gmap; a.msg = g.msg;
-    a.esplit = g.esplit > 0 ? g.esplit : 1;
-    // gather nodes are processed in chunks whose contracted rows (341 KB each at ns=48) fit the scratch Y buffer
-    const int chunk = c.y_chunk > 0 ? std::min(c.y_chunk, g.gcount) : g.gcount;
-    for (int d0 = 0; d0 < g.gcount; d0 += chunk) {
-      const int n = std::min(chunk, g.gcount - d0);
-      {
-        PhaseTimer t(m, "k_node_contract", gs);
-        launch_node_contract(Xin, g.gbase + d0, n, L.wpack[wg], L.nc_units, L.n_nc, L.KS, L.HK, L.HKp, L.NTs, Y, gs);
-      }
-      a.gcount = n; a.goff = g.goff + d0; a.Q = Q + (size_t)d0 * H;
-      PhaseTimer t(m, "k_edge_conv", gs);
-      launch_edge_conv(a, gs);
     }
   }
   if (forked) {
@@ -546,26 +536,14 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.HE = dalloc<float>(m, nullptr, {max_rows, H}); c.P = dalloc<float>(m, nullptr, {N, H}); c.Q = dalloc<float>(m, nullptr, {N, H});
   c.HE_b = dalloc<float>(m, nullptr, {std::max(std::max(c.Ell_cap, c.Elr_cap), c.Ela_cap), H}); c.P_b = dalloc<float>(m, nullptr, {N, H});
   c.Q_b = dalloc<float>(m, nullptr, {N, H}); c.rowbias_b = dalloc<float>(m, nullptr, {B, H});
-  int HKp = 0, NTs = 0;
-  auto upd = [&](const ConvW& L) { HKp = std::max(HKp, L.HKp); NTs = std::max(NTs, L.NTs); };
   std::vector<const ConvW*> all_layers;
   for (auto* fam : {&m.conv_layers, &m.lig_emb_layers, &m.rec_emb_layers, &m.old_lig, &m.old_rec, &m.old_l2r, &m.old_r2l})
     for (auto& L : *fam) all_layers.push_back(&L);
-  for (auto* L : all_layers) upd(*L);
-  if (const char* e = getenv("DDMI_Y_CHUNK")) c.y_chunk = atoi(e);
-  if (const char* e = getenv("DDMI_ESPLIT")) c.esplit_lig = std::max(0, atoi(e));
-  // rows of the HBM-resident contracted table: receptor / atom gather groups only need them when the fused kernel is off
-  const int y_big = std::max(std::max(nL, nR), m.fused ? 0 : c.nA);
-  const int y_nodes = c.y_chunk > 0 ? std::min(c.y_chunk, y_big) : y_big;
-  int ycols = NTs;   // granule-major rows (load mode of k_conv_fused) are 64 columns per granule
-  for (auto* L : all_layers) ycols = std::max(ycols, 64 * L->n_fgran);
-  c.Y = dalloc<float>(m, nullptr, {y_nodes, HKp, ycols}, true);
-  c.Y_b = dalloc<float>(m, nullptr, {c.y_chunk > 0 ? std::min(c.y_chunk, nL) : nL, HKp, ycols}, true);
-  if (m.fused) {
+  {
     int HKq = 0;
     for (auto* L : all_layers) HKq = std::max(HKq, L->HKq);
     // virtual-node lists: 0 lig<-rec, 1 rec-rec, 2 lig-lig, 3 rec<-lig; all_atoms: 4 lig<-atom, 5 rec<-atom, 6 atom-atom,
-    // 7 atom<-lig, 8 atom<-rec.  Ligand-gather lists (2, 3, 7) are load-mode lists (every node padded to an even count).
+    // 7 atom<-lig, 8 atom<-rec.  (lig_v: lists of the side-stream groups, which use the second hidden-row scratch.)
     const int ecap_v[9] = {c.Elr_cap, c.Err, c.Ell_cap, c.Elr_cap, c.Ela_cap, c.Ear, c.Eaa, c.Ela_cap, c.Ear};
     const int gn_v[9] = {nR, nR, nL, nL, c.nA, c.nA, c.nA, nL, nR};
     const bool lig_v[9] = {false, false, true, true, false, false, false, true, false};
@@ -574,7 +552,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     int vmax = 0, vmax_b = 0;
     for (int i = 0; i < (cfg.all_atoms ? 9 : 4); ++i) {
       Cx::VnSet& vs = c.vn[i];
-      vs.vcap = (lig_v[i] ? 2 : 1) * gn_v[i] + ecap_v[i] / 32 + 2;
+      vs.vcap = gn_v[i] + ecap_v[i] / 32 + 2;   // a gather node with deg edges: ceil(deg / 32) <= deg / 32 + 1 virtual nodes
       vs.cnt = dalloc<int>(m, nullptr, {gn_v[i] + 1}); vs.voff = dalloc<int>(m, names[i], {gn_v[i] + 1});
       vs.node = dalloc<int>(m, nullptr, {vs.vcap}); vs.e0 = dalloc<int>(m, nullptr, {vs.vcap});
       const int shd = (cfg.sh_lmax + 1) * (cfg.sh_lmax + 1);
@@ -883,7 +861,6 @@ static void forward_old(Model& m, const float* lig_pos, const float* t_tr, const
   RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                 nullptr, c.pnvec, c.pew, 1.f, c.msg[3]};   // same spherical harmonics as rec->lig (old_cg_model.py:264)
   g_ll.vn = 2; g_ll.load = true; g_lr.vn = 0; g_rr.vn = 1; g_rl.vn = 3; g_rl.load = true; g_rl.swap_pq = true;
-  g_rl.esplit = c.esplit_lig > 0 ? c.esplit_lig : std::max(1, std::min(8, (c.Elr_cap / std::max(nL, 1) + 63) / 64));
   float *Ua = c.X[Lc + 1], *Ub = c.X[Lc + 2];
   t_phase.reset();
   for (int l = 0; l < Lc; ++l) {
@@ -1033,7 +1010,6 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
                 nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
   g_lr.vn = 0; g_rr.vn = 1; g_rl.vn = 3; g_rl.load = true;
   // ligand gather nodes carry up to Nr edges each: their 32-edge passes are dealt over several workgroups
-  g_rl.esplit = c.esplit_lig > 0 ? c.esplit_lig : std::max(1, std::min(8, (c.Elr_cap / std::max(nL, 1) + 63) / 64));
   const int Lc = (int)m.conv_layers.size();
   if (cfg.all_atoms) {
     // ---- all-atom model (aa_model.py:364-436): atom rows, ligand<->atom radius graph, nine edge groups
@@ -1065,7 +1041,6 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     RunGroup a_ar{nL, nR, aB, nA, c.se_ar.goff, c.se_ar.tgt, c.se_ar.tslot, c.se_ar.arow, c.ar_edge_base, c.Ear, nullptr, c.rec_sig,
                   c.ar_batch, c.ar_nvec, nullptr, 1.f, c.msg_aa[8]};
     a_la.vn = 4; a_ra.vn = 5; a_aa.vn = 6; a_al.vn = 7; a_al.load = true; a_ar.vn = 8;
-    a_al.esplit = c.esplit_lig > 0 ? c.esplit_lig : 1;
     t_phase.reset();
     for (int l = 0; l < Lc; ++l, ++xi) {
       if (l < Lc - 1)

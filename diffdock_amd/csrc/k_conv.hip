@@ -11,10 +11,8 @@
 //   T[e][n]     = sum_k h_e[k] * Y[d(e)][k][n]               (MFMA 16x16x4 f32)           edge product
 //   m_e[o,w,k'] = sum_{paths,i,j} C[i][j][k'] sh_e[j] T[e][path,i,w]                       coupling with sh_e
 //   k_reduce_bn : deterministic segmented mean over the target-CSR, BatchNorm, residual
-// k_conv_fused does the first three per tile of 16 virtual nodes with Y never leaving LDS (default for every edge group);
-// k_node_contract + k_edge_conv are the same steps with Y in HBM (DDMI_FUSED=0 / DDMI_FUSED_LIG=0), and k_node_contract
-// also feeds the load mode of k_conv_fused.  k_edge_hidden(_mm) produces h_e in the fused kernel's A-fragment order.
-// Results equal the reference up to fp32 re-association.
+// k_conv_fused does the first three per tile of 16 virtual nodes with Y never leaving LDS (every edge group of every layer);
+// k_edge_hidden(_mm) produces h_e in its A-fragment order.  Results equal the reference up to fp32 re-association.
 #include <algorithm>
 #include <cstdlib>
 
@@ -26,16 +24,10 @@
 
 namespace ddmi {
 
-// ------------------------------------------------------------------ node pre-contraction
-// Workgroup = 16 gather nodes x KC consecutive k (rows of W2^T incl. the bias row).  Per k the four waves
-// share the (path, 16-wide w tile) work items: A = x rows from LDS (one fragment per input component i),
-// B = the k-th slab of the packed second-layer weights (L2-resident, 4 MB per edge group), v_mfma_f32_16x16x4_f32,
-// results scattered into an LDS row image in the item-major column order and then streamed out as 256-B runs
-// Y[node][super-tile][k][64] -- the exact order k_edge_conv reads them back.
 // x tile rows in LDS: stride 162 = 2 (mod 32).  An A fragment read has lane (node lr, quarter lq) at lr * stride + din * lq + c
 // (din = 1 or 3: odd): the 16 nodes land on 16 distinct EVEN banks and the next quarter on the odd ones -- conflict-free per
 // 32-lane half; an odd stride (161) put (lr, lq) and (lr + din, lq - 1) on one bank (2-way on almost every read).
-constexpr int NC_NODES = 32, NC_KC = 15, NC_XS = XS + 2;
+constexpr int NC_XS = XS + 2;
 
 // Profiling builds only (-DDDMI_PROFILING, tools/build_variant.sh): DDMI_ABLATE switches individual kernel phases off
 // (garbage scores, timing only) and k_conv_fused accumulates per-phase cycle counts (fc_prof_report).  The shipped library
@@ -100,10 +92,6 @@ struct FcProf {};
 #endif
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void nt_store4(float* p, float a, float b, float c, float d) {
-  vf4 v = {a, b, c, d};
-  DDMI_NT_STORE(v, reinterpret_cast<vf4*>(p));
-}
 __device__ __forceinline__ float4 nt_load4(const float* p) {
   const vf4 v = DDMI_NT_LOAD(reinterpret_cast<const vf4*>(p));
   return make_float4(v[0], v[1], v[2], v[3]);
@@ -111,30 +99,6 @@ __device__ __forceinline__ float4 nt_load4(const float* p) {
 
 // fragment j of a lane's chain inside the packed weights (layout: see nc_lane_off)
 __device__ __forceinline__ int nc_fo(int j, int pstride) { return (j >> 2) * pstride + (j & 3); }
-
-// One slot (= one column of every item of the unit) for TWO 16-node sub-tiles sharing the weight fragments:
-//   acc[t] += sum_u x[node_t][u, comp] * W2[k][path][u][w]        (16 nodes x 16 w each, v_mfma_f32_16x16x4_f32)
-// NSTEPS = MFMA steps per chain, fully unrolled: all B (L2) and A (LDS) fragments are requested first, then the chains.
-// Rows u >= mul_in of the packed weights are zero, so the x fragments need no predicate there (they read the
-// neighbouring block of the finite x row).
-template <int NSTEPS>
-__device__ __forceinline__ void nc_chain(const float* __restrict__ bp, const float* __restrict__ xp,
-                                         int xstride, f32x4& acc0, f32x4& acc1, int dbg, int ps) {
-  float bv[NSTEPS], a0[NSTEPS], a1[NSTEPS];
-#pragma unroll
-  for (int j = 0; j < NSTEPS; ++j) {
-    bv[j] = DDMI_ABL(dbg, 256) ? 0.f : bp[nc_fo(j, ps)];   // 4 consecutive fragments of a lane are contiguous: vector loads
-    a0[j] = xp[j * xstride];
-    a1[j] = xp[16 * NC_XS + j * xstride];
-  }
-  if (!DDMI_ABL(dbg, 512)) {
-#pragma unroll
-    for (int j = 0; j < NSTEPS; ++j) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bv[j], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bv[j], acc1, 0, 0, 0);
-    }
-  }
-}
 
 // Packed second-layer weights of one (k, path), per 16-w tile (u = 4j + lq, w = 16*tile + lr, lane = 16*lq + lr):
 //   chains of whole 4-step pieces (mul_in % 16 == 0):  [piece j/4][lane 64][j % 4]  -- a wave's 16-B request per piece is one
@@ -146,112 +110,7 @@ __device__ __forceinline__ int nc_lane_off(const NcSlot& S, int w0, int lr, int 
   const int steps = S.u_pad >> 2;
   return (w0 >> 4) * 64 * steps + (lq * 16 + lr) * ((steps & 3) == 0 ? 4 : steps);
 }
-struct NcSlotRt { const float* bp; const float* xp; int xstride, steps, ps; };   // per-lane, k-invariant part
-
-__device__ __forceinline__ NcSlotRt nc_slot_setup(const NcSlot S, const float* __restrict__ wpack, const float* __restrict__ xbuf,
-                                                  int w0, int lr, int lq) {
-  NcSlotRt R;
-  R.steps = S.din == 0 ? 0 : (S.u_pad >> 2);
-  R.bp = wpack + S.wk_off + nc_lane_off(S, w0, lr, lq);
-  R.ps = nc_pstride(S.u_pad >> 2);
-  R.xp = xbuf + lr * NC_XS + S.x_off + lq * S.din + S.comp;
-  R.xstride = 4 * S.din;
-  return R;
-}
-
-__device__ __forceinline__ void nc_slot(const NcSlotRt& R, size_t koff, f32x4& acc0, f32x4& acc1, int dbg) {
-  acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-  acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* __restrict__ bp = R.bp + koff;
-  const float* __restrict__ xp = R.xp;
-  int steps = R.steps;
-  const int ps = R.ps;   // whole 4-step pieces advance by ps floats (4 with the per-lane layout)
-  while (steps >= 12) { nc_chain<12>(bp, xp, R.xstride, acc0, acc1, dbg, ps); bp += 3 * ps; xp += 12 * R.xstride; steps -= 12; }
-  if (steps >= 8) { nc_chain<8>(bp, xp, R.xstride, acc0, acc1, dbg, ps); bp += 2 * ps; xp += 8 * R.xstride; steps -= 8; }
-  if (steps >= 4) { nc_chain<4>(bp, xp, R.xstride, acc0, acc1, dbg, ps); bp += ps; xp += 4 * R.xstride; steps -= 4; }
-  if (steps == 3) nc_chain<3>(bp, xp, R.xstride, acc0, acc1, dbg, ps);
-  else if (steps == 2) nc_chain<2>(bp, xp, R.xstride, acc0, acc1, dbg, ps);
-  else if (steps == 1) nc_chain<1>(bp, xp, R.xstride, acc0, acc1, dbg, ps);
-}
-
-// Workgroup = 32 gather nodes (two 16-row MFMA sub-tiles) x KC consecutive k.  The x rows sit in LDS (read-only after
-// the prologue: no barriers in the main loop).  Each wave owns whole (output block, 16-w tile) units and, per quad of
-// item columns, walks the k range with all addresses hoisted: because the columns are item-major, the accumulators of
-// 4 consecutive slots of a lane ARE 4 consecutive columns of Y, so every lane stores 16-B pieces and 16 lanes cover a
-// 256-B run of one node row -- straight from the MFMA result registers, no staging.
-__global__ __launch_bounds__(256, 2) void k_node_contract(const float* __restrict__ X, int gbase, int gcount,
-                                                       const float* __restrict__ wpack,
-                                                       const NcUnit* __restrict__ units, int n_units, int KS, int HK,
-                                                       int HKp, int NTs, float* __restrict__ Y, int dbg, int kc) {
-  DDMI_DYN_SMEM(float, smem);
-  float* xbuf = smem;                                   // [32][XS+1]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int node0 = blockIdx.x * NC_NODES;
-  const int n_super = NTs >> 6;
-  const int k_begin = blockIdx.y * kc, k_end = min(k_begin + kc, HK);
-  for (int idx = tid; idx < NC_NODES * XS; idx += 256) {
-    const int nl = idx / XS, c = idx - nl * XS;
-    xbuf[nl * NC_XS + c] = (node0 + nl) < gcount ? X[(size_t)(gbase + node0 + nl) * XS + c] : 0.f;
-  }
-  __syncthreads();
-  const int lr = lane & 15, lq = lane >> 4;
-  const int n_live = min(NC_NODES, gcount - node0);
-  const size_t node_stride = (size_t)n_super * HKp * 64;
-  for (int it = wave; it < n_units; it += 4) {
-    const NcUnit& U = units[it];
-    if (U.n_w == 0) continue;
-    const int col = U.col_base + (U.w0 + lr) * U.itemw;
-    for (int q = 0; q < (U.itemw >> 2); ++q) {
-      const NcSlotRt s0 = nc_slot_setup(U.slot[4 * q + 0], wpack, xbuf, U.w0, lr, lq);
-      const NcSlotRt s1 = nc_slot_setup(U.slot[4 * q + 1], wpack, xbuf, U.w0, lr, lq);
-      const NcSlotRt s2 = nc_slot_setup(U.slot[4 * q + 2], wpack, xbuf, U.w0, lr, lq);
-      const NcSlotRt s3 = nc_slot_setup(U.slot[4 * q + 3], wpack, xbuf, U.w0, lr, lq);
-      const int c = col + 4 * q;
-      float* __restrict__ yp = Y + (size_t)node0 * node_stride + ((size_t)(c >> 6) * HKp) * 64 + (c & 63);
-      for (int k = k_begin; k < k_end; ++k) {
-        const size_t koff = (size_t)k * KS;
-        f32x4 a00, a01, a10, a11, a20, a21, a30, a31;
-        nc_slot(s0, koff, a00, a01, dbg);
-        nc_slot(s1, koff, a10, a11, dbg);
-        nc_slot(s2, koff, a20, a21, dbg);
-        nc_slot(s3, koff, a30, a31, dbg);
-        if (lr < U.n_w && !DDMI_ABL(dbg, 2048)) {
-          float* __restrict__ yk = yp + (size_t)k * 64;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int n0 = 4 * lq + r;
-            if (n0 < n_live) nt_store4(yk + (size_t)n0 * node_stride, a00[r], a10[r], a20[r], a30[r]);
-            if (n0 + 16 < n_live) nt_store4(yk + (size_t)(n0 + 16) * node_stride, a01[r], a11[r], a21[r], a31[r]);
-          }
-        }
-      }
-    }
-  }
-}
-
-void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcUnit* units, int n_units,
-                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s) {
-  if (gcount <= 0 || n_units <= 0) return;
-  const size_t smem = (size_t)(NC_NODES * NC_XS) * sizeof(float);
-  // k rows per workgroup: 15 for large node sets (each x tile is read HK/15 times); fewer for small ones (ligand atoms), so
-  // that the launch still spreads over >= ~1500 workgroups
-  int kc = NC_KC;
-  while (kc > 3 && (long)cdiv(gcount, NC_NODES) * cdiv(HK, kc) < 1500) kc -= 2;
-  dim3 grid(cdiv(gcount, NC_NODES), cdiv(HK, kc));
-  hipLaunchKernelGGL(k_node_contract, grid, dim3(256), smem, s, X, gbase, gcount, wpack, units, n_units, KS, HK, HKp, NTs, Y,
-                     ablate_mask(), kc);
-  DDMI_CHECK_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------ edge kernel
-// One workgroup per (gather node d, split); edges are processed 32 at a time (two 16-row MFMA tiles):
-//   phase 1  h[32][HKp] = relu(HE[arow] + P[tgt] + Q[d]) (+) 1, per-edge coupling vectors
-//            G[e][path][i][k'] = sum_j C[i][j][k'] sh_e[j]                                       -> LDS
-//   phase 2  wave w owns the 64-column super-tiles w, w+W, ..: T = h * Y_d on v_mfma_f32_16x16x4_f32, Y_d streamed
-//            from HBM in its storage order with a 2-deep register prefetch (one 16-B load feeds 8 MFMAs); the
-//            accumulators never leave registers: lane (l&15) of a 16-lane group holds one quad of an item for 4
-//            edges, contracts it with G, sums the item's quads with wave shuffles -> message image in LDS
-//   phase 3  message rows streamed to their slots of the target-ordered buffer (no atomics, deterministic)
+// real spherical harmonics of a unit edge vector (component normalisation, e3nn order), l <= lmax
 __device__ __forceinline__ void edge_sh(const float* n, float sgn, int lmax, float* sh) {
   const float x = sgn * n[0], y = sgn * n[1], z = sgn * n[2];
   sh[0] = 1.f;
@@ -267,202 +126,6 @@ __device__ __forceinline__ void edge_sh(const float* n, float sgn, int lmax, flo
   } else {
     sh[4] = sh[5] = sh[6] = sh[7] = sh[8] = 0.f;
   }
-}
-
-constexpr int EC_E = 32;   // edges per pass
-
-template <int MAXD>
-__global__ __launch_bounds__(256, 3) void k_edge_conv(EdgeConvArgs a) {
-  DDMI_DYN_SMEM(float, smem);
-  const int HS = a.HKp + 1;                          // odd row stride: conflict-free A-fragment reads
-  const int GS = a.GN | 1, MS = a.D_out | 1;
-  float* hbuf = smem;                                // [32][HS]
-  float* gbuf = hbuf + EC_E * HS;                    // [32][GS]
-  float* mbuf = gbuf + EC_E * GS;                    // [32][MS]
-  float* shbuf = mbuf + EC_E * MS;                   // [32][10]: sh(9), edge weight
-  int* ibuf = reinterpret_cast<int*>(shbuf + EC_E * 10);   // [32][3]: arow, tgt - tbase, tslot
-  // (gather node, split) from the linear workgroup id: consecutive ids are dealt round-robin over the 8 XCDs, so the
-  // splits of one node take ids 8 apart -- same XCD, dispatched together -- and share the node's rows Y_d in that L2
-  int d = blockIdx.x, split = 0;
-  if (a.esplit > 1) {
-    const int id = blockIdx.x, blk = 8 * a.esplit;
-    const int base = (id / blk) * 8;
-    if (base + 8 <= a.gcount) { d = base + id % 8; split = (id / 8) % a.esplit; }
-    else { const int rem = a.gcount - base, r = id - (id / blk) * blk; d = base + r % rem; split = r / rem; }   // ragged tail
-  }
-  const int e_begin = a.goff[d], e_end = a.goff[d + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
-  const int n_super = a.NTs >> 6;
-  const float* __restrict__ Yd = a.Y + (size_t)d * n_super * a.HKp * 64;
-  const float* __restrict__ Qd = a.Q + (size_t)d * a.H;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int H4 = a.H >> 2;                           // H = 3*ns is a multiple of 4 for every supported ns
-  int pass = 0;
-  for (int e0 = e_begin; e0 < e_end; e0 += EC_E, ++pass) {
-    if (pass % a.esplit != split) continue;
-    const int ne = min(EC_E, e_end - e0);
-    // ---- phase 1a: per-edge indices, spherical harmonics, weight
-    if (tid < EC_E) {
-      float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      float w = 0.f;
-      int ar = 0, tg = 0, slot = 0;
-      if (tid < ne) {
-        const int e = e0 + tid;
-        ar = a.arow ? a.arow[e] : e;
-        tg = a.tgt[e] - a.tbase;
-        slot = a.tslot[e];
-        edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
-        w = a.ew ? a.ew[ar] : 1.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 9; ++j) shbuf[tid * 10 + j] = sh[j];
-      shbuf[tid * 10 + 9] = w;
-      ibuf[tid * 3] = ar; ibuf[tid * 3 + 1] = tg; ibuf[tid * 3 + 2] = slot;
-    }
-    __syncthreads();
-    // ---- phase 1b: h rows (16-B loads), bias column, coupling vectors
-    for (int idx = tid; idx < EC_E * H4; idx += nthr) {
-      const int el = idx / H4, k4 = idx - el * H4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (el < ne && !DDMI_ABL(a.dbg, 1)) {
-        const float4 x = nt_load4(a.HE + (size_t)ibuf[el * 3] * a.H + 4 * k4);
-        const float4 p = *reinterpret_cast<const float4*>(a.P + (size_t)ibuf[el * 3 + 1] * a.H + 4 * k4);
-        const float4 q = *reinterpret_cast<const float4*>(Qd + 4 * k4);
-        v.x = fmaxf(x.x + p.x + q.x, 0.f); v.y = fmaxf(x.y + p.y + q.y, 0.f);
-        v.z = fmaxf(x.z + p.z + q.z, 0.f); v.w = fmaxf(x.w + p.w + q.w, 0.f);
-      }
-      float* hp = hbuf + el * HS + 4 * k4;
-      hp[0] = v.x; hp[1] = v.y; hp[2] = v.z; hp[3] = v.w;
-    }
-    for (int idx = tid; idx < EC_E * (a.HKp - a.H); idx += nthr) {
-      const int el = idx / (a.HKp - a.H), k = a.H + idx - el * (a.HKp - a.H);
-      hbuf[el * HS + k] = (k == a.H && el < ne) ? 1.f : 0.f;
-    }
-    for (int idx = tid; idx < ne * a.GN; idx += nthr) {
-      const int el = idx / a.GN, g = idx - el * a.GN;
-      const GEntry G = a.gmap[g];
-      const float* __restrict__ sh = shbuf + el * 10 + G.s_off;
-      float acc = 0.f;
-      for (int j = 0; j < G.ds; ++j) acc = fmaf(a.ctab[G.c_idx + j * G.dout], sh[j], acc);
-      gbuf[el * GS + g] = acc;
-    }
-    __syncthreads();
-    // ---- phase 2
-    const bool two = ne > 16;
-    for (int st = wave; st < n_super; st += nwave) {
-      const int col0 = st * 64 + 4 * lr;
-      f32x4 acc0[4], acc1[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { acc0[c] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      const float* __restrict__ hp0 = hbuf + lr * HS + lq;
-      const float* __restrict__ hp1 = hp0 + 16 * HS;
-      const float* __restrict__ yp = Yd + ((size_t)st * a.HKp + lq) * 64 + 4 * lr;
-      // Y_d super-tile streamed in blocks of 4 k-steps (4 x 16 B per lane), next block in flight during the 32 MFMAs
-      const int nsteps = a.HKp >> 2;
-      float4 cur[4], nxt[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cur[j] = (j < nsteps && !DDMI_ABL(a.dbg, 2)) ? nt_load4(yp + (size_t)j * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s0 = 0; s0 < nsteps; s0 += 4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          nxt[j] = ((s0 + 4 + j) < nsteps && !DDMI_ABL(a.dbg, 2)) ? nt_load4(yp + (size_t)(s0 + 4 + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (s0 + j >= nsteps || DDMI_ABL(a.dbg, 4)) break;
-          const float4 b = cur[j];
-          const float a0 = hp0[(s0 + j) * 4];
-          acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc0[0], 0, 0, 0);
-          acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.y, acc0[1], 0, 0, 0);
-          acc0[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.z, acc0[2], 0, 0, 0);
-          acc0[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.w, acc0[3], 0, 0, 0);
-          if (two) {
-            const float a1 = hp1[(s0 + j) * 4];
-            acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.x, acc1[0], 0, 0, 0);
-            acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc1[1], 0, 0, 0);
-            acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.z, acc1[2], 0, 0, 0);
-            acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.w, acc1[3], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
-      }
-      // coupling in registers: this lane's quad = columns col0 .. col0+3 (all private arrays statically indexed)
-      int ob = -1;
-      for (int b = 0; b < a.n_ob; ++b)
-        if (col0 >= a.obs[b].base && col0 < a.obs[b].base + a.obs[b].mul * a.obs[b].itemw) ob = b;
-      ObInfo O{0, 4, 0, 0, 1};
-      int w = 0, qi = 0;
-      int g0 = -1, g1 = -1, g2 = -1, g3 = -1;
-      if (ob >= 0) {
-        O = a.obs[ob];
-        const int rel = col0 - O.base;
-        w = rel / O.itemw;
-        qi = (rel - w * O.itemw) >> 2;
-        const QuadDesc qd = a.qdesc[ob * 4 + qi];
-        g0 = qd.path[0] >= 0 ? a.paths[qd.path[0]].g_off + qd.comp[0] * O.dout : -1;
-        g1 = qd.path[1] >= 0 ? a.paths[qd.path[1]].g_off + qd.comp[1] * O.dout : -1;
-        g2 = qd.path[2] >= 0 ? a.paths[qd.path[2]].g_off + qd.comp[2] * O.dout : -1;
-        g3 = qd.path[3] >= 0 ? a.paths[qd.path[3]].g_off + qd.comp[3] * O.dout : -1;
-      }
-      const int nq = O.itemw >> 2;
-      const bool writer = ob >= 0 && qi == 0;
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        if ((rt == 1 && !two) || DDMI_ABL(a.dbg, 8)) break;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int el = rt * 16 + 4 * lq + r;
-          const float* __restrict__ G = gbuf + el * GS;
-          const float t0 = rt == 0 ? acc0[0][r] : acc1[0][r], t1 = rt == 0 ? acc0[1][r] : acc1[1][r];
-          const float t2 = rt == 0 ? acc0[2][r] : acc1[2][r], t3 = rt == 0 ? acc0[3][r] : acc1[3][r];
-          float m[MAXD];
-#pragma unroll
-          for (int k = 0; k < MAXD; ++k) {
-            float v = 0.f;
-            if (k < O.dout) {
-              if (g0 >= 0) v = fmaf(G[g0 + k], t0, v);
-              if (g1 >= 0) v = fmaf(G[g1 + k], t1, v);
-              if (g2 >= 0) v = fmaf(G[g2 + k], t2, v);
-              if (g3 >= 0) v = fmaf(G[g3 + k], t3, v);
-            }
-            const float m1 = __shfl_down(v, 1, 64);     // sum the item's quads (items never straddle a 16-lane group)
-            if (nq >= 2) v += m1;
-            const float m2 = __shfl_down(v, 2, 64);
-            if (nq >= 4) v += m2;
-            m[k] = v;
-          }
-          if (writer && el < ne) {
-            float* __restrict__ mp = mbuf + el * MS + O.o_off + w * O.dout;
-            const float we = shbuf[el * 10 + 9];
-#pragma unroll
-            for (int k = 0; k < MAXD; ++k)
-              if (k < O.dout) mp[k] = we * m[k];
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // ---- phase 3
-    for (int idx = tid; idx < ne * a.D_out && !DDMI_ABL(a.dbg, 16); idx += nthr) {
-      const int el = idx / a.D_out, c = idx - el * a.D_out;
-      DDMI_NT_STORE(mbuf[el * MS + c], a.msg + (size_t)ibuf[el * 3 + 2] * XS + c);
-    }
-    __syncthreads();
-  }
-}
-
-void launch_edge_conv(const EdgeConvArgs& a_in, hipStream_t s) {
-  if (a_in.gcount <= 0) return;
-  EdgeConvArgs a = a_in;
-  a.dbg = ablate_mask();
-  const int HS = a.HKp + 1, GS = a.GN | 1, MS = a.D_out | 1;
-  const size_t smem = (size_t)(EC_E * (HS + GS + MS) + 13 * EC_E) * sizeof(float);
-  const int n_super = a.NTs >> 6;
-  const int waves = n_super < 4 ? n_super : 4;   // 3 workgroups of 4 waves per CU: their phases interleave
-  if (a.H % 4 != 0) throw Error(DDMI_ERR_ARG, "3*ns must be a multiple of 4");
-  if (a.maxd <= 3) hipLaunchKernelGGL(k_edge_conv<3>, dim3(a.gcount * a.esplit), dim3(64 * waves), smem, s, a);
-  else hipLaunchKernelGGL(k_edge_conv<5>, dim3(a.gcount * a.esplit), dim3(64 * waves), smem, s, a);
-  DDMI_CHECK_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------ fused contraction + edge kernel
@@ -869,6 +532,9 @@ struct FcOrder {   // issue order of the slot chains: slot 0 alternating with th
 // 16x16x4 form): a quarter of the matrix-core time per pass.  The four channel partials of a column sit in the four lane
 // rows; a reduce-scatter by row / half swaps leaves node slot lq in lane row lq, stored with one request per chain.
 // ywr: SH ? chunk row `wave` of node slot lq, column lr : of node 4lq (+r); yrd: SH ? without the node term : node 2*wave.
+#ifndef FC_R0B_ALL
+#define FC_R0B_ALL 1
+#endif
 template <int NBK, int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3, bool SH = false>
 __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
                                                   int KS, int HK, int NG8, int wave, int lane,
@@ -913,6 +579,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       bw[t][0] = v.x; bw[t][1] = v.y; bw[t][2] = v.z;
     }
   };
+  constexpr bool FC_R0B = SH || FC_R0B_ALL;
   auto cmma = [](float av, float bv, f32x4 c) __attribute__((always_inline)) -> f32x4 {   // contraction MFMA
 #ifdef FCV_NOCMMA   // timing-only: no contraction MFMAs (the weight requests stay alive)
     c[0] += bv; (void)av;
@@ -981,12 +648,12 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       fc_sfor<0, NC>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int t = O::slot(i);
-        if constexpr (t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa[i], bw[wsl(t)][O::step(i)], r0b);
+        if constexpr (FC_R0B && t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa[i], bw[wsl(t)][O::step(i)], r0b);
         else r[t] = cmma(xa[i], bw[wsl(t)][O::step(i)], r[t]);
         if (i == NC - 3) readq(0, eb, 0);
         DDMI_SCHED_FENCE();
       });
-      if constexpr (S0 > 3) r[0] += r0b;
+      if constexpr (FC_R0B && S0 > 3) r[0] += r0b;
     } else {
       readq(0, eb, 0);
     }
@@ -1084,10 +751,10 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
     fc_sfor<0, NC>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       constexpr int t = O::slot(i);
-      if constexpr (t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa[i], bw[wsl(t)][O::step(i)], r0b);
+      if constexpr (FC_R0B && t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa[i], bw[wsl(t)][O::step(i)], r0b);
       else r[t] = cmma(xa[i], bw[wsl(t)][O::step(i)], r[t]);
     });
-    if constexpr (S0 > 3) r[0] += r0b;
+    if constexpr (FC_R0B && S0 > 3) r[0] += r0b;
   }
 #pragma unroll
   for (int pc = 0; pc < NP; ++pc) store_piece(0, pc);

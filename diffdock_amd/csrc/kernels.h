@@ -27,7 +27,6 @@ void launch_gemm_batch(const GemmBatch& b, hipStream_t s);   // independent prob
 // channel w one ITEM of itemw = 4, 8 or 16 consecutive columns holding the (path, i) terms that feed that output
 // channel, so that after the edge GEMM one lane (or 2/4 neighbouring lanes) owns everything an output needs.
 struct ObInfo { int base, itemw, mul, o_off, dout; };       // columns [base, base + mul*itemw)
-struct QuadDesc { int path[4]; int comp[4]; };             // per (ob, quad in item): path = -1 -> padding column
 struct DevPath {    // coupling descriptor of one tensor-product path
   int n_off, mul_out, din, ds, dout, s_off, c_off, o_off;
   int mul_in, i_off, w_off;   // used by the per-edge-weight form (k_tp_apply)
@@ -41,33 +40,7 @@ struct NcUnit {     // one (output block, 16-wide w tile) unit of the node contr
   NcSlot slot[16];  // slot[s].din == 0 -> padding column (written as 0)
 };
 
-// Y[node][st][k][64] (st = 64-column super-tile) = sum_u x[node][x_off + u*din + i] * W2pack[k][path][u][w]
-void launch_node_contract(const float* X, int gbase, int gcount, const float* wpack, const NcUnit* units, int n_units,
-                          int KS, int HK, int HKp, int NTs, float* Y, hipStream_t s);
-
-struct EdgeConvArgs {
-  int gcount;            // gather nodes
-  int esplit;            // workgroups per gather node (its 32-edge passes are dealt round-robin)
-  const int* goff;       // [gcount+1]
-  const int* tgt;        // [E] global target node id
-  const int* tslot;      // [E] row of msg
-  const int* arow;       // [E] attr row or nullptr (identity)
-  int tbase;             // first target node id (row 0 of P)
-  const float* HE;       // [rows][H]   W1e * edge_attr (+ per-graph term)
-  const float* P;        // [tcount][H] W1s * x_target[:ns]
-  const float* Q;        // [gcount][H] W1d * x_gather[:ns] + b1
-  const float* Y;        // [gcount][n_super][HKp][64]
-  const float* nvec;     // [rows][3] unit edge vectors (by arow)
-  const float* ew;       // [rows] edge weights or nullptr
-  float sgn;             // +1 / -1 : direction of nvec for this group
-  int H, HKp, NTs, sh_lmax, D_out, GN, n_ob, maxd;
-  const ObInfo* obs; const QuadDesc* qdesc; const DevPath* paths; const float* ctab; const GEntry* gmap;
-  float* msg;            // [E][XS]
-  int dbg = 0;           // profiling ablation mask (env DDMI_ABLATE)
-};
-void launch_edge_conv(const EdgeConvArgs& a, hipStream_t s);
-
-// ---- fused form: the contracted rows never leave the CU.
+// ---- the contracted rows never leave the CU (k_conv_fused).
 // A VIRTUAL NODE = one gather node with up to 32 of its edges (nodes with more edges appear several times, nodes
 // without edges not at all).  A workgroup owns 16 virtual nodes and walks GRANULES of fused columns: per 8-row k chunk it
 // contracts the 16 x rows with the packed second-layer weights into LDS (v_mfma_f32_16x16x4_f32, M = nodes) and

@@ -42,14 +42,14 @@ struct ConvW {  // one TensorProductConvLayer
   bool faster = false, residual = true, has_bn = true, yform = true;
   Irreps in_irr, sh_irr, out_irr;
   TPTable table;
-  int n_edge = 0, H = 0, HK = 0, HKp = 0, D_in = 0, D_out = 0, NT = 0, NTs = 0, sh_dim = 0, Wn = 0;
+  int n_edge = 0, H = 0, HK = 0, D_in = 0, D_out = 0, NT = 0, sh_dim = 0, Wn = 0;
   std::vector<float*> W1, b1, W2, b2, wpack;
   std::vector<float*> W1p, b1p;   // first layer with the hidden units of every block of 16 in the order k_edge_hidden_mm emits them
-  NcUnit* nc_units = nullptr; int n_nc = 0, KS = 0;          // node-contraction work list, k-slab size of wpack
+  int KS = 0;                                                // k-slab size of wpack
   FGran* fgran = nullptr; int n_fgran = 0, HKq = 0; bool fgran_generic = false;          // fused form: granule list, padded hidden-row length
   float* cgt = nullptr; int max_nb = 4;                      // dense coupling rows per granule; widest granule in column blocks
   std::vector<int> fgran_unit;                               // unit id of every granule (split points of the grid)
-  ObInfo* obs = nullptr; int n_ob = 0; QuadDesc* qdesc = nullptr; GEntry* gmap = nullptr; int GN = 0, maxd = 1;
+  int maxd = 1;
   DevPath* paths = nullptr; float* ctab = nullptr; CgItem* items = nullptr; int n_items = 0;
   float *bn_mean = nullptr, *bn_scale = nullptr, *bn_bias = nullptr;
 };
@@ -92,9 +92,6 @@ struct Model {
   hipStream_t side_stream = nullptr;   // ligand-gather edge groups run here, concurrently with the receptor-gather ones
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cross = nullptr;
   bool two_streams = true;
-  bool fused = true;        // receptor-gather edge groups use k_conv_fused (DDMI_FUSED=0: contracted rows through HBM)
-  int fused_lig = 3;        // ligand-gather groups (DDMI_FUSED_LIG): 3 = k_conv_fused like every other group, 0 = unfused
-                            // (k_node_contract + k_edge_conv)
   int fused_shared = 1;     // 1: rec<-lig group contracts the distinct gather nodes of a tile on the 4x4x1 MFMA; 0: per virtual node; 2: every dense group (tests)
   bool fused_pack = true;   // packed granules for output blocks of <= 10 channels (DDMI_FUSED_PACK=0: classic granules only)
   bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden

@@ -58,7 +58,7 @@ static void init_conv_meta(const ddmi_config& c, ConvW& L, const std::string& na
   L.table = faster ? faster_table(in, out) : fctp_table(in, sh, out);
   std::stable_sort(L.table.paths.begin(), L.table.paths.end(),
                    [](const TPPath& a, const TPPath& b) { return a.out_block < b.out_block; });
-  L.n_edge = n_edge; L.H = n_edge; L.HK = L.H + 1; L.HKp = (int)round_up(L.HK, 4);
+  L.n_edge = n_edge; L.H = n_edge; L.HK = L.H + 1; 
   L.D_in = irreps_dim(in); L.D_out = irreps_dim(out); L.sh_dim = irreps_dim(sh); L.Wn = L.table.weight_numel;
   // item-major column layout: per output block, per w, one item of (power-of-two quads) x 4 columns
   int nt = 0;
@@ -70,7 +70,7 @@ static void init_conv_meta(const ddmi_config& c, ConvW& L, const std::string& na
     if (quads > 4 && yform) throw Error(DDMI_ERR_ARG, "tensor product with more than 16 terms per output channel");
     nt = (int)round_up(nt, quads * 4) + out[ob].mul * quads * 4;
   }
-  L.NT = nt; L.NTs = (int)round_up(nt, 64);
+  L.NT = nt;
 }
 
 void build_weight_spec(Model& m) {
@@ -277,7 +277,6 @@ static void commit_conv(Model& m, ConvW& L) {
   }
   std::vector<CgItem> items;
   std::vector<ObInfo> obs;
-  std::vector<QuadDesc> qdesc;
   std::vector<int> slot_base(L.table.paths.size(), 0);   // column of (path, i=0) inside its item
   int col = 0;
   for (int ob = 0; ob < (int)L.out_irr.size(); ++ob) {
@@ -290,16 +289,6 @@ static void commit_conv(Model& m, ConvW& L) {
     while (quads * 4 < wi) quads *= 2;
     col = (int)round_up(col, quads * 4);
     obs.push_back({col, quads * 4, L.out_irr[ob].mul, L.out_irr[ob].off, L.out_irr[ob].d()});
-    for (int q = 0; q < 4 && L.yform; ++q) {
-      QuadDesc qd;
-      for (int c = 0; c < 4; ++c) {
-        const int slot = q * 4 + c;
-        qd.path[c] = -1; qd.comp[c] = 0;
-        for (int i = pb; i < pe; ++i)
-          if (slot >= slot_base[i] && slot < slot_base[i] + L.table.paths[i].din) { qd.path[c] = i; qd.comp[c] = slot - slot_base[i]; }
-      }
-      qdesc.push_back(qd);
-    }
     col += L.out_irr[ob].mul * quads * 4;
   }
   if (L.yform && col != L.NT) throw Error(DDMI_ERR_ARG, "internal: column layout mismatch");
@@ -307,9 +296,6 @@ static void commit_conv(Model& m, ConvW& L) {
   L.ctab = m.wpool.upload(ctab);
   L.items = m.wpool.upload(items);
   L.n_items = (int)items.size();
-  L.obs = m.wpool.upload(obs); L.n_ob = (int)obs.size();
-  L.qdesc = m.wpool.upload(qdesc);
-  L.gmap = m.wpool.upload(gmap); L.GN = (int)gmap.size();
   // dense layers --------------------------------------------------------------------
   // packed second layer for the node contraction: [k][path][16-w tile][lane 64][step], k = H is the bias row
   std::vector<int> wk_off(L.table.paths.size(), 0);
@@ -368,8 +354,7 @@ static void commit_conv(Model& m, ConvW& L) {
   }
   if (L.yform) {
     // work list of the node contraction: (output block, 16-wide w tile) units, heaviest first so the 4 waves balance
-    std::vector<NcUnit> nc;
-    std::vector<long> cost;
+    int n_units = 0;   // (output block, 16-wide w tile) units so far
     std::vector<FGran> fg;
     L.fgran_unit.clear();
     for (int ob = 0; ob < (int)obs.size(); ++ob) {
@@ -379,7 +364,6 @@ static void commit_conv(Model& m, ConvW& L) {
         U.col_base = O.base; U.itemw = O.itemw; U.w0 = w0; U.n_w = std::min(16, O.mul - w0);
         int slot_g[16];
         for (int i = 0; i < 16; ++i) slot_g[i] = -1;
-        long c = 0;
         for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
           const TPPath& p = L.table.paths[pi];
           if (p.out_block != ob) continue;
@@ -387,7 +371,6 @@ static void commit_conv(Model& m, ConvW& L) {
             U.slot[slot_base[pi] + i] = {p.i_off, p.din, i, p.mul_in, (int)round_up(p.mul_in, 4),
                                          (int)round_up(p.mul_out, 16), wk_off[pi]};
             slot_g[slot_base[pi] + i] = dp[pi].g_off + i * p.dout;
-            c += round_up(p.mul_in, 4) / 4;
           }
         }
         // fused form, packed granule: an output block of <= 10 channels fed by one 12-step chain (a scalar path) and / or
@@ -419,7 +402,7 @@ static void commit_conv(Model& m, ConvW& L) {
             for (int t = ns_; t < FC_MAXSLOT; ++t) G.g[t] = -1;
             G.nslot = ns_; G.nb = (ns_ + 1) / 2 + 1;
             fg.push_back(G);
-            L.fgran_unit.push_back((int)nc.size());
+            L.fgran_unit.push_back(n_units);
             packed = true;
           }
         }
@@ -462,10 +445,9 @@ static void commit_conv(Model& m, ConvW& L) {
             if (G.shape == 2 && same(0, 1) && same(0, 2)) G.dup = same(0, 3) ? 3 : 2;
           }
           fg.push_back(G);
-          L.fgran_unit.push_back((int)nc.size());
+          L.fgran_unit.push_back(n_units);
         }
-        nc.push_back(U);
-        cost.push_back(c);
+        ++n_units;
       }
     }
     L.fgran_generic = false;
@@ -496,25 +478,6 @@ static void commit_conv(Model& m, ConvW& L) {
       L.cgt = m.wpool.upload(cgt);
     }
     L.HKq = (int)round_up(L.H, 8);   // hidden width padded to the 8-k groups of the fused kernel
-    std::vector<int> order(nc.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-    // snake assignment: position j of the sorted list goes to wave (j % 8 < 4 ? j % 4 : 3 - j % 4); the kernel walks
-    // its units with stride 4, so store them in that interleaved order
-    std::vector<std::vector<NcUnit>> per_wave(4);
-    for (size_t j = 0; j < order.size(); ++j) per_wave[(j % 8 < 4) ? (j % 4) : (3 - j % 4)].push_back(nc[order[j]]);
-    std::vector<NcUnit> flat;
-    size_t rounds = 0;
-    for (auto& v : per_wave) rounds = std::max(rounds, v.size());
-    for (size_t r = 0; r < rounds; ++r)
-      for (int w = 0; w < 4; ++w) {
-        NcUnit U{};
-        U.n_w = 0;   // empty filler keeps the stride-4 walk aligned
-        if (r < per_wave[w].size()) U = per_wave[w][r];
-        flat.push_back(U);
-      }
-    L.nc_units = m.wpool.upload(flat);
-    L.n_nc = (int)flat.size();
   }
   // batch norm (e3nn.nn.BatchNorm eval, eps 1e-5): per-column mean / scale / bias ---------
   if (L.has_bn) {

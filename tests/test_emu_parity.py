@@ -214,8 +214,8 @@ def test_crop_with_embedding_layers_matches_oracle(emu_lib):
 def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
     """DDL-synth channel widths (ns=48, nv=10) on a small complex: the statically-shaped main loop of k_conv_fused
     (chain shapes (12,3,3,3)/(3,3,3,3)/(12,-,-,-) and the packed 12|3x3 granule of the second layer), the generic variant at
-    sh_lmax=2, receptor residues with more than 32 ligand neighbours (two virtual nodes per residue), against the oracle and
-    the unfused kernels."""
+    sh_lmax=2, receptor residues with more than 32 ligand neighbours (two virtual nodes per residue), against the oracle, with
+    the dense-row and the sparse-row loop."""
     from dataclasses import replace
     from diffdock_amd.config import DDL_SYNTH
     from diffdock_amd.synth import make_complex, make_pose_list
@@ -230,17 +230,14 @@ def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
     so3_t, tor_t = tables()
     ref = CGModelOracle(cfg, sd, so3_t, tor_t)(b)[:3]
     outs = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("DDMI_FUSED", fused)
-        monkeypatch.setenv("DDMI_FUSED_LIG", "3" if lmax == 1 else "0")   # lmax 2: the ligand-gather groups through the unfused pair
+    for dense in ("1", "0"):          # dense-row and sparse-row loops (lmax 2: the generic, compiler-scheduled variant both times)
+        monkeypatch.setenv("DDMI_FUSED_DENSE", dense)
         m = make_model(cfg, sd, emu_lib)
         m.set_kernel_timing(True)
-        outs[fused] = m(b)[:3]
-        launched = m.kernel_timings()
-        assert ("k_conv_fused" in launched) == (fused == "1")
-        if fused == "1":
-            assert int(m.debug_buffer("vn_off_cross")[-1]) == 2 * b["receptor"].pos.shape[0]   # 40 neighbours -> 2 virtual nodes
-        for o, r in zip(outs[fused], ref):
+        outs[dense] = m(b)[:3]
+        assert "k_conv_fused" in m.kernel_timings()
+        assert int(m.debug_buffer("vn_off_cross")[-1]) == 2 * b["receptor"].pos.shape[0]   # 40 neighbours -> 2 virtual nodes
+        for o, r in zip(outs[dense], ref):
             assert rel_err(o, r) < 1e-4
     for a_, b_ in zip(outs["1"], outs["0"]):
         assert rel_err(a_, b_) < 1e-5
@@ -324,7 +321,7 @@ def test_ligand_atoms_with_many_receptor_neighbours(emu_lib):
     m.set_kernel_timing(True)
     out = m(b)[:3]
     launched = m.kernel_timings()
-    assert "k_conv_fused" in launched and "k_edge_conv" not in launched
+    assert "k_conv_fused" in launched
     assert int(m.debug_buffer("vn_off_rl")[-1]) == 3 * b["ligand"].pos.shape[0]     # ceil(70 / 32) virtual nodes per ligand atom
     assert int(m.debug_buffer("vn_off_cross")[-1]) == b["receptor"].pos.shape[0]    # 5 ligand neighbours: one sparse tile each
     for o, r in zip(out, ref):
@@ -352,38 +349,34 @@ def test_confidence_mode_matches_reference_fixture(name, emu_lib):
 @pytest.mark.parametrize("name", ["tiny_oldconf", "tiny_oldconf_2l"])
 def test_legacy_confidence_class_matches_reference_fixture(name, emu_lib, monkeypatch):
     """models/old_cg_model.py in confidence mode (get_model(old=True)): OldAtomEncoder, four separately normalised layers per
-    interaction layer, the swapped [edge, gather, target] input of the lig->rec layer; fused and unfused kernels."""
+    interaction layer, the swapped [edge, gather, target] input of the lig->rec layer."""
     fx, cfg, data_list = fixture_case(name)
     batch = HeteroBatch.from_data_list(data_list)
     set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
-    for fused in ("1", "0"):
-        monkeypatch.setenv("DDMI_FUSED", fused)
-        m = MIScoreModel(cfg, device="cpu", lib_path=emu_lib)
-        m.load_state_dict(fx["state_dict"])
-        conf = m(batch)
-        assert torch.is_tensor(conf) and conf.shape == fx["forward"]["confidence"].shape
-        assert rel_err(conf, fx["forward"]["confidence"]) < 1e-4
+    m = MIScoreModel(cfg, device="cpu", lib_path=emu_lib)
+    m.load_state_dict(fx["state_dict"])
+    conf = m(batch)
+    assert torch.is_tensor(conf) and conf.shape == fx["forward"]["confidence"].shape
+    assert rel_err(conf, fx["forward"]["confidence"]) < 1e-4
 
 
 def test_legacy_class_score_mode_matches_reference_fixture(emu_lib, monkeypatch):
     """models/old_cg_model.py in score mode (get_model(old=True, confidence_mode=False)): 3-tuple scores and the device loop
-    against the reference-executed fixture; fused and unfused kernels."""
+    against the reference-executed fixture."""
     fx, cfg, data_list = fixture_case("tiny_oldscore")
     s = fx["sampling"]
     B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
-    for fused in ("1", "0"):
-        monkeypatch.setenv("DDMI_FUSED", fused)
-        m = make_model(cfg, fx["state_dict"], emu_lib)
-        batch = HeteroBatch.from_data_list(data_list)
-        set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
-        out = m(batch)
-        assert len(out) == 3
-        for mine, key in zip(out, ("tr", "rot", "tor")):
-            assert mine.shape == fx["forward"][key].shape and rel_err(mine, fx["forward"][key]) < 1e-4, key
-        sched = get_t_schedule(s["steps"])
-        pos = m.sample_batch(HeteroBatch.from_data_list(data_list), s["steps"], (sched, sched, sched),
-                             noise=split_draws(s["draws"], s["steps"], B, R), no_final_step_noise=True, **s["temp"])
-        assert (pos.reshape(B, -1, 3) - s["final_pos"]).abs().max() < 2e-3
+    m = make_model(cfg, fx["state_dict"], emu_lib)
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    out = m(batch)
+    assert len(out) == 3
+    for mine, key in zip(out, ("tr", "rot", "tor")):
+        assert mine.shape == fx["forward"][key].shape and rel_err(mine, fx["forward"][key]) < 1e-4, key
+    sched = get_t_schedule(s["steps"])
+    pos = m.sample_batch(HeteroBatch.from_data_list(data_list), s["steps"], (sched, sched, sched),
+                         noise=split_draws(s["draws"], s["steps"], B, R), no_final_step_noise=True, **s["temp"])
+    assert (pos.reshape(B, -1, 3) - s["final_pos"]).abs().max() < 2e-3
 
 
 def test_sampling_calls_confidence_model(emu_lib):

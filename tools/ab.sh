@@ -19,8 +19,8 @@ try:
     r = d.get("roofline") or {}
     s = (r.get("serialised") or {})
     print(f"{v:60s} poses/s={d['value']:7.1f} fwd={p.get('forward_total',0):6.2f} fused={p.get('k_conv_fused',0):6.2f} "
-          f"hidden={p.get('k_edge_hidden',0):5.2f} gemms={p.get('conv_fc1_gemms',0):5.2f} reduce={p.get('k_reduce_bn',0):5.2f} nc={p.get('k_node_contract',0):5.2f} "
-          f"ec={p.get('k_edge_conv',0):5.2f} frac={r.get('frac',0):.3f} ser={s.get('frac',0) or 0:.3f}"
+          f"hidden={p.get('k_edge_hidden',0):5.2f} gemms={p.get('conv_fc1_gemms',0):5.2f} reduce={p.get('k_reduce_bn',0):5.2f} "
+          f"frac={r.get('frac',0):.3f} ser={s.get('frac',0) or 0:.3f}"
           + "".join(f" {k[13:]}={x:.2f}" for k, x in sorted(p.items()) if k.startswith("k_conv_fused:")))
 except Exception as e:
     print(f"{v:60s} FAILED {e} {line[:200]}")
