@@ -344,6 +344,11 @@ void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {
 
 constexpr int FC_VN = 16, FC_KC = 8, FC_WAVES = 8, FC_CAP0 = 12, FC_CAPN = 4;
 static_assert(FC_VN == 16, "k_vn_rows pads the per-edge rows to whole 16-node tiles");
+#ifdef FCV_NOBAR   // timing-only: main loops without the per-chunk barrier (garbage results)
+#define FC_STEP_BARRIER() ((void)0)
+#else
+#define FC_STEP_BARRIER() __syncthreads()
+#endif
 constexpr int FC_GWORDS = sizeof(FGran) / 4;   // granule descriptor, in 32-bit words
 constexpr int FC_MAXG = 24;                    // granule descriptors kept in LDS per workgroup (launches split larger ranges)
 // chunk buffer in LDS: [16 nodes][8 rows][16 * NBK columns] (NBK = column blocks of the widest granule of the launch: 4, or 5
@@ -775,26 +780,26 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   FC_STAMP(pf, 2);
   // first pair (hidden rows of pair 0 came with the prologue), pairs with a successor pair, last pair
   step(T{}, T{}, F{}, Even{}, F{});
-  __syncthreads();
+  FC_STEP_BARRIER();
   step(T{}, T{}, T{}, Odd{}, F{});
-  __syncthreads();
+  FC_STEP_BARRIER();
   for (int g = 2; g + 2 < NG8; g += 2) {
     step(T{}, T{}, F{}, Even{}, T{});
     FC_STAMP_FINE(pf, 3);
-    __syncthreads();
+    FC_STEP_BARRIER();
     FC_STAMP_FINE(pf, 11);
     step(T{}, T{}, T{}, Odd{}, F{});
     FC_STAMP_FINE(pf, 3);
-    __syncthreads();
+    FC_STEP_BARRIER();
     FC_STAMP_FINE(pf, 11);
   }
   step(T{}, F{}, F{}, Even{}, T{});        // last pair: one contraction left, nothing to request
   FC_STAMP_FINE(pf, 3);
-  __syncthreads();
+  FC_STEP_BARRIER();
   FC_STAMP_FINE(pf, 11);
   step(F{}, F{}, F{}, Odd{}, F{});
   FC_STAMP_FINE(pf, 3);
-  __syncthreads();
+  FC_STEP_BARRIER();
   FC_STAMP(pf, 3 + 8 * (DDMI_PROF_FINE));
 }
 
@@ -1058,19 +1063,19 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
     }
   FC_STAMP(pf, 2);
   step(T{}, T{}, F{}, Even{}, F{});
-  __syncthreads();
+  FC_STEP_BARRIER();
   step(T{}, T{}, T{}, Odd{}, F{});
-  __syncthreads();
+  FC_STEP_BARRIER();
   for (int g = 2; g + 2 < NG8; g += 2) {
     step(T{}, T{}, F{}, Even{}, T{});
-    __syncthreads();
+    FC_STEP_BARRIER();
     step(T{}, T{}, T{}, Odd{}, F{});
-    __syncthreads();
+    FC_STEP_BARRIER();
   }
   step(T{}, F{}, F{}, Even{}, T{});
-  __syncthreads();
+  FC_STEP_BARRIER();
   step(F{}, F{}, F{}, Odd{}, F{});
-  __syncthreads();
+  FC_STEP_BARRIER();
   FC_STAMP(pf, 3);
 }
 
@@ -1389,7 +1394,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
             }
           } else {
 #pragma unroll
-            for (int k = 0; k < MAXD; ++k) gw[row * GS2 + 4 * k + part] = gval(part, k);   // the four slots of (row, k') side by side
+            for (int k = 0; k < MAXD; ++k)
+              if (k < Gd.dout) gw[row * GS2 + 4 * k + part] = gval(part, k);   // the four slots of (row, k') side by side (scalar blocks: k' = 0 only)
           }
         }
         DDMI_WAVE_SYNC();

@@ -52,7 +52,7 @@ def test_committed_traffic_record_is_what_bench_reads():
     b = load_bench()
     rec = json.load(open(b.TRAFFIC_RECORD))
     assert rec["kernel"] == "k_conv_fused" and rec["config"] == "configs2"
-    assert rec["bytes_per_launch"] == (2.0 * rec["fetch_size_kb_per_launch_raw"] + rec["write_size_kb_per_launch"]) * 1024.0
+    assert rec["bytes_per_launch"] == (2.0 * rec["fetch_size_kb_per_launch"] + rec["write_size_kb_per_launch"]) * 1024.0
     assert 1e8 < rec["bytes_per_launch"] < 1e10 and rec["source"].startswith("profiles/")
 
 
