@@ -111,6 +111,11 @@ def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr):
     return out
 
 
+def copy_poses(dl):
+    import copy
+    return copy.deepcopy(dl)
+
+
 def cpu_baseline(cfg, sd, so3_t, tor_t, g, full=False):
     """Bounded CPU sample of the same workload on this host's cores: the first steps of the 20-step schedule (largest cross
     cutoffs = the same all-pairs graph as the GPU run) for a few poses, extrapolated linearly to 20 steps."""
@@ -160,12 +165,21 @@ def cpu_baseline(cfg, sd, so3_t, tor_t, g, full=False):
         gen = torch.Generator().manual_seed(0)
         noise = (torch.randn(INFERENCE_STEPS, n_s, 3, generator=gen), torch.randn(INFERENCE_STEPS, n_s, 3, generator=gen),
                  torch.randn(INFERENCE_STEPS, n_s * R, generator=gen))
-        t0 = time.time()
-        oracle_sampling(dl, model, n_steps, cfg, noise, schedules=(s, s, s), batch_size=n_s, **TEMP)
-        dt = time.time() - t0
+        # the per-edge einsums of the restated tensor product stop scaling after a few dozen threads: time the sample at 16 threads
+        # and at every core (<= 64), report the faster one as the baseline and both in `thread_scaling`
+        scaling = {}
+        for th in ([threads] if big or threads <= 16 else [16, threads]):
+            torch.set_num_threads(th)
+            t0 = time.time()
+            oracle_sampling(copy_poses(dl), model, n_steps, cfg, noise, schedules=(s, s, s), batch_size=n_s, **TEMP)
+            scaling[th] = time.time() - t0
+        threads = min(scaling, key=scaling.get)
+        dt = scaling[threads]
+        thread_scaling = {str(th): round(n_s / (t / n_steps * INFERENCE_STEPS), 5) for th, t in scaling.items()}
         kind = "port"
     poses_per_s = n_s / (dt / n_steps * INFERENCE_STEPS)
     return {"value": poses_per_s, "unit": "poses/s", "cores": threads, "kind": kind,
+            **({"thread_scaling_poses_per_s": thread_scaling} if kind == "port" else {}),
             "sample": f"{n_s} poses x the first {n_steps} of {INFERENCE_STEPS} steps of the "
                       f"{g['receptor'].pos.shape[0]}-residue / {g['ligand'].pos.shape[0]}-atom complex, same weights, extrapolated "
                       f"linearly to {INFERENCE_STEPS} steps; torch {torch.__version__}, {threads} threads, {dt:.1f} s wall"}
