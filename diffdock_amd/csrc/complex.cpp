@@ -295,6 +295,9 @@ void run_direct_conv(Model& m, const ConvW& L, const float* attr, int E, float* 
   a.E = E; a.valid_cnt = valid_cnt; a.cap = cap; a.Wt = Wt; a.ldw = L.Wn; a.X = X; a.xrow = xrow; a.sh = sh;
   a.lds_ = L.sh_dim; a.ew = ew; a.paths = L.paths; a.ctab = L.ctab; a.items = L.items; a.n_items = L.n_items;
   a.out = out_rows; a.ldo = L.D_out;
+  a.n_paths = (int)L.table.paths.size();
+  a.z_floats = 0;
+  for (auto& p : L.table.paths) a.z_floats += p.mul_in * p.dout;
   launch_tp_apply(a, s);
 }
 

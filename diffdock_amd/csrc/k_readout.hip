@@ -5,6 +5,9 @@
 // tor_bond_conv, tor_final_layer, utils/torus.py:79-83).  These graphs have B*Nl and
 // ~B*R*10 edges -- three orders of magnitude fewer than the interaction layers -- so they use
 // the direct form: per-edge weights from the GEMM, then a table-driven tensor product.
+#include <cstring>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ddmi {
@@ -172,10 +175,68 @@ __global__ __launch_bounds__(256) void k_tp_apply_wave(TpApplyArgs a) {
     for (int k = 0; k < item.dout; ++k) a.out[(size_t)e * a.ldo + item.o_off + item.w * item.dout + k] = w * m[k];
   }
 }
+// Same arithmetic with one WORKGROUP per edge, in two stages: z[path][u][k] = sum_{i,j} C[i][j][k] * x[u,i] * sh[j] once per edge
+// (it does not depend on the output channel w), then a thread per item sums Wt[e][w_off + u*mul_out + w] * z over its paths.
+// The thread-per-item form recomputes z for every one of the 96 output channels of the torsion read-out: ~200 dependent
+// requests per thread, 148 us for 19 200 edges at 40 poses (address-unit bound); this form issues the weight reads only.
+constexpr int TPE_THREADS = 128, TPE_MAXPATHS = 32;
+__global__ __launch_bounds__(TPE_THREADS) void k_tp_apply_edge(TpApplyArgs a) {
+  DDMI_DYN_SMEM(float, z);                       // [sum_paths mul_in * dout]
+  __shared__ int zoff[TPE_MAXPATHS + 1];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const bool live = !a.valid_cnt || (e % a.cap) < a.valid_cnt[e / a.cap];
+  if (tid <= a.n_paths) {
+    int off = 0;
+    for (int q = 0; q < tid; ++q) off += a.paths[q].mul_in * a.paths[q].dout;
+    zoff[tid] = off;
+  }
+  __syncthreads();
+  if (live) {
+    const float* __restrict__ x = a.X + (size_t)a.xrow[e] * XS;
+    const float* __restrict__ sh = a.sh + (size_t)e * a.lds_;
+    for (int p = 0; p < a.n_paths; ++p) {
+      const DevPath P = a.paths[p];
+      const float* __restrict__ C = a.ctab + P.c_off;
+      for (int t = tid; t < P.mul_in * P.dout; t += TPE_THREADS) {
+        const int u = t / P.dout, k = t - u * P.dout;
+        float v = 0.f;
+        for (int i = 0; i < P.din; ++i) {
+          const float xv = x[P.i_off + u * P.din + i];
+          for (int j = 0; j < P.ds; ++j) v = fmaf(C[(i * P.ds + j) * P.dout + k], xv * sh[P.s_off + j], v);
+        }
+        z[zoff[p] + t] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const float w_e = (live && a.ew) ? a.ew[e] : 1.f;
+  const float* __restrict__ wt = a.Wt + (size_t)e * a.ldw;
+  for (int it = tid; it < a.n_items; it += TPE_THREADS) {
+    const CgItem item = a.items[it];
+    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      for (int p = item.path_begin; p < item.path_end; ++p) {
+        const DevPath P = a.paths[p];
+        const float* __restrict__ zp = z + zoff[p];
+        for (int u = 0; u < P.mul_in; ++u) {
+          const float w = wt[P.w_off + u * P.mul_out + item.w];
+          for (int k = 0; k < P.dout; ++k) m[k] = fmaf(w, zp[u * P.dout + k], m[k]);
+        }
+      }
+    }
+    for (int k = 0; k < item.dout; ++k) a.out[(size_t)e * a.ldo + item.o_off + item.w * item.dout + k] = w_e * m[k];
+  }
+}
 void launch_tp_apply(const TpApplyArgs& a, hipStream_t s) {
   if (a.E <= 0 || a.n_items <= 0) return;
   const long pairs = (long)a.E * a.n_items;
-  if (pairs <= 32768) hipLaunchKernelGGL(k_tp_apply_wave, dim3(cdiv(pairs, 4)), dim3(256), 0, s, a);
+  const char* force = getenv("DDMI_TP_APPLY");   // tests: "edge" / "thread" / "wave" instead of the size rule (two launches per forward)
+  const bool edge_ok = a.n_paths <= TPE_MAXPATHS && a.z_floats > 0 && a.z_floats <= 8192;
+  const int form = force && !strcmp(force, "wave") ? 0 : force && !strcmp(force, "thread") ? 2 : force && !strcmp(force, "edge") && edge_ok ? 1
+                   : pairs <= 32768 ? 0 : edge_ok ? 1 : 2;
+  if (form == 0) hipLaunchKernelGGL(k_tp_apply_wave, dim3(cdiv(pairs, 4)), dim3(256), 0, s, a);
+  else if (form == 1)
+    hipLaunchKernelGGL(k_tp_apply_edge, dim3(a.E), dim3(TPE_THREADS), (size_t)a.z_floats * sizeof(float), s, a);
   else hipLaunchKernelGGL(k_tp_apply, dim3(cdiv(pairs, 128)), dim3(128), 0, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }

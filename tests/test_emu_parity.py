@@ -302,6 +302,21 @@ def test_shared_node_contraction_matches_oracle(emu_lib, monkeypatch):
             assert rel_err(a_, b_) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2"])
+def test_readout_tensor_product_forms_agree(name, emu_lib, monkeypatch):
+    """final_conv / tor_bond_conv in the direct (per-edge-weight) form: the wave-per-item, thread-per-item and
+    workgroup-per-edge kernels (k_readout.hip; picked by launch size in production, forced here) against the reference fixture."""
+    fx, cfg, data_list = fixture_case(name)
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
+    ref = fx["forward"]
+    for form in ("edge", "thread", "wave"):
+        monkeypatch.setenv("DDMI_TP_APPLY", form)
+        m = make_model(cfg, fx["state_dict"], emu_lib)
+        tr, rot, tor, _ = m(batch)
+        assert_scores_close((tr, rot, tor), (ref["tr"], ref["rot"], ref["tor"]), what=form)
+
+
 def test_ligand_atoms_with_many_receptor_neighbours(emu_lib):
     """Ligand-gather groups through the fused kernel with several virtual nodes per ligand atom (70 receptor neighbours ->
     32 + 32 + 6 edges: the node term is repeated per virtual node, the last one is a sparse tile) at a width the MFMA first
