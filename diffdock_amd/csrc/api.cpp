@@ -32,6 +32,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     if (const char* e = getenv("DDMI_FUSED_PACK")) h->m.fused_pack = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_SHARED")) h->m.fused_shared = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;
+    if (const char* e = getenv("DDMI_FC1_BATCH")) h->m.fc1_batch = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_DENSE")) h->m.fused_dense = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_YS")) h->m.fused_ysplit = std::max(0, atoi(e));
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));

@@ -40,6 +40,7 @@ struct Model::Cx {
   float *pdist, *pnvec, *pew, *cross_ea;
   float *HE, *P, *Q; float* msg[4];
   float *HE_b, *P_b, *Q_b, *rowbias_b;   // second scratch set: ligand-gather groups on the side stream
+  float *Pg[9] = {}, *Qg[9] = {}, *rbg[9] = {};   // per-group first-layer terms when a layer's GEMMs go out in one launch (run_conv)
   // fused form (k_conv_fused): virtual-node lists of the two receptor-gather topologies (0 = lig<-rec cross, 1 = rec-rec),
   // rebuilt when the edge list they were built for changes (once per forward), and the hidden-row scratch
   struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr, *ne = nullptr;
@@ -154,6 +155,39 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     for (auto& g : groups) any_main = any_main || !(g.gbase == 0 && g.gcount == c.nL);
     forked = forked && any_main;
   }
+  // tiles of 16 virtual nodes per group ~ gather nodes x ceil(mean degree / 32) / 16; a SMALL layer = no group fills the chip once
+  auto tiles_of = [](const RunGroup& q) {
+    const long gn = std::max(1, q.gcount);
+    return std::max(1L, gn * (((long)q.ea_rows / gn + 31) / 32) / 16);
+  };
+  long biggest = 1;
+  for (auto& q : groups) biggest = std::max(biggest, tiles_of(q));
+  const bool small_layer = biggest < 256;
+  // The per-graph and per-node terms of the first Linear of EVERY group (P = W1s x_target, Q = W1d x_gather + b1, sigma rows)
+  // depend on the layer input only.  Small layers: one batched launch in front of the fork instead of one small launch at the
+  // head of every group's chain (5 poses: 101.4 -> 102.9 poses/s).  Large layers keep them per group: there the other stream
+  // fills the gap, and a common launch in front of the fork delays the side stream (40 poses: -0.5 %; profiles/r03_e42_ab.txt).
+  bool mm_all = m.fc1_batch && small_layer && m.fused_mm && ns % 16 == 0 && ns <= 64 && groups.size() <= 9 && c.Pg[0];
+  for (size_t gi = 0; gi < groups.size(); ++gi) mm_all = mm_all && L.W1p[std::min<int>((int)gi, L.G - 1)];
+  if (mm_all) {
+    PhaseTimer t(m, "conv_fc1_gemms", s);
+    GemmBatch gb;
+    auto add = [&](const float* A, int lda, const float* W, const float* bias, float* C, int M) {
+      if (gb.n == GEMM_BATCH_MAX) { launch_gemm_batch(gb, s); gb.n = 0; }
+      GemmArgs& x = gb.g[gb.n++];
+      x = GemmArgs{};
+      x.A = A; x.lda = lda; x.W = W; x.ldw = L.n_edge; x.bias = bias; x.C = C; x.ldc = H; x.M = M; x.N = H; x.K = ns;
+    };
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      const RunGroup& g = groups[gi];
+      const int wg = std::min<int>((int)gi, L.G - 1);
+      const float* W1p = L.W1p[wg];
+      if (g.sig) add(g.sig, ns, W1p, nullptr, c.rbg[gi], c.B);
+      add(Xin + (size_t)g.tbase * XS, XS, W1p + (g.swap_pq ? 2 : 1) * ns, nullptr, c.Pg[gi], g.tcount);
+      add(Xin + (size_t)g.gbase * XS, XS, W1p + (g.swap_pq ? 1 : 2) * ns, L.b1p[wg], c.Qg[gi], g.gcount);
+    }
+    launch_gemm_batch(gb, s);
+  }
   if (forked) {
     DDMI_CHECK_HIP(hipEventRecord(m.ev_fork, s));
     DDMI_CHECK_HIP(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0));
@@ -164,6 +198,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     hipStream_t gs = side ? m.side_stream : s;
     float *HE = side ? c.HE_b : c.HE, *P = side ? c.P_b : c.P, *Q = side ? c.Q_b : c.Q;
     float* rowbias = side ? c.rowbias_b : c.rr_rowbias;
+    if (mm_all) { P = c.Pg[gi]; Q = c.Qg[gi]; rowbias = c.rbg[gi]; }
     const int wg = std::min<int>((int)gi, L.G - 1);
     const float* W1 = L.W1[wg];
     const float* rb = nullptr;
@@ -173,7 +208,9 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     DDMI_REQUIRE(g.vn >= 0 && L.n_fgran > 0 && c.Hb, DDMI_ERR_STATE, "convolution layer without a granule list / virtual-node set");
     float* Hb = side ? c.Hb_b : c.Hb;
     const bool fuse_mm = m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
-    if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
+    if (mm_all) {
+      if (g.sig) rb = rowbias;
+    } else if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
       PhaseTimer t(m, "conv_fc1_gemms", gs);
       const float* W1p = L.W1p[wg];
       GemmBatch gb;   // the group's per-graph and per-node terms of the first Linear: independent, one launch
@@ -236,16 +273,10 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         // one granule per workgroup, 5 poses 94 -> 100 poses/s.  Otherwise the round-2 rule (at most 6 ranges, tiles estimated
         // from nodes + edges / 32): the small lig-lig launch that runs next to the big groups is sensitive to its split -- 4
         // ranges at 40 poses; 5-6 cost the headline 2.5 % (profiles/r03_e27..e37_ab.txt).
-        auto tiles_of = [](const RunGroup& q) {
-          const long gn = std::max(1, q.gcount);
-          return std::max(1L, gn * (((long)q.ea_rows / gn + 31) / 32) / 16);
-        };
-        long biggest = 1;
-        for (auto& q : groups) biggest = std::max(biggest, tiles_of(q));
-        if (biggest < 256) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
+        if (small_layer) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
         else ys_req = (int)std::min(6L, std::max(1L, 768 / std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16)));
         static const int ys_small = getenv("DDMI_FUSED_YS_SMALL") ? atoi(getenv("DDMI_FUSED_YS_SMALL")) : 0;   // tuning: split of a small group next to big ones
-        if (ys_small > 0 && biggest >= 256 && tiles_of(g) < 256) ys_req = ys_small;
+        if (ys_small > 0 && !small_layer && tiles_of(g) < 256) ys_req = ys_small;
       }
       ys_req = std::max(ys_req, (L.n_fgran + 19) / 20);   // a workgroup keeps at most 24 granule descriptors in LDS
       const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
@@ -539,6 +570,9 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.HE = dalloc<float>(m, nullptr, {max_rows, H}); c.P = dalloc<float>(m, nullptr, {N, H}); c.Q = dalloc<float>(m, nullptr, {N, H});
   c.HE_b = dalloc<float>(m, nullptr, {std::max(std::max(c.Ell_cap, c.Elr_cap), c.Ela_cap), H}); c.P_b = dalloc<float>(m, nullptr, {N, H});
   c.Q_b = dalloc<float>(m, nullptr, {N, H}); c.rowbias_b = dalloc<float>(m, nullptr, {B, H});
+  for (int i = 0; i < (cfg.all_atoms ? 9 : 4); ++i) {
+    c.Pg[i] = dalloc<float>(m, nullptr, {N, H}); c.Qg[i] = dalloc<float>(m, nullptr, {N, H}); c.rbg[i] = dalloc<float>(m, nullptr, {B, H});
+  }
   std::vector<const ConvW*> all_layers;
   for (auto* fam : {&m.conv_layers, &m.lig_emb_layers, &m.rec_emb_layers, &m.old_lig, &m.old_rec, &m.old_l2r, &m.old_r2l})
     for (auto& L : *fam) all_layers.push_back(&L);

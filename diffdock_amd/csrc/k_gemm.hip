@@ -66,7 +66,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, int bx, int by) {
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a) { gemm_tile<VEC>(a, blockIdx.x, blockIdx.y); }
-// up to 8 independent small GEMMs in one launch (blockIdx.z = problem): the per-node terms of one edge group's first layer
+// up to GEMM_BATCH_MAX independent small GEMMs in one launch (blockIdx.z = problem): the per-node terms of one edge group's first layer
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_gemm_nt_batch(GemmBatch b) {
   const GemmArgs& a = b.g[blockIdx.z];

@@ -19,7 +19,8 @@ struct GemmArgs {
   int act = 0;  // 0 none, 1 relu, 2 tanh
 };
 void launch_gemm(const GemmArgs& a, hipStream_t s);
-struct GemmBatch { GemmArgs g[8]; int n = 0; };
+constexpr int GEMM_BATCH_MAX = 16;
+struct GemmBatch { GemmArgs g[GEMM_BATCH_MAX]; int n = 0; };
 void launch_gemm_batch(const GemmBatch& b, hipStream_t s);   // independent problems, one launch
 
 // ---------------------------------------------------------------- k_conv.hip
