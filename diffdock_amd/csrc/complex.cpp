@@ -298,7 +298,8 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       }
       static const bool per_group = getenv("DDMI_TIME_GROUPS") != nullptr;   // profiling: one timing row per edge group
       if (m.timing && per_group) {
-        const std::string tname = "k_conv_fused:g" + std::to_string(gi);
+        static const bool per_layer = atoi(getenv("DDMI_TIME_GROUPS")) >= 2;   // 2: one row per (layer, edge group)
+        const std::string tname = "k_conv_fused:" + (per_layer ? "L" + L.name.substr(L.name.size() - 1) : std::string()) + "g" + std::to_string(gi);
         PhaseTimer t(m, tname.c_str(), gs);
         launch_conv_fused(f, gs);
       } else {

@@ -550,12 +550,17 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   const bool two[2] = {DENSE || vne[0] > 16, DENSE || vne[1] > 16};
   using O = FcOrder<S0, SN, NLV>;
   constexpr int NC = O::NC;
-  float xa[NC];
+  // SAMEX (SN == 12, merged granule): slots 1.. are further channel tiles of slot 0's path -- one set of x fragments
+  constexpr bool SAMEX = SN == 12;
+  constexpr int NXA = SAMEX ? S0 : NC;
+  auto xi = [](int i) constexpr { return SAMEX ? O::step(i) : i; };
+  float xa_[NXA];
   float bw[4][S0 > 3 ? S0 : 3];   // weight fragments [slot][step] (slot 0: S0 steps, slots 1..3: SN steps)
   fc_sfor<0, NC>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    xa[i] = sl[O::slot(i)].xp[O::step(i) * sl[O::slot(i)].xstride];
+    if constexpr (!SAMEX || O::slot(i) == 0) xa_[xi(i)] = sl[O::slot(i)].xp[O::step(i) * sl[O::slot(i)].xstride];
   });
+#define xa(i) xa_[xi(i)]
   unsigned woff[4];            // uniform byte offset of row k = 8g + wave of each slot's packed weights
   unsigned lo[4];              // per-lane byte offset of the lane's run of fragments
 #pragma unroll
@@ -567,18 +572,24 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   const FcBuf wbuf = fc_buf(wpack, (unsigned)HK * (unsigned)KS * 4u);
   // vector requests: slot 0 in pieces of 4 steps (or one piece of 3), slots 1..3 one piece of 3 each
   static_assert(DUP != 2 || NLV == 3, "DUP 2 keeps slot 3's own fragments");
-  constexpr int NLN = SN == 0 ? 0 : DUP == 1 ? 1 : DUP == 2 ? 1 : DUP == 3 ? 0 : NLV;   // requests for slots 1..3
+  constexpr int PSN = SN >= 4 ? SN / 4 : 1;                                              // request pieces of a slot 1..3
+  constexpr int NLN = SN == 0 ? 0 : DUP == 1 ? 1 : DUP == 2 ? 1 : DUP == 3 ? 0 : NLV * PSN;   // requests for slots 1..3
   constexpr int NL0 = S0 >= 4 ? S0 / 4 : (S0 > 0 ? 1 : 0), NL = NL0 + NLN;
+  static_assert(SN != 12 || DUP == 0, "merged granules have their own weights per slot");
   // slot whose fragments slot t multiplies with
   auto wsl = [](int t) constexpr { return DUP == 1 ? (t == 0 ? 0 : 1) : DUP == 2 ? (t == 3 ? 3 : 0) : DUP == 3 ? 0 : t; };
   static_assert(S0 % 4 == 0 || S0 == 3, "slot-0 chains are whole 4-step pieces or one 3-step piece");
-  static_assert(SN == 0 || SN == 3, "slots 1..3 hold 3-step chains");
+  static_assert(SN == 0 || SN == 3 || SN == 12, "slots 1..3 hold 3-step chains (or 12-step chains of slot 0's path)");
   auto loadw = [&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    constexpr int t = i < NL0 ? 0 : (DUP == 2 ? 3 : 1 + (i - NL0));   // DUP 2: the one extra request is slot 3's
+    constexpr int t = i < NL0 ? 0 : (DUP == 2 ? 3 : 1 + (i - NL0) / PSN);   // DUP 2: the one extra request is slot 3's
     if constexpr (t == 0 && S0 >= 4) {
       const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0]);   // piece i of the chain: one contiguous KB per wave
       bw[0][4 * i] = v.x; bw[0][4 * i + 1] = v.y; bw[0][4 * i + 2] = v.z; bw[0][4 * i + 3] = v.w;
+    } else if constexpr (SN >= 4) {
+      constexpr int pc = (i - NL0) % PSN;
+      const float4 v = fc_buf_ld4(wbuf, lo[t] + 1024u * pc, woff[t]);
+      bw[t][4 * pc] = v.x; bw[t][4 * pc + 1] = v.y; bw[t][4 * pc + 2] = v.z; bw[t][4 * pc + 3] = v.w;
     } else {
       const float3 v = fc_buf_ld3(wbuf, lo[t], woff[t]);
       bw[t][0] = v.x; bw[t][1] = v.y; bw[t][2] = v.z;
@@ -653,8 +664,8 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       fc_sfor<0, NC>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int t = O::slot(i);
-        if constexpr (FC_R0B && t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa[i], bw[wsl(t)][O::step(i)], r0b);
-        else r[t] = cmma(xa[i], bw[wsl(t)][O::step(i)], r[t]);
+        if constexpr (FC_R0B && t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa(i), bw[wsl(t)][O::step(i)], r0b);
+        else r[t] = cmma(xa(i), bw[wsl(t)][O::step(i)], r[t]);
         if (i == NC - 3) readq(0, eb, 0);
         DDMI_SCHED_FENCE();
       });
@@ -714,10 +725,10 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   fc_sfor<0, NSLOT>([&](auto tc) {
     constexpr int t = decltype(tc)::value, ws = wsl(t);
     if (wave == t) {
-      if constexpr (ws == 0 && S0 >= 4) {
+      if constexpr ((ws == 0 && S0 >= 4) || (ws > 0 && SN >= 4)) {
 #pragma unroll
-        for (int i = 0; i < S0 / 4; ++i) {
-          const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0] + hrow);
+        for (int i = 0; i < (ws == 0 ? S0 : SN) / 4; ++i) {
+          const float4 v = fc_buf_ld4(wbuf, lo[ws] + 1024u * i, woff[ws] + hrow);
           bb[4 * i] = v.x; bb[4 * i + 1] = v.y; bb[4 * i + 2] = v.z; bb[4 * i + 3] = v.w;
         }
       } else {
@@ -737,8 +748,8 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
         constexpr int i = decltype(ic)::value;
         if constexpr (O::slot(i) == t) {
           constexpr int j = O::step(i);
-          if constexpr (LEN > 3 && (j & 1)) bq = cmma(xa[i], bb[j], bq);
-          else ba = cmma(xa[i], bb[j], ba);
+          if constexpr (LEN > 3 && (j & 1)) bq = cmma(xa(i), bb[j], bq);
+          else ba = cmma(xa(i), bb[j], ba);
         }
       });
       if constexpr (SH) {
@@ -756,8 +767,8 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
     fc_sfor<0, NC>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       constexpr int t = O::slot(i);
-      if constexpr (FC_R0B && t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa[i], bw[wsl(t)][O::step(i)], r0b);
-      else r[t] = cmma(xa[i], bw[wsl(t)][O::step(i)], r[t]);
+      if constexpr (FC_R0B && t == 0 && S0 > 3 && (O::step(i) & 1)) r0b = cmma(xa(i), bw[wsl(t)][O::step(i)], r0b);
+      else r[t] = cmma(xa(i), bw[wsl(t)][O::step(i)], r[t]);
     });
     if constexpr (FC_R0B && S0 > 3) r[0] += r0b;
   }
@@ -802,6 +813,8 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   FC_STEP_BARRIER();
   FC_STAMP(pf, 3 + 8 * (DDMI_PROF_FINE));
 }
+
+#undef xa
 
 // ---- packed granules (kernels.h, FGran): slots = [a 12-step chain (S0 = 12) or none (S0 = 0)] + NG groups of three 3-step
 // chains, the three sharing one set of weight fragments (components of one vector path).  Column of (slot s, channel w):
@@ -1203,7 +1216,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     const int gi = gorder[go - g_begin];
     const FGran& Gd = gran_l[gi];
     if (DDMI_ABL(a.dbg, 4096) && Gd.accumulate) continue;   // timing-only: the second granule of a wide unit dropped
-    const bool packed = PACK && Gd.shape >= 4;
+    const bool packed = PACK && Gd.shape >= 4 && Gd.shape <= 6;
     const int NB = packed ? Gd.nb : 4;                       // live column blocks of this granule
     f32x4 acc[2][2][NBK];
 #pragma unroll
@@ -1223,10 +1236,10 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         else if (Gd.shape == 6) FC_MLP(12, 1);
 #undef FC_MLP
       } else {
-      const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
-      const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
-      const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
-      const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
+      const FcSlotRt s0 = fc_slot_setup(Gd.slot[0], a.wpack, xbuf, Gd.shape == 7 ? 0 : Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
+      const FcSlotRt s1 = fc_slot_setup(Gd.slot[1], a.wpack, xbuf, Gd.shape == 7 ? 16 : Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
+      const FcSlotRt s2 = fc_slot_setup(Gd.slot[2], a.wpack, xbuf, Gd.shape == 7 ? 32 : Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
+      const FcSlotRt s3 = fc_slot_setup(Gd.slot[3], a.wpack, xbuf, Gd.shape == 7 ? 48 : Gd.w0, lr, lq, sh_tile ? (lr & 3) : xr);
       if (MODE == 0 || MODE == 3 || MODE == 4) {   // static chain shapes: hand-scheduled loop, dense (3, 4) or sparse (0) rows
         constexpr bool DN = MODE == 3 || MODE == 4;
         const FcSlotRt sl[4] = {s0, s1, s2, s3};
@@ -1238,7 +1251,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   } while (0)
         int dup, nlv;
         fc_variant(Gd, dup, nlv);
-        if (Gd.shape == 1 && dup == 1 && nlv == 3) FC_ML(12, 3, 1, 3);
+        if (Gd.shape == 7) FC_ML(12, 12, 0, 2);                // three channel tiles of one 12-step path
+        else if (Gd.shape == 1 && dup == 1 && nlv == 3) FC_ML(12, 3, 1, 3);
         else if (Gd.shape == 1 && dup == 1) FC_ML(12, 3, 1, 2);
         else if (Gd.shape == 1) FC_ML(12, 3, 0, 3);          // (a padding slot is contracted like a live one: its result is never read)
         else if (Gd.shape == 2 && dup == 3 && nlv == 2) FC_ML(3, 3, 3, 2);
@@ -1358,7 +1372,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     const float* __restrict__ cg = cgt + (gi - g_begin) * CGN;
     float* stg = ybuf + wave * ((2 * FC_YB) / FC_WAVES);   // the chunk buffers are idle during the coupling phase: [16][RS] message rows
     float* tT = stg + 16 * 16 * MAXD;                      // packed: [16 rows][2 channels][8 slots] accumulators of the tail block
-    const int RS = 16 * Gd.dout, L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
+    const bool tri = Gd.shape == 7;                        // merged granule: slot c = output channels 16c .. 16c+15 (dout = 1)
+    const int RS = tri ? 48 : 16 * Gd.dout, L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
     const int V = ((c0 | L) & 3) == 0 ? 4 : ((c0 | L) & 1) == 0 ? 2 : 1;
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi) {
@@ -1457,7 +1472,11 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
             const int row = 4 * lq_e + r;
             const float* __restrict__ G = gw + row * GS2;
             const float t0 = acc[vi][rt][0][r], t1 = acc[vi][rt][1][r], t2 = acc[vi][rt][2][r], t3 = acc[vi][rt][3][r];
-            if (Gd.dout == 1) {          // scalar output blocks
+            if (tri) {                   // three scalar channel tiles: every slot is its own output
+              const float4 g4 = *reinterpret_cast<const float4*>(G);
+              float* __restrict__ o = stg + row * 48 + lr_e;
+              o[0] = g4.x * t0; o[16] = g4.y * t1; o[32] = g4.z * t2;
+            } else if (Gd.dout == 1) {   // scalar output blocks
               stg[row * 16 + lr_e] = couple(G, 0, t0, t1, t2, t3);
             } else if (Gd.dout == 3) {   // vector output blocks: the three components of (row, w) side by side
               float* __restrict__ o = stg + row * 48 + lr_e * 3;

@@ -61,7 +61,8 @@ struct FGran {
   int g[FC_MAXSLOT];     // slot s couples through gmap[g[s] .. g[s]+dout), -1 = padding
   int accumulate;        // 0: first granule of its (output block, w tile) unit writes, later ones add
   int empty;             // no path reaches this granule: the message columns are zero
-  int shape;             // chain-length class: classic 1 = (12,3,3,3), 2 = (3,3,3,3), 3 = (12,-,-,-), 0 = generic;
+  int shape;             // chain-length class: classic 1 = (12,3,3,3), 2 = (3,3,3,3), 3 = (12,-,-,-), 0 = generic; 7 = three 12-step chains of ONE
+                         // path, slot s = channel tile 16*s (n_w = 48: the slots feed different output channels, weights.cpp);
                          // packed 4 = 12 | 3x3 | 3x3 (7 slots), 5 = 3x3 | 3x3 (6 slots), 6 = 12 | 3x3 (4 slots): a 12-step chain, then
                          // groups of three 3-step chains (the components of one path, sharing their weights)
   int nlive;             // classic: live (non-padding) slots among 1..3; padding slots trail after the host's sort

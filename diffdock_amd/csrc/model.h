@@ -93,6 +93,7 @@ struct Model {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cross = nullptr;
   bool two_streams = true;
   int fused_shared = 1;     // 1: rec<-lig group contracts the distinct gather nodes of a tile on the 4x4x1 MFMA; 0: per virtual node; 2: every dense group (tests)
+  bool fused_tri = true;    // the three light granules of a single-chain 48-channel scalar block as one (DDMI_FUSED_TRI=0: separate)
   bool fused_pack = true;   // packed granules for output blocks of <= 10 channels (DDMI_FUSED_PACK=0: classic granules only)
   bool fc1_batch = true;    // per-node / per-graph terms of the first Linear of all groups of a layer in one launch (DDMI_FC1_BATCH=0: per group)
   bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden

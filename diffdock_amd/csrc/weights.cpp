@@ -450,6 +450,30 @@ static void commit_conv(Model& m, ConvW& L) {
         ++n_units;
       }
     }
+    // Merged granule (shape 7): a 48-channel scalar output block fed by ONE 12-step chain (the first interaction layer: 0e x 0e ->
+    // 0e) gives three light granules -- 12 contraction + 8 edge MFMAs per chunk step, too short to cover the request latency of
+    // the next chunk.  Their x fragments and hidden rows are the same, so the three 16-channel tiles become the three slots of one
+    // granule (36 + 24 MFMAs per step, one hidden-row pass, one epilogue); the slots feed DIFFERENT output channels (16*slot + w).
+    bool any_generic = false;   // (a generic granule sends the whole layer to the compiler-scheduled kernel variant, which has no merged form)
+    for (auto& G : fg) any_generic = any_generic || (!G.empty && G.shape == 0);
+    if (m.fused_tri && !any_generic && L.maxd <= 3 && m.cfg.sh_lmax <= 1 && L.H % 16 == 0) {
+      for (size_t i = 0; i + 2 < fg.size(); ++i) {
+        auto light = [&](const FGran& G, int w0) {
+          return G.shape == 3 && !G.empty && !G.accumulate && G.dout == 1 && G.n_w == 16 && G.w0 == w0 && G.nslot == 4 &&
+                 G.o_off == fg[i].o_off && G.slot[0].wk_off == fg[i].slot[0].wk_off && G.slot[0].x_off == fg[i].slot[0].x_off &&
+                 G.slot[0].u_pad == 48 && G.g[0] == fg[i].g[0];
+        };
+        if (!(light(fg[i], 0) && light(fg[i + 1], 16) && light(fg[i + 2], 32))) continue;
+        FGran G = fg[i];
+        G.shape = 7; G.n_w = 48; G.nslot = 3; G.nb = 3; G.nlive = 2; G.dup = 0;
+        G.slot[1] = G.slot[2] = G.slot[0];
+        G.g[1] = G.g[2] = G.g[0];
+        G.slot[3] = NcSlot{}; G.g[3] = -1;
+        fg[i] = G;
+        fg.erase(fg.begin() + i + 1, fg.begin() + i + 3);
+        L.fgran_unit.erase(L.fgran_unit.begin() + i + 1, L.fgran_unit.begin() + i + 3);
+      }
+    }
     L.fgran_generic = false;
     for (auto& G : fg) if (!G.empty && G.shape == 0) L.fgran_generic = true;
     if (L.H % 16 != 0) L.fgran_generic = true;   // the static loops walk whole pairs of 8-k groups

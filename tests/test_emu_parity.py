@@ -267,6 +267,7 @@ def test_packed_granules_match_oracle_and_classic_granules(emu_lib, monkeypatch,
         listing = capfd.readouterr().err
         assert ("shape 4 slots 7 nb 5" in listing) == (pack == "1") and ("shape 5 slots 6 nb 4" in listing) == (pack == "1")
         assert ("shape 6 slots 4 nb 3" in listing) == (pack == "1") and (" acc]" in listing) == (pack == "0")
+        assert "conv_layers.0: [shape 7 slots 3 nb 3 w 48] [shape 3" in listing   # first layer: the three scalar tiles as one granule
         outs[pack] = m(b)[:3]
         for o, r in zip(outs[pack], ref):
             assert rel_err(o, r) < 1e-4

@@ -113,7 +113,7 @@ def width48_case():
 
 @pytest.mark.parametrize("env", [{"DDMI_FUSED_PACK": "0"}, {"DDMI_FUSED_DENSE": "0"},
                                  {"DDMI_FUSED_DENSE": "2"}, {"DDMI_FUSED_MM": "0"}, {"DDMI_STREAMS": "1"}, {"DDMI_FUSED_YS": "3"},
-                                 {"DDMI_FUSED_SHARED": "0"}, {"DDMI_FUSED_SHARED": "2", "DDMI_FUSED_DENSE": "2"}, {"DDMI_FC1_BATCH": "0"}],
+                                 {"DDMI_FUSED_SHARED": "0"}, {"DDMI_FUSED_SHARED": "2", "DDMI_FUSED_DENSE": "2"}, {"DDMI_FC1_BATCH": "0"}, {"DDMI_FUSED_TRI": "0"}],
                          ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
 def test_selectable_kernel_paths_agree_on_the_gpu(env, width48_case, monkeypatch):
     """Every selectable route of an edge group (classic instead of packed granules for the 10-channel vector blocks,
