@@ -238,6 +238,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         PhaseTimer t(m, "vn_build", gs);
         VnRowsArgs vr{};
         vr.arow = g.arow; vr.nvec = g.nvec; vr.ew = g.ew; vr.tslot = g.tslot; vr.sgn = g.sgn; vr.sh_lmax = m.cfg.sh_lmax;
+        vr.tgt = g.tgt; vr.tbase = g.tbase;
         vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
         launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs);
         vs.built_goff = g.goff; vs.epoch = c.epoch;
@@ -252,6 +253,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = L.W1p[wg]; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
         h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb;
         h.zero_fill = (!L.fgran_generic && dense_rows) ? 1 : 0;
+        if (m.cfg.sh_lmax <= 1) { h.vrows = vs.rows; h.vn_ne = vs.ne; }
         launch_edge_hidden_mm(h, gs);
       } else {
         PhaseTimer t(m, "k_edge_hidden", gs);

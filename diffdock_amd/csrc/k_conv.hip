@@ -155,13 +155,18 @@ __global__ __launch_bounds__(256) void k_vn_rows(VnRowsArgs a) {
   if (v < nvn) { e0 = a.vn_e0[v]; ne = min(32, a.goff[a.vn_node[v] + 1] - e0); }
   float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float we = 0.f;
-  int ts = 0;
+  int ts = 0, ar = 0, tg = 0;
   if (r < ne) {
     const int e = e0 + r;
-    const int ar = a.arow ? a.arow[e] : e;
+    ar = a.arow ? a.arow[e] : e;
     edge_sh(a.nvec + (size_t)ar * 3, a.sgn, a.sh_lmax, sh);
     we = a.ew ? a.ew[ar] : 1.f;
     ts = a.tslot[e];
+    tg = a.tgt[e] - a.tbase;
+  } else if (ne > 0) {   // rows past the node's last edge: the tile's first edge (valid memory for k_edge_hidden_mm, which stores zeros there)
+    const int e = e0 + ((r & 16) < ne ? (r & 16) : 0);
+    ar = a.arow ? a.arow[e] : e;
+    tg = a.tgt[e] - a.tbase;
   }
   float* er = a.rows + ((size_t)v * 32 + r) * ES;
 #pragma unroll
@@ -170,6 +175,10 @@ __global__ __launch_bounds__(256) void k_vn_rows(VnRowsArgs a) {
   reinterpret_cast<int*>(er)[SHD + 1] = ts;
 #pragma unroll
   for (int j = SHD + 2; j < ES; ++j) er[j] = 0.f;
+  if (ES >= SHD + 4) {   // (l <= 1 rows: attribute row and target row of the edge for the first-layer kernel)
+    reinterpret_cast<int*>(er)[SHD + 2] = ar;
+    reinterpret_cast<int*>(er)[SHD + 3] = tg;
+  }
   if (r == 0) a.vn_ne[v] = ne;
 }
 void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, const VnRowsArgs& rows_in,
@@ -256,15 +265,27 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
   // a.W1 is the permuted copy of the first layer (weights.cpp): output position 4a + i of a 16-block holds hidden unit
   // 8 (i >> 1) + 2a + (i & 1), so lane (row, quarter a) ends with k = 8g + 2a + {0, 1} of BOTH 8-k groups g = 2nb, 2nb + 1 --
   // the float4 of fragment lane 16a + row; P, Q and the sigma rows arrive in the same order.
-  for (int idx = tid; idx < H * 4 * KS; idx += 256) {   // k fastest: coalesced reads of the weight rows
-    const int k = idx % (4 * KS), n = idx / (4 * KS);
-    const int q = k / KS, t = k - q * KS;
-    wl[(t * 4 + q) * HP + n] = a.W1[(size_t)n * a.ldw + k];
+  {   // k fastest: coalesced reads of the weight rows; every request of the thread is issued before the first LDS store (the
+      // rolled loop was a chain of 27 request -> store round trips per workgroup: ~a quarter of the kernel)
+    constexpr int NW = (H * 4 * KS + 255) / 256;
+    float wreg[NW];
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int idx = tid + 256 * it;
+      wreg[it] = idx < H * 4 * KS ? a.W1[(size_t)(idx / (4 * KS)) * a.ldw + idx % (4 * KS)] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int idx = tid + 256 * it;
+      const int k = idx % (4 * KS), n = idx / (4 * KS);
+      const int q = k / KS, t = k - q * KS;
+      if (idx < H * 4 * KS) wl[(t * 4 + q) * HP + n] = wreg[it];
+    }
   }
   __syncthreads();
   for (int v = blockIdx.x * 4 + wave; v < nvn; v += gridDim.x * 4) {
     const int d = a.vn_node[v], e0 = a.vn_e0[v];
-    const int ne = min(32, a.goff[d + 1] - e0);
+    const int ne = a.vn_ne ? a.vn_ne[v] : min(32, a.goff[d + 1] - e0);
     // All requests of a (virtual node, row tile) are issued before the first use and nothing in the tile body branches:
     // a load -> wait -> MFMA -> store chain per 16 hidden units made this kernel latency-bound (0.24 of the HBM write
     // roofline in round 1).  Rows past the node's edge count read the tile's first edge (valid memory) and store zeros.
@@ -293,10 +314,17 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
       }
       const int el = 16 * rt + lr;
       const bool live = el < ne;
-      const int e = e0 + (live ? el : 16 * rt);
-      const int ar = a.arow ? a.arow[e] : e;
+      int ar, tg;
+      if (a.vrows) {   // attribute row / target row of the lane's edge row, prepared by k_vn_rows: one dependent request less
+        const int2 at = *reinterpret_cast<const int2*>(a.vrows + ((size_t)v * 32 + el) * 8 + 6);
+        ar = at.x; tg = at.y;
+      } else {
+        const int e = e0 + (live ? el : 16 * rt);
+        ar = a.arow ? a.arow[e] : e;
+        tg = a.tgt[e] - a.tbase;
+      }
       const float* __restrict__ ep = a.ea + (size_t)ar * a.ns + KS * lq;
-      const float* __restrict__ prow = a.P + (size_t)(a.tgt[e] - a.tbase) * H + 4 * lq;
+      const float* __restrict__ prow = a.P + (size_t)tg * H + 4 * lq;
       float4 ae[NSQ], pv[NB];
 #pragma unroll
       for (int j = 0; j < NSQ; ++j) ae[j] = *reinterpret_cast<const float4*>(ep + 4 * j);

@@ -75,6 +75,7 @@ struct FGran {
 struct VnRowsArgs {
   const int* nvn; const int* vn_node; const int* vn_e0; const int* goff;   // filled by launch_vn_build
   const int* arow; const float* nvec; const float* ew; const int* tslot; float sgn; int sh_lmax;
+  const int* tgt; int tbase;           // target node of every edge (first node id of the target range)
   int vcap; float* rows; int* vn_ne;   // rows == nullptr: lists only
 };
 void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, const VnRowsArgs& rows,
@@ -96,6 +97,7 @@ struct EdgeHiddenArgs {
   const float* rowbias; const int* ridx;   // optional per-graph term [B][H], graph of attr row
   int H, NG8;
   int zero_fill;   // write zero fragments for empty row tiles (the dense-row loop multiplies them; the other loops skip them)
+  const float* vrows; const int* vn_ne;   // l <= 1: per-edge rows of k_vn_rows (words 6, 7 = attribute row, target row) and edge counts; nullptr = index chain
   float* Hb;
 };
 void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s);
