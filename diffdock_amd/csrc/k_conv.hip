@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
         }
       }
     }
-#pragma unroll 1
+#pragma unroll 1   // (unrolled, the second row tile's requests do not move ahead of the first one's MFMAs anyway and the kernel loses 9 %: r03_e51)
     for (int rt = 0; rt < 2; ++rt) {
       float* __restrict__ hp = a.Hb + fc_hb_off(v, rt, 0, lane, NG8 / 2);   // + 256 per pair of 8-k groups
       if (16 * rt >= ne) {   // empty row tile (wave-uniform): zero fragments where the consumer multiplies them
