@@ -60,7 +60,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     __builtin_amdgcn_wave_barrier();                                                         \
   } while (0)
 // nothing is scheduled across this point (hand-placed issue order of the MFMA main loops)
+#ifdef FCV_NOFENCE   // timing experiment: the compiler's own order instead of the hand-placed one
+#define DDMI_SCHED_FENCE() ((void)0)
+#else
 #define DDMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // every outstanding vector-memory request of the wave has completed (vmcnt(0); expcnt / lgkmcnt untouched) -- a real
 // S_WAITCNT, which the compiler's own wait-count insertion takes into account
 #define DDMI_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
