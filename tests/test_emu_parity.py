@@ -241,6 +241,11 @@ def test_fused_conv_full_width_matches_oracle(lmax, emu_lib, monkeypatch):
             assert rel_err(o, r) < 1e-4
     for a_, b_ in zip(outs["1"], outs["0"]):
         assert rel_err(a_, b_) < 1e-5
+    if lmax == 1:   # the merged first-layer granule (three scalar channel tiles in one) against the separate granules
+        monkeypatch.setenv("DDMI_FUSED_TRI", "0")
+        sep = make_model(cfg, sd, emu_lib)(b)[:3]
+        for a_, b_ in zip(outs["0"], sep):
+            assert rel_err(a_, b_) < 1e-5
 
 
 def test_packed_granules_match_oracle_and_classic_granules(emu_lib, monkeypatch, capfd):
