@@ -34,6 +34,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     if (const char* e = getenv("DDMI_FUSED_SHARED")) h->m.fused_shared = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FC1_BATCH")) h->m.fc1_batch = atoi(e) != 0;
+    if (const char* e = getenv("DDMI_TP_APPLY")) h->m.tp_form = !strcmp(e, "wave") ? 0 : !strcmp(e, "edge") ? 1 : !strcmp(e, "thread") ? 2 : -1;
     if (const char* e = getenv("DDMI_FUSED_DENSE")) h->m.fused_dense = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_YS")) h->m.fused_ysplit = std::max(0, atoi(e));
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));

@@ -330,6 +330,7 @@ void run_direct_conv(Model& m, const ConvW& L, const float* attr, int E, float* 
   a.lds_ = L.sh_dim; a.ew = ew; a.paths = L.paths; a.ctab = L.ctab; a.items = L.items; a.n_items = L.n_items;
   a.out = out_rows; a.ldo = L.D_out;
   a.n_paths = (int)L.table.paths.size();
+  a.form = m.tp_form;
   a.z_floats = 0;
   for (auto& p : L.table.paths) a.z_floats += p.mul_in * p.dout;
   launch_tp_apply(a, s);

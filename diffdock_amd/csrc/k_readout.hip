@@ -5,9 +5,6 @@
 // tor_bond_conv, tor_final_layer, utils/torus.py:79-83).  These graphs have B*Nl and
 // ~B*R*10 edges -- three orders of magnitude fewer than the interaction layers -- so they use
 // the direct form: per-edge weights from the GEMM, then a table-driven tensor product.
-#include <cstring>
-#include <cstdlib>
-
 #include "kernels.h"
 
 namespace ddmi {
@@ -230,10 +227,9 @@ __global__ __launch_bounds__(TPE_THREADS) void k_tp_apply_edge(TpApplyArgs a) {
 void launch_tp_apply(const TpApplyArgs& a, hipStream_t s) {
   if (a.E <= 0 || a.n_items <= 0) return;
   const long pairs = (long)a.E * a.n_items;
-  const char* force = getenv("DDMI_TP_APPLY");   // tests: "edge" / "thread" / "wave" instead of the size rule (two launches per forward)
   const bool edge_ok = a.n_paths <= TPE_MAXPATHS && a.z_floats > 0 && a.z_floats <= 8192;
-  const int form = force && !strcmp(force, "wave") ? 0 : force && !strcmp(force, "thread") ? 2 : force && !strcmp(force, "edge") && edge_ok ? 1
-                   : pairs <= 32768 ? 0 : edge_ok ? 1 : 2;
+  // a.form (tests, DDMI_TP_APPLY at ddmi_create): 0 wave / 1 edge / 2 thread instead of the size rule
+  const int form = a.form == 0 || a.form == 2 ? a.form : a.form == 1 && edge_ok ? 1 : pairs <= 32768 ? 0 : edge_ok ? 1 : 2;
   if (form == 0) hipLaunchKernelGGL(k_tp_apply_wave, dim3(cdiv(pairs, 4)), dim3(256), 0, s, a);
   else if (form == 1)
     hipLaunchKernelGGL(k_tp_apply_edge, dim3(a.E), dim3(TPE_THREADS), (size_t)a.z_floats * sizeof(float), s, a);

@@ -204,6 +204,7 @@ struct TpApplyArgs {
   const float* ew;                        // optional per-edge weight
   const DevPath* paths; const float* ctab; const CgItem* items; int n_items;
   int n_paths, z_floats;                  // paths of the layer; sum over them of mul_in * dout (the per-edge scratch of k_tp_apply_edge)
+  int form = -1;                          // -1: by launch size; 0 wave per (edge, item), 1 workgroup per edge, 2 thread per (edge, item)
   float* out; int ldo;                    // [E][out_dim]
 };
 void launch_tp_apply(const TpApplyArgs& a, hipStream_t s);

@@ -95,6 +95,7 @@ struct Model {
   int fused_shared = 1;     // 1: rec<-lig group contracts the distinct gather nodes of a tile on the 4x4x1 MFMA; 0: per virtual node; 2: every dense group (tests)
   bool fused_tri = true;    // the three light granules of a single-chain 48-channel scalar block as one (DDMI_FUSED_TRI=0: separate)
   bool fused_pack = true;   // packed granules for output blocks of <= 10 channels (DDMI_FUSED_PACK=0: classic granules only)
+  int tp_form = -1;         // read-out tensor product: -1 by launch size; DDMI_TP_APPLY=wave|edge|thread forces one form (tests)
   bool fc1_batch = true;    // per-node / per-graph terms of the first Linear of all groups of a layer in one launch (DDMI_FC1_BATCH=0: per group)
   bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden
   int fused_dense = 1;      // branch-free dense-row main loop: 0 never, 1 groups with >= 20 edges per gather node, 2 always
