@@ -1567,6 +1567,8 @@ void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
   if (a_in.vcap <= 0 || a_in.ysplit <= 0) return;
   FusedConvArgs a = a_in;
   a.dbg = ablate_mask();
+  // the predicated variant (MODE 1) walks classic 4-slot granules only: a packed / merged granule there would be mis-read
+  if (a.generic && a.max_nb > 4) throw Error(DDMI_ERR_ARG, "k_conv_fused: packed granule in a generic layer (weights.cpp builds those layers unpacked)");
   if (a.maxd <= 3 && a.sh_lmax <= 1) {   // the l <= 1 tensor product (FasterTensorProduct structure): static chain shapes, packed granules
     if (a.generic) launch_conv_fused_k<3, 4, 1, 4>(a, s);
     else if (a.max_nb > 4) {

@@ -356,6 +356,14 @@ static void commit_conv(Model& m, ConvW& L) {
     // work list of the node contraction: (output block, 16-wide w tile) units, heaviest first so the 4 waves balance
     int n_units = 0;   // (output block, 16-wide w tile) units so far
     std::vector<FGran> fg;
+    // Packed granules exist only in the static-shape kernel variants: a layer with ANY generic granule (chain shapes outside the
+    // static set, H % 16 != 0) runs the predicated variant, which walks classic 4-slot granules only.  So the list is built with
+    // packing first and, when a generic granule turns up next to a packed one, once more without.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool allow_pack = m.fused_pack && attempt == 0;
+    bool any_packed = false;
+    n_units = 0;
+    fg.clear();
     L.fgran_unit.clear();
     for (int ob = 0; ob < (int)obs.size(); ++ob) {
       const ObInfo& O = obs[ob];
@@ -377,7 +385,7 @@ static void commit_conv(Model& m, ConvW& L) {
         // groups of three 3-step chains (the components of a vector path): every slot of the block in ONE granule
         // (kernels.h, FGran).  Anything else: classic granules, one per quad of item columns.
         bool packed = false;
-        if (m.fused_pack && L.maxd <= 3 && m.cfg.sh_lmax <= 1 && L.H % 16 == 0 && O.mul > 8 && O.mul <= 10 && O.dout == 3) {
+        if (allow_pack && L.maxd <= 3 && m.cfg.sh_lmax <= 1 && L.H % 16 == 0 && O.mul > 8 && O.mul <= 10 && O.dout == 3) {
           auto chain = [&](int t) { return U.slot[t].din == 0 ? 0 : U.slot[t].u_pad / 4; };
           int c12 = -1, groups[2] = {-1, -1}, ng = 0;
           bool ok = true;
@@ -403,7 +411,7 @@ static void commit_conv(Model& m, ConvW& L) {
             G.nslot = ns_; G.nb = (ns_ + 1) / 2 + 1;
             fg.push_back(G);
             L.fgran_unit.push_back(n_units);
-            packed = true;
+            packed = any_packed = true;
           }
         }
         for (int q = 0; q < O.itemw / 4 && !packed; ++q) {
@@ -450,6 +458,10 @@ static void commit_conv(Model& m, ConvW& L) {
         ++n_units;
       }
     }
+    bool generic_now = L.H % 16 != 0;
+    for (auto& G : fg) generic_now = generic_now || (!G.empty && G.shape == 0);
+    if (!(generic_now && any_packed)) break;
+    }
     // Merged granule (shape 7): a 48-channel scalar output block fed by ONE 12-step chain (the first interaction layer: 0e x 0e ->
     // 0e) gives three light granules -- 12 contraction + 8 edge MFMAs per chunk step, too short to cover the request latency of
     // the next chunk.  Their x fragments and hidden rows are the same, so the three 16-channel tiles become the three slots of one
@@ -477,6 +489,9 @@ static void commit_conv(Model& m, ConvW& L) {
     L.fgran_generic = false;
     for (auto& G : fg) if (!G.empty && G.shape == 0) L.fgran_generic = true;
     if (L.H % 16 != 0) L.fgran_generic = true;   // the static loops walk whole pairs of 8-k groups
+    if (L.fgran_generic)
+      for (auto& G : fg)
+        if (G.shape >= 4) throw Error(DDMI_ERR_ARG, "internal: packed / merged granule in a generic layer (" + L.name + ")");
     L.fgran = m.wpool.upload(fg);
     L.n_fgran = (int)fg.size();
     L.max_nb = 4;

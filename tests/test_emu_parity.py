@@ -280,6 +280,38 @@ def test_packed_granules_match_oracle_and_classic_granules(emu_lib, monkeypatch,
         assert rel_err(a_, b_) < 1e-5
 
 
+@pytest.mark.parametrize("ns", [16, 32])
+def test_packing_is_dropped_in_layers_with_generic_granules(ns, emu_lib, monkeypatch, capfd):
+    """ns = 16 / 32 with nv = 10: the 4- / 8-step scalar chains are outside the static shape set, so every layer with a scalar
+    input path runs the predicated kernel variant, which walks classic 4-slot granules only.  Such a layer must not contain a
+    packed granule (round-3 defect: its slots 4..6 were dropped, 1 % error in the 1e block); packing on / off must agree."""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = replace(DDL_SYNTH, ns=ns, nv=10, num_conv_layers=4, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0,
+                  tr_sigma_max=5.0)
+    sd = init_state_dict(cfg, seed=3)
+    g = make_complex(seed=1, n_res=10, n_lig=12, lm_dim=0)
+    b = HeteroBatch.from_data_list(make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.3))
+    set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+    ref = CGModelOracle(cfg, sd, *tables())(b)[:3]
+    outs = {}
+    monkeypatch.setenv("DDMI_DEBUG_GRAN", "1")
+    for pack in ("1", "0"):
+        monkeypatch.setenv("DDMI_FUSED_PACK", pack)
+        capfd.readouterr()
+        m = make_model(cfg, sd, emu_lib)
+        for line in capfd.readouterr().err.splitlines():
+            if line.startswith("ddmi granules") and "[shape 0 " in line:
+                assert not any(f"[shape {s} " in line for s in (4, 5, 6, 7)), line
+        outs[pack] = m(b)[:3]
+        for o, r in zip(outs[pack], ref):
+            assert rel_err(o, r) < 1e-5
+    for a_, b_ in zip(outs["1"], outs["0"]):
+        assert rel_err(a_, b_) < 1e-5
+
+
 def test_shared_node_contraction_matches_oracle(emu_lib, monkeypatch):
     """Shared-node tiles of k_conv_fused (MODE 4: the x tile holds the distinct gather nodes of the 16 virtual nodes, classic
     granules contract them on the 4x4x1 MFMA, packed granules read their rows through the slot map), forced onto EVERY edge
