@@ -167,6 +167,11 @@ def main():
     # the same legacy class in score mode (get_model(old=True, confidence_mode=False)): read-outs old_cg_model.py:293-352
     cases["tiny_oldscore"] = dict(cfg=TINY.replace(old=True, confidence_mode=False, sh_lmax=2, num_conv_layers=3), n_res=26, n_lig=10,
                                   n_samples=3, seed=12, t=0.45)
+    # second-order node features (use_second_order_repr: 2e / 2o blocks, models/tensor_layers.py:17-24), CGModel and AAModel
+    cases["tiny_2nd"] = dict(cfg=TINY.replace(use_second_order_repr=True, sh_lmax=2, num_conv_layers=4), n_res=26, n_lig=10,
+                             n_samples=2, seed=15, t=0.55)
+    cases["tiny_aa_2nd"] = dict(cfg=TINY.replace(all_atoms=True, use_second_order_repr=True, sh_lmax=2, num_conv_layers=3,
+                                                  reduce_pseudoscalars=True), n_res=16, n_lig=9, n_samples=2, seed=17, t=0.45)
     if len(sys.argv) > 1:
         cases = {k: v for k, v in cases.items() if k in sys.argv[1:]}
     for name, c in cases.items():

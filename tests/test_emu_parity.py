@@ -18,7 +18,7 @@ from util import assert_scores_close, fixture_case, graph_from_dict, load_fixtur
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "hipemu", "libddmi_emu.so")
 CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb",   # tiny_aa_*: AAModel
-         "tiny_noaa"]
+         "tiny_noaa", "tiny_2nd", "tiny_aa_2nd"]   # tiny_*2nd: use_second_order_repr (2e / 2o node blocks)
 
 
 @pytest.fixture(scope="session")
@@ -59,7 +59,7 @@ def test_forward_matches_reference_fixture(name, emu_lib):
         assert int(m.debug_buffer("offs_la_l")[-1]) == inter["edge_counts"][2] == int(m.debug_buffer("offs_la_a")[-1]) > 0
 
 
-@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb"])
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb", "tiny_2nd", "tiny_aa_2nd"])
 def test_device_loop_matches_reference_trajectory(name, emu_lib):
     fx, cfg, data_list = fixture_case(name)
     m = make_model(cfg, fx["state_dict"], emu_lib)

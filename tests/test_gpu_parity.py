@@ -19,7 +19,7 @@ from util import assert_scores_close, fixture_case, graph_from_dict, load_fixtur
 pytestmark = pytest.mark.gpu
 REL = 1e-4
 CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb",
-         "tiny_noaa"]
+         "tiny_noaa", "tiny_2nd", "tiny_aa_2nd"]   # tiny_*2nd: use_second_order_repr (2e / 2o node blocks)
 
 
 def gpu_model(cfg, sd):
@@ -51,7 +51,7 @@ def test_forward_matches_reference_fixture(name):
             assert rel_err(mine[:n, :ref_nodes.shape[1]], ref_nodes[:n]) < REL, l
 
 
-@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb"])
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb", "tiny_2nd", "tiny_aa_2nd"])
 def test_device_loop_matches_reference_trajectory(name):
     fx, cfg, data_list = fixture_case(name)
     m = gpu_model(cfg, fx["state_dict"])
