@@ -50,7 +50,8 @@ class ModelConfig:
     scale_by_sigma: bool = True
     fixed_center_conv: bool = False
     lm_embedding_type: str | None = "precomputed"
-    embedding_scale: float = 1000.0     # sinusoidal timestep embedding scale
+    embedding_scale: float = 1000.0     # sinusoidal: multiplies t; fourier: std of the frozen projection W (init only)
+    embedding_type: str = "sinusoidal"  # get_timestep_embedding (utils/diffusion_utils.py:129-136): 'sinusoidal' | 'fourier'
     # noise schedule (args.* in the reference)
     tr_sigma_min: float = 0.1
     tr_sigma_max: float = 19.0
@@ -119,7 +120,7 @@ class ModelConfig:
         d = asdict(self)
         d.update(max_radius=self.lig_max_radius, no_batch_norm=not self.batch_norm,
                  no_differentiate_convolutions=not self.differentiate_convolutions,
-                 embedding_type="sinusoidal", dropout=0.0,
+                 dropout=0.0,
                  esm_embeddings_path="precomputed" if self.lm_embedding_type else None)
         for k in ('fixed_center_conv', 'lm_embedding_type', 'batch_norm', 'differentiate_convolutions',
                   'lig_max_radius', 'rec_max_radius', 'center_max_distance', 'in_lig_edge_features', 'confidence_mode',
@@ -154,8 +155,8 @@ def config_from_args(args) -> ModelConfig:
     # Arguments the reference's get_model acts on (utils/utils.py:174-276) that the built path does not implement: raise
     # instead of silently computing a different function (most of them leave the weight shapes unchanged).
     unsupported = []
-    if has("embedding_type") and args.embedding_type != "sinusoidal":
-        unsupported.append(f"embedding_type={args.embedding_type!r} (only 'sinusoidal', utils/diffusion_utils.py:99-110)")
+    if has("embedding_type") and args.embedding_type not in ("sinusoidal", "fourier"):
+        unsupported.append(f"embedding_type={args.embedding_type!r} (the reference raises too, utils/diffusion_utils.py:135)")
     if get("esm_embeddings_model", None) is not None:
         unsupported.append("esm_embeddings_model (on-the-fly language-model embeddings)")
     if get("parallel", 1) not in (1, None):
@@ -166,18 +167,14 @@ def config_from_args(args) -> ModelConfig:
         unsupported.append("sidechain_pred (sidechain_loss_weight / backbone_loss_weight > 0)")
     if get("include_miscellaneous_atoms", False):
         unsupported.append("include_miscellaneous_atoms")
-    if get("tp_weights_layers", 2) != 2:
-        unsupported.append("tp_weights_layers != 2")
+    if get("tp_weights_layers", 2) < 2:
+        unsupported.append("tp_weights_layers < 2 (FCBlock asserts layers >= 2, models/layers.py:12)")
     if unsupported:
         raise NotImplementedError("get_model arguments outside the built path: " + "; ".join(unsupported))
     # norm_by_sigma is stored by the reference classes and never read in forward (cg_model.py:44): accepted, no effect
-    if get("num_prot_emb_layers", 0) > 0 and not get("embed_also_ligand", False):
-        if get("all_atoms", False):
-            # AAModel runs this (receptor / atom rows through the embedding layers, ligand rows zero-padded to their width,
-            # models/aa_model.py:351-357); the padded-ligand variant is not built here
-            raise NotImplementedError("all_atoms with num_prot_emb_layers > 0 and embed_also_ligand=False (zero-padded ligand rows, "
-                                      "models/aa_model.py:356) is not built; set embed_also_ligand")
-        # CGModel asserts the same on every forward (models/cg_model.py:263 "otherwise reimplement padding")
+    if get("num_prot_emb_layers", 0) > 0 and not get("embed_also_ligand", False) and not get("all_atoms", False):
+        # CGModel asserts this on every forward (models/cg_model.py:263 "otherwise reimplement padding"); AAModel zero-pads the
+        # ligand rows to the width the receptor embedding layers produced (models/aa_model.py:351-357): built
         raise NotImplementedError("num_prot_emb_layers > 0 requires embed_also_ligand (models/cg_model.py:263 asserts it)")
     cut = get("rmsd_classification_cutoff", None)
     acut = get("atom_rmsd_classification_cutoff", None)
@@ -202,6 +199,7 @@ def config_from_args(args) -> ModelConfig:
         fixed_center_conv=(not args.not_fixed_center_conv) if has("not_fixed_center_conv") else False,
         lm_embedding_type=lm,
         embedding_scale=args.embedding_scale if has("embedding_type") else 10000.0,
+        embedding_type=get("embedding_type", "sinusoidal"),
         tr_sigma_min=args.tr_sigma_min, tr_sigma_max=args.tr_sigma_max,
         rot_sigma_min=args.rot_sigma_min, rot_sigma_max=args.rot_sigma_max,
         tor_sigma_min=args.tor_sigma_min, tor_sigma_max=args.tor_sigma_max,

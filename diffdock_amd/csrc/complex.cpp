@@ -63,6 +63,7 @@ struct Model::Cx {
   ReduceGroup *rg_aa_all = nullptr, *rg_aa_lig = nullptr;
   long epoch = 0;
   float *Hb = nullptr, *Hb_b = nullptr;   // hidden rows of the main-stream / side-stream group in flight
+  float *HD[2] = {nullptr, nullptr}, *HD_b[2] = {nullptr, nullptr};   // tp_weights_layers > 2: plain per-edge hidden rows [E][H]
   ReduceGroup *rg_all, *rg_lig, *rg_ll, *rg_rr;
   // read-outs
   float *c_dist, *c_nvec, *c_ea, *c_attr, *c_hid, *c_W, *c_sh, *c_out, *gp;
@@ -167,7 +168,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
   // depend on the layer input only.  Small layers: one batched launch in front of the fork instead of one small launch at the
   // head of every group's chain (5 poses: 101.4 -> 102.9 poses/s).  Large layers keep them per group: there the other stream
   // fills the gap, and a common launch in front of the fork delays the side stream (40 poses: -0.5 %; profiles/r03_e42_ab.txt).
-  bool mm_all = m.fc1_batch && small_layer && m.fused_mm && ns % 16 == 0 && ns <= 64 && groups.size() <= 9 && c.Pg[0];
+  bool mm_all = L.TL == 2 && m.fc1_batch && small_layer && m.fused_mm && ns % 16 == 0 && ns <= 64 && groups.size() <= 9 && c.Pg[0];
   for (size_t gi = 0; gi < groups.size(); ++gi) mm_all = mm_all && L.W1p[std::min<int>((int)gi, L.G - 1)];
   if (mm_all) {
     PhaseTimer t(m, "conv_fc1_gemms", s);
@@ -207,7 +208,8 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     // shared-node tiles, mode 4 of the kernel).
     DDMI_REQUIRE(g.vn >= 0 && L.n_fgran > 0 && c.Hb, DDMI_ERR_STATE, "convolution layer without a granule list / virtual-node set");
     float* Hb = side ? c.Hb_b : c.Hb;
-    const bool fuse_mm = m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
+    const bool deep = L.TL > 2;   // FCBlock with hidden Linear layers: first layer as plain per-edge rows, the hidden ones as GEMMs
+    const bool fuse_mm = !deep && m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
     if (mm_all) {
       if (g.sig) rb = rowbias;
     } else if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
@@ -255,6 +257,17 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         h.zero_fill = (!L.fgran_generic && dense_rows) ? 1 : 0;
         if (m.cfg.sh_lmax <= 1) { h.vrows = vs.rows; h.vn_ne = vs.ne; }
         launch_edge_hidden_mm(h, gs);
+      } else if (deep) {
+        PhaseTimer t(m, "k_edge_hidden", gs);
+        float* cur = side ? c.HD_b[0] : c.HD[0];
+        float* nxt = side ? c.HD_b[1] : c.HD[1];
+        DDMI_REQUIRE(cur && nxt, DDMI_ERR_STATE, "tp_weights_layers > 2: hidden-row scratch missing");
+        launch_edge_rows(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, cur, gs);
+        for (int j = 0; j + 2 < L.TL; ++j) {   // hidden Linear + ReLU layers (models/layers.py:14-15), rows in gather order
+          gemm(cur, H, L.Wmid[wg][j], H, L.bmid[wg][j], nxt, H, g.ea_rows, H, H, 1, gs, g.ea_rows_dev);
+          std::swap(cur, nxt);
+        }
+        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, nullptr, g.tgt, g.tbase, cur, nullptr, nullptr, H, L.HKq / 8, Hb, gs);
       } else {
         PhaseTimer t(m, "k_edge_hidden", gs);
         launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs);
@@ -574,6 +587,12 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   c.HE = dalloc<float>(m, nullptr, {max_rows, H}); c.P = dalloc<float>(m, nullptr, {N, H}); c.Q = dalloc<float>(m, nullptr, {N, H});
   c.HE_b = dalloc<float>(m, nullptr, {std::max(std::max(c.Ell_cap, c.Elr_cap), c.Ela_cap), H}); c.P_b = dalloc<float>(m, nullptr, {N, H});
   c.Q_b = dalloc<float>(m, nullptr, {N, H}); c.rowbias_b = dalloc<float>(m, nullptr, {B, H});
+  if (cfg.tp_weights_layers > 2) {   // per-edge hidden rows of the deeper edge MLP (ping-pong), main and side stream
+    for (int i = 0; i < 2; ++i) {
+      c.HD[i] = dalloc<float>(m, nullptr, {max_rows, H});
+      c.HD_b[i] = dalloc<float>(m, nullptr, {std::max(std::max(c.Ell_cap, c.Elr_cap), c.Ela_cap), H});
+    }
+  }
   for (int i = 0; i < (cfg.all_atoms ? 9 : 4); ++i) {
     c.Pg[i] = dalloc<float>(m, nullptr, {N, H}); c.Qg[i] = dalloc<float>(m, nullptr, {N, H}); c.rbg[i] = dalloc<float>(m, nullptr, {B, H});
   }
@@ -844,7 +863,7 @@ static void forward_old(Model& m, const float* lig_pos, const float* t_tr, const
   ++c.epoch;
   PhaseTimer t_fwd(m, "forward_total", s);
   std::unique_ptr<PhaseTimer> t_phase(new PhaseTimer(m, "embed_and_graphs", s));
-  launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, c.temb, s);
+  launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, cfg.embedding_type, c.temb, s);
   // OldAtomEncoder: ligand = sum of embeddings + linear(sigma) ; receptor = static part + the sigma columns of lm_embedding_layer
   gemm(c.temb, sd, m.old_lig_lin.W0, sd, m.old_lig_lin.b0, c.ligsig, ns, B, ns, sd, 0, s);
   if (m.lm > 0) gemm(c.temb, sd, m.old_lm_W + ns + m.lm - sd, ns + m.lm, nullptr, c.rec_sig, ns, B, ns, sd, 0, s);
@@ -948,7 +967,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   PhaseTimer t_fwd(m, "forward_total", s);
   std::unique_ptr<PhaseTimer> t_phase(new PhaseTimer(m, "embed_and_graphs", s));
   // ---- per-graph time terms
-  launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, c.temb, s);
+  launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, cfg.embedding_type, c.temb, s);
   {   // the per-graph terms of the time embedding: independent tiny GEMMs, one launch (+ the second layer of rec_sigma)
     GemmBatch gb;
     auto add = [&](const float* W, int ldw, const float* bias, float* C, int act) {

@@ -222,15 +222,43 @@ __global__ __launch_bounds__(256) void k_edge_hidden(const int* __restrict__ nvn
       const int e = e0 + el;
       const int ar = arow ? arow[e] : e;
       const float4 x = nt_load4(HE + (size_t)ar * H + k);
-      const float4 p = *reinterpret_cast<const float4*>(P + (size_t)(tgt[e] - tbase) * H + k);
-      const float4 q = *reinterpret_cast<const float4*>(Q + (size_t)d * H + k);
-      o.x = fmaxf(x.x + p.x + q.x, 0.f); o.y = fmaxf(x.y + p.y + q.y, 0.f);
-      o.z = fmaxf(x.z + p.z + q.z, 0.f); o.w = fmaxf(x.w + p.w + q.w, 0.f);
+      if (P) {   // (P == nullptr: HE already holds the finished hidden rows of a deeper edge MLP, k_edge_rows + GEMMs)
+        const float4 p = *reinterpret_cast<const float4*>(P + (size_t)(tgt[e] - tbase) * H + k);
+        const float4 q = *reinterpret_cast<const float4*>(Q + (size_t)d * H + k);
+        o.x = fmaxf(x.x + p.x + q.x, 0.f); o.y = fmaxf(x.y + p.y + q.y, 0.f);
+        o.z = fmaxf(x.z + p.z + q.z, 0.f); o.w = fmaxf(x.w + p.w + q.w, 0.f);
+      } else {
+        o = x;
+      }
     }
     const int rt = el >> 4, r = el & 15, g = k >> 3, q0 = (k & 7) >> 1;
     *reinterpret_cast<float2*>(Hb + fc_hb_off(v, rt, g, q0 * 16 + r, NGP)) = make_float2(o.x, o.y);
     *reinterpret_cast<float2*>(Hb + fc_hb_off(v, rt, g, (q0 + 1) * 16 + r, NGP)) = make_float2(o.z, o.w);
   }
+}
+// First hidden layer of a deeper edge MLP (tp_weights_layers > 2, models/layers.py:10-17), one plain row per edge in gather
+// order: rows[e] = relu(HE[arow[e]] + P[tgt[e]] + Q[d]); the hidden Linear layers then are ordinary GEMMs over these rows and
+// k_edge_hidden (P == nullptr) only re-orders the last one into fragment order.
+__global__ __launch_bounds__(256) void k_edge_rows(const int* __restrict__ nvn, const int* __restrict__ vn_node,
+                                                  const int* __restrict__ vn_e0, const int* __restrict__ goff,
+                                                  const int* __restrict__ arow, const int* __restrict__ tgt, int tbase,
+                                                  const float* __restrict__ HE, const float* __restrict__ P,
+                                                  const float* __restrict__ Q, int H, float* __restrict__ rows) {
+  const int v = blockIdx.x;
+  if (v >= *nvn) return;
+  const int d = vn_node[v], e0 = vn_e0[v];
+  const int ne = min(32, goff[d + 1] - e0);
+  for (int idx = threadIdx.x; idx < ne * H; idx += blockDim.x) {
+    const int el = idx / H, k = idx - el * H, e = e0 + el;
+    const int ar = arow ? arow[e] : e;
+    rows[(size_t)e * H + k] = fmaxf(HE[(size_t)ar * H + k] + P[(size_t)(tgt[e] - tbase) * H + k] + Q[(size_t)d * H + k], 0.f);
+  }
+}
+void launch_edge_rows(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
+                      const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, float* rows, hipStream_t s) {
+  if (vcap <= 0) return;
+  hipLaunchKernelGGL(k_edge_rows, dim3(vcap), dim3(256), 0, s, nvn, vn_node, vn_e0, goff, arow, tgt, tbase, HE, P, Q, H, rows);
+  DDMI_CHECK_HIP(hipGetLastError());
 }
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                         const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,

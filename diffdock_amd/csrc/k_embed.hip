@@ -8,23 +8,28 @@
 
 namespace ddmi {
 
+// sinusoidal_embedding(scale * t) (utils/diffusion_utils.py:99-110; freq = its exp table) or, fourier = 1,
+// GaussianFourierProjection (:113-127; freq = the frozen parameter W): phase ((t * W) * 2) * pi in the reference's float32 order.
 __global__ void k_time_embedding(const float* __restrict__ t, int B, const float* __restrict__ freq, int half,
-                                 float scale, float* __restrict__ out) {
+                                 float scale, int fourier, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * half) return;
   const int b = idx / half, k = idx - b * half;
+  const float pi = 3.14159274101257324f;   // float32(np.pi)
 #ifdef DDMI_HIPEMU
-  volatile float ts = scale * t[b];
-  volatile float ph = ts * freq[k];
+  volatile float ts = fourier ? t[b] * freq[k] : scale * t[b];
+  volatile float p2 = fourier ? ts * 2.f : ts * freq[k];
+  volatile float ph = fourier ? p2 * pi : p2;
 #else
-  const float ts = __fmul_rn(scale, t[b]);
-  const float ph = __fmul_rn(ts, freq[k]);
+  const float ts = fourier ? __fmul_rn(t[b], freq[k]) : __fmul_rn(scale, t[b]);
+  const float p2 = fourier ? __fmul_rn(ts, 2.f) : __fmul_rn(ts, freq[k]);
+  const float ph = fourier ? __fmul_rn(p2, pi) : p2;
 #endif
   out[b * 2 * half + k] = sinf(ph);
   out[b * 2 * half + half + k] = cosf(ph);
 }
-void launch_time_embedding(const float* t, int B, const float* freq, int half, float scale, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_time_embedding, dim3(cdiv(B * half, 64)), dim3(64), 0, s, t, B, freq, half, scale, out);
+void launch_time_embedding(const float* t, int B, const float* freq, int half, float scale, int fourier, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_time_embedding, dim3(cdiv(B * half, 64)), dim3(64), 0, s, t, B, freq, half, scale, fourier, out);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

@@ -25,7 +25,7 @@ void launch_gemm_batch(const GemmBatch& b, hipStream_t s);   // independent prob
 
 // ---------------------------------------------------------------- k_conv.hip
 // Column layout of a contracted node row Y_d[k][n] ("item-major"): for every output block ob and every output
-// channel w one ITEM of itemw = 4, 8 or 16 consecutive columns holding the (path, i) terms that feed that output
+// channel w one ITEM of itemw = 4, 8, .. 64 consecutive columns holding the (path, i) terms that feed that output
 // channel, so that after the edge GEMM one lane (or 2/4 neighbouring lanes) owns everything an output needs.
 struct ObInfo { int base, itemw, mul, o_off, dout; };       // columns [base, base + mul*itemw)
 struct DevPath {    // coupling descriptor of one tensor-product path
@@ -36,9 +36,10 @@ struct DevPath {    // coupling descriptor of one tensor-product path
 struct GEntry { int c_idx, s_off, ds, dout; };              // G[g] = sum_j ctab[c_idx + j*dout] * sh[s_off + j]
 struct CgItem { int path_begin, path_end, o_off, dout, w; };  // (output block, w) work item of k_tp_apply
 struct NcSlot { int x_off, din, comp, mul_in, u_pad, w_pad, wk_off; };   // one column of an item: (path, input component)
+constexpr int NC_MAXITEM = 64;
 struct NcUnit {     // one (output block, 16-wide w tile) unit of the node contraction: n_w items x itemw columns
   int col_base, itemw, w0, n_w;
-  NcSlot slot[16];  // slot[s].din == 0 -> padding column (written as 0)
+  NcSlot slot[NC_MAXITEM];  // slot[s].din == 0 -> padding column (written as 0)
 };
 
 // ---- the contracted rows never leave the CU (k_conv_fused).
@@ -82,7 +83,9 @@ void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* 
                      hipStream_t s);
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                         const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
-                        float* Hb, hipStream_t s);
+                        float* Hb, hipStream_t s);   // P == Q == nullptr: HE[arow ? arow[e] : e] is the finished hidden row
+void launch_edge_rows(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
+                      const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, float* rows, hipStream_t s);
 // Hidden rows of the edge MLP from the edge attributes in one pass (ns % 16 == 0): first Linear split over its inputs,
 //   h_e = relu(W1e * edge_attr[arow[e]] + P[tgt[e]] + Q[d] (+ rowbias[ridx])),  P = W1s * x_s[:ns], Q = W1d * x_d[:ns] + b1,
 // edge-attribute block on the matrix cores, written straight in the A-fragment order of k_conv_fused (replaces the
@@ -163,7 +166,7 @@ void launch_tor_radius(const float* pos, const int* ptr, const int* tor_u, const
                        float* bond_nvec, hipStream_t s);
 
 // ---------------------------------------------------------------- k_embed.hip
-void launch_time_embedding(const float* t, int B, const float* freq, int half, float scale, float* out, hipStream_t s);
+void launch_time_embedding(const float* t, int B, const float* freq, int half, float scale, int fourier, float* out, hipStream_t s);
 void launch_lig_node_embed(const int* x, int nL, const float* emb, const int* emb_off, int n_feat, int ns, float* out,
                            hipStream_t s);
 void launch_add_rowvec(float* X, int ldx, const float* base, int ldb, const float* vec, int ldv, const int* idx, int rows,

@@ -44,6 +44,8 @@ struct ConvW {  // one TensorProductConvLayer
   TPTable table;
   int n_edge = 0, H = 0, HK = 0, D_in = 0, D_out = 0, NT = 0, sh_dim = 0, Wn = 0;
   std::vector<float*> W1, b1, W2, b2, wpack;
+  int TL = 2;                                                // Linear layers of the per-edge weight MLP (tp_weights_layers)
+  std::vector<std::vector<float*>> Wmid, bmid;               // [group][TL - 2] hidden Linear layers H -> H (TL > 2)
   std::vector<float*> W1p, b1p;   // first layer with the hidden units of every block of 16 in the order k_edge_hidden_mm emits them
   int KS = 0;                                                // k-slab size of wpack
   FGran* fgran = nullptr; int n_fgran = 0, HKq = 0; bool fgran_generic = false;          // fused form: granule list, padded hidden-row length

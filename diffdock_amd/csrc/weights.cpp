@@ -67,7 +67,7 @@ static void init_conv_meta(const ddmi_config& c, ConvW& L, const std::string& na
     for (auto& p : L.table.paths) if (p.out_block == ob) wi += p.din;
     int quads = 1;
     while (quads * 4 < wi) quads *= 2;
-    if (quads > 4 && yform) throw Error(DDMI_ERR_ARG, "tensor product with more than 16 terms per output channel");
+    if (quads > 16 && yform) throw Error(DDMI_ERR_ARG, "tensor product with more than 64 terms per output channel");   // (second-order features reach 20-35: several granules of 4 slots whose message columns add up)
     nt = (int)round_up(nt, quads * 4) + out[ob].mul * quads * 4;
   }
   L.NT = nt;
@@ -78,8 +78,8 @@ void build_weight_spec(Model& m) {
   DDMI_REQUIRE(c.ns > 0 && c.nv >= 0 && c.num_conv_layers >= 1, DDMI_ERR_ARG, "bad ns/nv/num_conv_layers");
   DDMI_REQUIRE(c.sh_lmax == 1 || c.sh_lmax == 2, DDMI_ERR_ARG, "sh_lmax must be 1 or 2");
   DDMI_REQUIRE(c.sigma_embed_dim % 2 == 0 && c.sigma_embed_dim >= 4, DDMI_ERR_ARG, "sigma_embed_dim must be even");
-  DDMI_REQUIRE(c.embed_also_ligand || c.num_prot_emb_layers == 0, DDMI_ERR_ARG,
-               "embed_also_ligand=False with embedding layers is rejected by the reference (cg_model.py:263)");
+  DDMI_REQUIRE(c.embed_also_ligand || c.num_prot_emb_layers == 0 || c.all_atoms, DDMI_ERR_ARG,
+               "embed_also_ligand=False with embedding layers is rejected by the reference's CGModel (cg_model.py:263)");
   DDMI_REQUIRE(irreps_dim(layer_irreps(c, 3)) <= XS, DDMI_ERR_ARG, "irreps wider than the node-table stride");
   m.ns = c.ns; m.sd = c.sigma_embed_dim; m.D = c.distance_embed_dim; m.Dc = c.cross_distance_embed_dim;
   m.nf = c.in_lig_edge_features; m.lm = c.lm_embedding_dim; m.H = 3 * c.ns;
@@ -108,10 +108,14 @@ void build_weight_spec(Model& m) {
     for (int g = 0; g < L.G; ++g) {
       const std::string pre = L.G == 1 ? L.name + ".fc" : L.name + ".fc." + std::to_string(g);
       lin(pre + ".0", L.n_edge, L.H);
-      lin(pre + ".3", L.H, L.Wn);
+      for (int j = 1; j + 1 < L.TL; ++j) lin(pre + "." + std::to_string(3 * j), L.H, L.H);   // FCBlock hidden layers (models/layers.py:14-15)
+      lin(pre + "." + std::to_string(3 * (L.TL - 1)), L.H, L.Wn);
     }
     if (L.has_bn) bn(L.name + ".batch_norm", L.out_irr);
   };
+  const int TL = c.tp_weights_layers <= 0 ? 2 : c.tp_weights_layers;
+  DDMI_REQUIRE(TL >= 2 && TL <= 8, DDMI_ERR_ARG, "tp_weights_layers must be >= 2 (FCBlock asserts it, models/layers.py:12)");
+  DDMI_REQUIRE(c.embedding_type == 0 || c.embedding_type == 1, DDMI_ERR_ARG, "embedding_type: 0 sinusoidal, 1 fourier");
   const Irreps sh = sh_irreps(c.sh_lmax);
   const bool faster = c.sh_lmax == 1 && !c.use_second_order_repr;
   const int K = c.num_prot_emb_layers, Lc = c.num_conv_layers;
@@ -138,6 +142,7 @@ void build_weight_spec(Model& m) {
   if (c.old_model) {   // models/old_cg_model.py:18-200, models/layers.py:70-118, models/tensor_layers.py:338-380
     DDMI_REQUIRE(c.sh_lmax == 2 && !c.all_atoms && K == 0, DDMI_ERR_ARG,
                  "legacy class: sh_lmax = 2, CG graphs, no embedding layers");
+    DDMI_REQUIRE(c.embedding_type == 0, DDMI_ERR_ARG, "legacy class: sinusoidal timestep embedding only");
     auto old_encoder = [&](const std::string& n, const int* dims, int nd, bool lm) {
       for (int i = 0; i < nd; ++i) S.push_back({n + ".atom_embedding_list." + std::to_string(i) + ".weight", {dims[i], ns}});
       lin(n + ".linear", sd, ns);
@@ -197,22 +202,26 @@ void build_weight_spec(Model& m) {
   S.push_back({"lig_distance_expansion.offset", {m.D}});
   S.push_back({"rec_distance_expansion.offset", {m.D}});
   S.push_back({"cross_distance_expansion.offset", {m.Dc}});
+  if (c.embedding_type == 1) S.push_back({"timestep_emb_func.W", {sd / 2}});   // GaussianFourierProjection.W (nn.Parameter, requires_grad=False)
   m.rec_emb_layers.assign(K, ConvW());
   m.lig_emb_layers.assign(c.embed_also_ligand ? K : 0, ConvW());
   m.conv_layers.assign(Lc, ConvW());
   for (int i = 0; i < K; ++i) {
     init_conv_meta(c, m.rec_emb_layers[i], "rec_emb_layers." + std::to_string(i), layer_irreps(c, i), sh,
                    layer_irreps(c, i + 1), 3 * ns, (c.all_atoms && c.differentiate_convolutions) ? 4 : 1, faster, true, true);
+    m.rec_emb_layers[i].TL = TL;
     conv(m.rec_emb_layers[i]);
   }
   for (int i = 0; i < (int)m.lig_emb_layers.size(); ++i) {
     init_conv_meta(c, m.lig_emb_layers[i], "lig_emb_layers." + std::to_string(i), layer_irreps(c, i), sh,
                    layer_irreps(c, i + 1), 3 * ns, 1, faster, true, true);
+    m.lig_emb_layers[i].TL = TL;
     conv(m.lig_emb_layers[i]);
   }
   for (int l = 0; l < Lc; ++l) {
     init_conv_meta(c, m.conv_layers[l], "conv_layers." + std::to_string(l), layer_irreps(c, K + l), sh,
                    layer_irreps(c, K + l + 1), 3 * ns, conv_groups(c, l), faster, true, true);
+    m.conv_layers[l].TL = TL;
     conv(m.conv_layers[l]);
   }
   const Irreps last_out = layer_irreps(c, K + Lc);
@@ -257,6 +266,8 @@ static Mlp2W up_mlp(Model& m, const std::string& n) {
 
 static void commit_conv(Model& m, ConvW& L) {
   const int H = L.H, HK = L.HK;
+  // (a second load_state_dict on the same handle starts from empty lists: the pool behind the old pointers was released)
+  L.W1.clear(); L.b1.clear(); L.W2.clear(); L.b2.clear(); L.wpack.clear(); L.W1p.clear(); L.b1p.clear(); L.Wmid.clear(); L.bmid.clear();
   // coupling tables ---------------------------------------------------------------
   std::vector<DevPath> dp;
   std::vector<float> ctab;
@@ -329,7 +340,13 @@ static void commit_conv(Model& m, ConvW& L) {
         L.b1p.push_back(nullptr);
       }
     }
-    const HostTensor &w2 = W(m, pre + ".3.weight"), &b2 = W(m, pre + ".3.bias");
+    const std::string last = pre + "." + std::to_string(3 * (L.TL - 1));
+    L.Wmid.emplace_back(); L.bmid.emplace_back();
+    for (int j = 1; j + 1 < L.TL; ++j) {
+      L.Wmid.back().push_back(up(m, pre + "." + std::to_string(3 * j) + ".weight"));
+      L.bmid.back().push_back(up(m, pre + "." + std::to_string(3 * j) + ".bias"));
+    }
+    const HostTensor &w2 = W(m, last + ".weight"), &b2 = W(m, last + ".bias");
     if (!L.yform) {
       L.W2.push_back(m.wpool.upload(w2.data));
       L.b2.push_back(m.wpool.upload(b2.data));
@@ -370,8 +387,8 @@ static void commit_conv(Model& m, ConvW& L) {
       for (int w0 = 0; w0 < O.mul; w0 += 16) {
         NcUnit U{};
         U.col_base = O.base; U.itemw = O.itemw; U.w0 = w0; U.n_w = std::min(16, O.mul - w0);
-        int slot_g[16];
-        for (int i = 0; i < 16; ++i) slot_g[i] = -1;
+        int slot_g[NC_MAXITEM];
+        for (int i = 0; i < NC_MAXITEM; ++i) slot_g[i] = -1;
         for (size_t pi = 0; pi < L.table.paths.size(); ++pi) {
           const TPPath& p = L.table.paths[pi];
           if (p.out_block != ob) continue;
@@ -708,8 +725,13 @@ void commit_weights(Model& m) {
   for (auto& L : m.lig_emb_layers) commit_conv(m, L);
   for (auto& L : m.conv_layers) commit_conv(m, L);
   if (!c.confidence_mode) commit_readouts(m);
-  // sinusoidal embedding frequencies (utils/diffusion_utils.py:101-103) unless supplied by the caller
+  // sinusoidal embedding frequencies (utils/diffusion_utils.py:101-103) unless supplied by the caller; 'fourier': the frozen W
   const int half = m.sd / 2;
+  if (c.embedding_type == 1) {
+    m.time_freq = up(m, "timestep_emb_func.W");
+    m.committed = true;
+    return;
+  }
   if ((int)m.time_freq_host.size() != half) {
     m.time_freq_host.resize(half);
     const double e = std::log(10000.0) / (half - 1);

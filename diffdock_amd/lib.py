@@ -33,7 +33,7 @@ class Config(C.Structure):
                                          "rot_sigma_max", "tor_sigma_min", "tor_sigma_max")] + \
                [("all_atoms", C.c_int32), ("confidence_mode", C.c_int32), ("num_confidence_outputs", C.c_int32),
                 ("old_model", C.c_int32), ("atom_confidence", C.c_int32), ("atom_num_confidence_outputs", C.c_int32),
-                ("affinity_prediction", C.c_int32)]
+                ("affinity_prediction", C.c_int32), ("embedding_type", C.c_int32), ("tp_weights_layers", C.c_int32)]
 
 
 class Complex(C.Structure):
@@ -60,6 +60,8 @@ def make_config(cfg) -> Config:
             c.lm_embedding_dim = cfg.lm_embedding_dim
         elif name == "old_model":
             c.old_model = int(cfg.old)
+        elif name == "embedding_type":
+            c.embedding_type = {"sinusoidal": 0, "fourier": 1}[cfg.embedding_type]
         else:
             setattr(c, name, getattr(cfg, name))
     return c

@@ -32,6 +32,45 @@ def _collate(chunk):
         return HeteroBatch.from_data_list(chunk)
 
 
+def _edge_store(g, a, b):
+    """Edge store of node types (a, b) whatever the relation name (('receptor', 'rec_contact', 'receptor') in the reference)."""
+    for et in g.edge_types:
+        if et[0] == a and et[-1] == b:
+            return g[et]
+    return g[a, b]
+
+
+def crop_beyond(graph, cutoff, all_atoms=False):
+    """utils/utils.py:388-413 on ONE complex graph, in place: residues (and, all_atoms, their atoms) farther than `cutoff`
+    from every ligand atom are removed, contact graphs restricted to the kept nodes and relabelled.  Host tensors: the
+    reference applies it to the confidence graphs once per batch (utils/sampling.py:213-217); the per-step crop of the score
+    model runs on the device instead (ddmi_set_crop_cutoff)."""
+    lig, rec = graph["ligand"].pos, graph["receptor"].pos
+    keep = torch.any(torch.sum((lig.unsqueeze(0) - rec.unsqueeze(1)) ** 2, -1) < cutoff ** 2, dim=1)
+
+    def sub_graph(mask, edge_index):
+        ok = mask[edge_index[0]] & mask[edge_index[1]]
+        return (torch.cumsum(mask.long(), 0) - 1)[edge_index[:, ok]]
+    if all_atoms:
+        ar = _edge_store(graph, "atom", "receptor")
+        a2r = ar.edge_index[1]
+        atoms_keep = keep[a2r]
+        new_a2r = (torch.cumsum(keep.long(), 0) - 1)[a2r][atoms_keep]
+    graph["receptor"].pos = rec[keep]
+    graph["receptor"].x = graph["receptor"].x[keep]
+    if hasattr(graph["receptor"], "side_chain_vecs") and graph["receptor"].side_chain_vecs is not None:
+        graph["receptor"].side_chain_vecs = graph["receptor"].side_chain_vecs[keep]
+    rr = _edge_store(graph, "receptor", "receptor")
+    rr.edge_index = sub_graph(keep, rr.edge_index)
+    if all_atoms:
+        graph["atom"].x = graph["atom"].x[atoms_keep]
+        graph["atom"].pos = graph["atom"].pos[atoms_keep]
+        aa = _edge_store(graph, "atom", "atom")
+        aa.edge_index = sub_graph(atoms_keep, aa.edge_index)
+        ar.edge_index = torch.stack([torch.arange(len(new_a2r), device=new_a2r.device), new_a2r])
+    return graph
+
+
 def step_coefficients(model_args, t_idx, inference_steps, schedules, ode=False, no_random=False, no_final_step_noise=False,
                       temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5):
     """Host float64 scalars of one step (utils/sampling.py:97-186): per component (score coefficient, noise
@@ -66,9 +105,8 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         raise NotImplementedError("visualisation / trajectories / feature returns are outside the built path")
     confidence = [] if confidence_model is not None else None
     conf_batches = None
+    conf_crop = getattr(confidence_model_args, "crop_beyond", None) if confidence_model_args is not None else None
     if confidence_model is not None and confidence_data_list is not None:
-        if getattr(confidence_model_args, "crop_beyond", None) is not None:
-            raise NotImplementedError("crop_beyond on the confidence graphs (sampling.py:213-217)")
         conf_batches = iter([c for _, c in _batches(confidence_data_list, batch_size)])   # DataLoader order, sampling.py:87
     crop = getattr(model_args, "crop_beyond", None) if model_args is not None else getattr(model.cfg, "crop_beyond", None)
     N = len(data_list)
@@ -116,7 +154,13 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 data_list[lo + i]["ligand"].pos = pos[i]
             if confidence_model is not None:   # sampling.py:208-227
                 if conf_batches is not None:
-                    cbatch = _collate(next(conf_batches))
+                    cgraphs = next(conf_batches)
+                    if conf_crop is not None:   # sampling.py:213-217: every confidence graph cropped around ITS final pose
+                        cgraphs = [g_.clone() for g_ in cgraphs]
+                        for i, g_ in enumerate(cgraphs):
+                            g_["ligand"].pos = pos[i].detach().to(g_["receptor"].pos.device, g_["receptor"].pos.dtype)
+                            crop_beyond(g_, conf_crop, bool(getattr(confidence_model_args, "all_atoms", False)))
+                    cbatch = _collate(cgraphs)
                     cbatch["ligand"].pos = pos.reshape(b * n, 3).to(cbatch["ligand"].pos.device)
                     if device is not None:
                         cbatch = cbatch.to(device)

@@ -58,13 +58,15 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
         spec[f"{name}.weight"] = ((nf,), "bn_w")
         spec[f"{name}.bias"] = ((n0,), "bn_b")
 
-    def conv(name, in_irr, sh, out_irr, n_edge, hidden, groups, faster):
+    def conv(name, in_irr, sh, out_irr, n_edge, hidden, groups, faster, deep=False):
         W = tp_weight_numel(in_irr, sh, out_irr, faster)
         for g in range(groups):
             pre = f"{name}.fc" if groups == 1 else f"{name}.fc.{g}"
-            assert cfg.tp_weights_layers == 2, "FCBlock with extra hidden layers not on the built path"
+            tl = cfg.tp_weights_layers if deep else 2   # FCBlock(..., tp_weights_layers, ...) (models/layers.py:10-17): keys 0, 3, .. 3(tl-1)
             lin(f"{pre}.0", n_edge, hidden)
-            lin(f"{pre}.3", hidden, W)
+            for j in range(1, tl - 1):
+                lin(f"{pre}.{3 * j}", hidden, hidden)
+            lin(f"{pre}.{3 * (tl - 1)}", hidden, W)
         if cfg.batch_norm:
             bn(f"{name}.batch_norm", out_irr)
 
@@ -90,18 +92,20 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
     spec["lig_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:lig")
     spec["rec_distance_expansion.offset"] = ((cfg.distance_embed_dim,), "offset:rec")
     spec["cross_distance_expansion.offset"] = ((cfg.cross_distance_embed_dim,), "offset:cross")
+    if cfg.embedding_type == "fourier":   # GaussianFourierProjection.W (utils/diffusion_utils.py:118-120)
+        spec["timestep_emb_func.W"] = ((sd // 2,), "fourier_w")
     K, L = cfg.num_prot_emb_layers, cfg.num_conv_layers
     for i in range(K):
         a, b = cfg.layer_irreps(i)
         conv(f"rec_emb_layers.{i}", a, sh, b, 3 * ns, 3 * ns,
-             (4 if cfg.differentiate_convolutions else 1) if cfg.all_atoms else 1, cfg.faster)
+             (4 if cfg.differentiate_convolutions else 1) if cfg.all_atoms else 1, cfg.faster, deep=True)
     if cfg.embed_also_ligand:
         for i in range(K):
             a, b = cfg.layer_irreps(i)
-            conv(f"lig_emb_layers.{i}", a, sh, b, 3 * ns, 3 * ns, 1, cfg.faster)
+            conv(f"lig_emb_layers.{i}", a, sh, b, 3 * ns, 3 * ns, 1, cfg.faster, deep=True)
     for l in range(L):
         a, b = cfg.layer_irreps(K + l)
-        conv(f"conv_layers.{l}", a, sh, b, 3 * ns, 3 * ns, cfg.conv_groups(l), cfg.faster)
+        conv(f"conv_layers.{l}", a, sh, b, 3 * ns, 3 * ns, cfg.conv_groups(l), cfg.faster, deep=True)
     last_out = cfg.layer_irreps(K + L - 1)[1]
     if cfg.confidence_mode:   # cg_model.py:181-207: Linear, BatchNorm1d, ReLU, Dropout, Linear, BatchNorm1d, ReLU, Dropout, Linear
         n_in = ns + (cfg.nv if cfg.reduce_pseudoscalars else ns) if K + L >= 3 else ns
@@ -218,6 +222,8 @@ def init_state_dict(cfg: ModelConfig, seed: int = 1234, dtype=torch.float32) -> 
             sd[key] = (U(shape, 0.5) + 1.0)
         elif kind == "bn_b":
             sd[key] = U(shape, 0.2)
+        elif kind == "fourier_w":     # torch.randn(embedding_size // 2) * scale
+            sd[key] = (torch.randn(shape, generator=g, dtype=torch.float64) * cfg.embedding_scale).to(dtype)
         else:
             raise KeyError(kind)
     return sd

@@ -64,6 +64,12 @@ typedef struct ddmi_config {
    * graph mean (`atom_confidence_loss_weight > 0`, atom_num_confidence_outputs = len(atom_rmsd_classification_cutoff) + 1)
    * and one extra affinity output of confidence_predictor (`affinity_prediction`, parallel = 1) */
   int32_t atom_confidence, atom_num_confidence_outputs, affinity_prediction;
+  /* get_timestep_embedding (utils/diffusion_utils.py:129-136): 0 = 'sinusoidal' (embedding_scale multiplies t), 1 = 'fourier'
+   * (GaussianFourierProjection, :113-127; its frozen parameter W is the state_dict key `timestep_emb_func.W`) */
+  int32_t embedding_type;
+  /* FCBlock depth of the per-edge weight MLP of the embedding / interaction layers (models/layers.py:10-17,
+   * tensor_layers.py:302-304): 2 (or 0) = Linear, ReLU, Linear; n > 2 adds n - 2 hidden Linear + ReLU (keys fc.3 .. fc.3(n-1)) */
+  int32_t tp_weights_layers;
 } ddmi_config;
 
 /* Static description of one collated batch of complexes = the fields of the PyG Batch the

@@ -10,6 +10,7 @@ Line map (reference models/aa_model.py):
 Ligand graph, centre/bond graphs and the read-outs are the CGModel ones (same code in the reference).
 """
 import torch
+import torch.nn.functional as F
 
 from .cg_model import CGModelOracle
 from .conformer import t_to_sigma
@@ -23,7 +24,8 @@ class AAModelOracle(CGModelOracle):
         c, sd = cfg, self.sd
         g4 = 4 if c.differentiate_convolutions else 1
         self.rec_emb_layers = [TPConv(sd, f"rec_emb_layers.{i}", *self._io(i), residual=True, batch_norm=c.batch_norm,
-                                      faster=c.faster, edge_groups=g4) for i in range(c.num_prot_emb_layers)]
+                                      faster=c.faster, edge_groups=g4, tp_weights_layers=c.tp_weights_layers)
+                               for i in range(c.num_prot_emb_layers)]
 
     # ------------------------------------------------------------------ receptor-side graphs (static)
     def build_atom_conv_graph(self, data):
@@ -103,7 +105,10 @@ class AAModelOracle(CGModelOracle):
         atom_node_attr[:, :ns] = atom_node_attr[:, :ns] + sig[atom.batch]
         atom_edge_attr = atom_edge_attr + sig[atom.batch[atom_ei[0]]]
         ar_edge_attr = ar_edge_attr + sig[atom.batch[ar_ei[0]]]
-        return self.ligand_embedding(data) + (rec_node_attr, rec_ei, rec_edge_attr, rec_edge_sh, rec_ew,
+        lig = self.ligand_embedding(data)
+        if not c.embed_also_ligand:   # aa_model.py:355-357: ligand rows zero-padded to the width the embedding layers produced
+            lig = (F.pad(lig[0], (0, rec_node_attr.shape[-1] - lig[0].shape[-1])),) + lig[1:]
+        return lig + (rec_node_attr, rec_ei, rec_edge_attr, rec_edge_sh, rec_ew,
                                                atom_node_attr, atom_ei, atom_edge_attr, atom_edge_sh, atom_ew,
                                                ar_ei, ar_edge_attr, ar_edge_sh, ar_ew)
 

@@ -49,7 +49,7 @@ class CGModelOracle:
         self.sh_irreps = Irreps.spherical_harmonics(c.sh_lmax)
         K, L = c.num_prot_emb_layers, c.num_conv_layers
         mk = lambda name, i, groups: TPConv(sd, name, *self._io(i), residual=True, batch_norm=c.batch_norm,
-                                            faster=c.faster, edge_groups=groups)
+                                            faster=c.faster, edge_groups=groups, tp_weights_layers=c.tp_weights_layers)
         self.rec_emb_layers = [mk(f"rec_emb_layers.{i}", i, 1) for i in range(K)]
         self.lig_emb_layers = [mk(f"lig_emb_layers.{i}", i, 1) for i in range(K)] if c.embed_also_ligand else []
         self.conv_layers = [mk(f"conv_layers.{l}", K + l, c.conv_groups(l)) for l in range(L)]
@@ -71,6 +71,9 @@ class CGModelOracle:
 
     # ------------------------------------------------------------------ helpers
     def _temb(self, t):
+        if self.cfg.embedding_type == "fourier":   # GaussianFourierProjection.forward (utils/diffusion_utils.py:123-127)
+            x_proj = t.to(self.dtype)[:, None] * self.sd["timestep_emb_func.W"][None, :] * 2 * np.pi
+            return torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
         return sinusoidal_embedding(self.cfg.embedding_scale * t, self.cfg.sigma_embed_dim).to(self.dtype)
 
     def _sh(self, vec, irreps=None):

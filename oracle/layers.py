@@ -30,6 +30,13 @@ def mlp2(sd, name, x, act=torch.relu, second="3"):
     return linear(sd, f"{name}.{second}", act(linear(sd, f"{name}.0", x)))
 
 
+def fc_block(sd, name, x, layers):
+    """FCBlock(in, hidden, out, layers) in eval mode (models/layers.py:10-17): Linear keys 0, 3, .. 3(layers-1), ReLU between."""
+    for j in range(layers - 1):
+        x = torch.relu(linear(sd, f"{name}.{3 * j}", x))
+    return linear(sd, f"{name}.{3 * (layers - 1)}", x)
+
+
 def gaussian_smearing(offset, dist):
     coeff = -0.5 / (offset[1] - offset[0]).item() ** 2
     d = dist.reshape(-1, 1) - offset.reshape(1, -1)
@@ -110,7 +117,8 @@ class TPConv:
     """One TensorProductConvLayer (eval mode) bound to a state_dict prefix."""
 
     def __init__(self, sd, name, in_irreps, sh_irreps, out_irreps, residual=True, batch_norm=True,
-                 faster=False, edge_groups=1):
+                 faster=False, edge_groups=1, tp_weights_layers=2):
+        self.tp_weights_layers = tp_weights_layers
         self.sd, self.name = sd, name
         self.in_irreps, self.sh_irreps, self.out_irreps = Irreps(in_irreps), Irreps(sh_irreps), Irreps(out_irreps)
         self.residual, self.batch_norm, self.faster, self.edge_groups = residual, batch_norm, faster, edge_groups
@@ -127,7 +135,7 @@ class TPConv:
 
     def _fc(self, g, edge_attr):
         pre = f"{self.name}.fc" if self.edge_groups == 1 else f"{self.name}.fc.{g}"
-        return mlp2(self.sd, pre, edge_attr)
+        return fc_block(self.sd, pre, edge_attr, self.tp_weights_layers)
 
     def __call__(self, node_attr, edge_index, edge_attr, edge_sh, out_nodes=None, reduce="mean", edge_weight=1.0):
         if edge_index.shape[1] == 0 and node_attr.shape[0] == 0:

@@ -172,6 +172,14 @@ def main():
                              n_samples=2, seed=15, t=0.55)
     cases["tiny_aa_2nd"] = dict(cfg=TINY.replace(all_atoms=True, use_second_order_repr=True, sh_lmax=2, num_conv_layers=3,
                                                   reduce_pseudoscalars=True), n_res=16, n_lig=9, n_samples=2, seed=17, t=0.45)
+    # get_timestep_embedding('fourier') (GaussianFourierProjection, utils/diffusion_utils.py:113-136): the frozen W is a state_dict key
+    cases["tiny_fourier"] = dict(cfg=TINY.replace(embedding_type="fourier", sh_lmax=2), n_res=24, n_lig=10, n_samples=2, seed=18, t=0.65)
+    # FCBlock with a hidden Linear layer (tp_weights_layers = 3, models/layers.py:10-17) in embedding and interaction layers
+    cases["tiny_tpw3"] = dict(cfg=TINY.replace(tp_weights_layers=3, num_prot_emb_layers=1, num_conv_layers=3), n_res=22, n_lig=10,
+                              n_samples=2, seed=19, t=0.5)
+    # AAModel with receptor embedding layers and embed_also_ligand=False: ligand rows zero-padded (models/aa_model.py:351-357)
+    cases["tiny_aa_emb_nolig"] = dict(cfg=TINY.replace(all_atoms=True, num_conv_layers=2, num_prot_emb_layers=2, sh_lmax=2,
+                                                        embed_also_ligand=False), n_res=17, n_lig=9, n_samples=2, seed=20, t=0.5)
     if len(sys.argv) > 1:
         cases = {k: v for k, v in cases.items() if k in sys.argv[1:]}
     for name, c in cases.items():
@@ -239,6 +247,47 @@ def main():
         torch.save(fixture, os.path.join(HERE, f"{name}.pt"))
         print(name, "tr", tr[0].tolist(), "tor", tor[:3].tolist(), "n_draws", len(draws))
 
+    if len(sys.argv) == 1 or "conf_crop" in sys.argv[1:]:
+        # ---- sampling() with a confidence model whose args carry crop_beyond (utils/sampling.py:208-227): the confidence graphs
+        # are cropped around the final poses before the confidence model sees them.  Score model = tiny_l1, confidence = tiny_conf_l2.
+        from tests_util_shim import fixture_case_shim
+        fs, cfg_s, dl_s = fixture_case_shim(HERE, "tiny_l1")
+        fc, cfg_c, _ = fixture_case_shim(HERE, "tiny_conf_l2")
+        args_s, args_c = cfg_s.to_namespace(), cfg_c.to_namespace()
+        args_c.crop_beyond = 18.0
+        tts = partial(t_to_sigma_compl, args=args_s)
+        score = get_model(args_s, torch.device("cpu"), t_to_sigma=tts, no_parallel=True)
+        score.load_state_dict(fs["state_dict"], strict=False); score.eval()
+        confm = get_model(args_c, torch.device("cpu"), t_to_sigma=partial(t_to_sigma_compl, args=args_c), no_parallel=True,
+                          confidence_mode=True)
+        confm.load_state_dict(fc["state_dict"], strict=False); confm.eval()
+        steps, draws, real_normal = 3, [], torch.normal
+
+        def rec_normal2(*a, **kw):
+            z = real_normal(*a, **kw)
+            draws.append(z.clone())
+            return z
+        torch.manual_seed(11)
+        ref_sampling.torch.normal = rec_normal2
+        kept = []
+        real_crop = ref_sampling.crop_beyond
+
+        def rec_crop(g_, cutoff, aa):
+            real_crop(g_, cutoff, aa)
+            kept.append(int(g_["receptor"].pos.shape[0]))
+        ref_sampling.crop_beyond = rec_crop
+        sched = get_t_schedule("expbeta", steps)
+        try:
+            out_list, conf = ref_sampling.sampling(copy.deepcopy(dl_s), score, steps, sched, sched, sched, torch.device("cpu"), tts,
+                                                   args_s, confidence_model=confm, confidence_data_list=copy.deepcopy(dl_s),
+                                                   confidence_model_args=args_c, batch_size=len(dl_s), no_final_step_noise=True)
+        finally:
+            ref_sampling.torch.normal = real_normal
+            ref_sampling.crop_beyond = real_crop
+        assert 0 < min(kept) < dl_s[0]["receptor"].pos.shape[0], kept
+        torch.save({"steps": steps, "draws": draws, "crop_beyond": 18.0, "kept_residues": kept, "confidence": conf,
+                    "final_pos": torch.stack([d["ligand"].pos for d in out_list])}, os.path.join(HERE, "conf_crop.pt"))
+        print("conf_crop kept", kept, "confidence", conf.tolist())
     if len(sys.argv) > 1:
         return
     # ---- crop_beyond (utils/utils.py:388-413) on one complex

@@ -76,8 +76,8 @@ def test_load_state_dict_accepts_the_reference_modules_unfiltered_keys(make):
 def test_get_model_rejects_arguments_outside_the_built_path():
     base = TINY.to_namespace()
     assert config_from_args(base).ns == TINY.ns
-    for key, val in (("embedding_type", "fourier"), ("esm_embeddings_model", "esm2_t33"), ("parallel", 2),
-                     ("depthwise_convolution", True), ("sidechain_loss_weight", 0.5), ("tp_weights_layers", 3)):
+    for key, val in (("embedding_type", "learned"), ("esm_embeddings_model", "esm2_t33"), ("parallel", 2),
+                     ("depthwise_convolution", True), ("sidechain_loss_weight", 0.5), ("tp_weights_layers", 1)):
         ns = argparse.Namespace(**vars(base))
         setattr(ns, key, val)
         with pytest.raises(NotImplementedError):
@@ -89,6 +89,12 @@ def test_get_model_rejects_arguments_outside_the_built_path():
     ns.num_prot_emb_layers = 1
     with pytest.raises(NotImplementedError):
         config_from_args(ns)
+    ns.all_atoms = True                          # AAModel zero-pads the ligand rows instead (aa_model.py:351-357): built
+    assert not config_from_args(ns).embed_also_ligand
+    for key, val in (("embedding_type", "fourier"), ("tp_weights_layers", 3), ("use_second_order_repr", True)):   # built since round 4
+        ns = argparse.Namespace(**vars(base))
+        setattr(ns, key, val)
+        assert getattr(config_from_args(ns), key) == val
 
 
 def test_randomize_position_matches_reference_execution():

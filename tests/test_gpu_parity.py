@@ -19,7 +19,9 @@ from util import assert_scores_close, fixture_case, graph_from_dict, load_fixtur
 pytestmark = pytest.mark.gpu
 REL = 1e-4
 CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb",
-         "tiny_noaa", "tiny_2nd", "tiny_aa_2nd"]   # tiny_*2nd: use_second_order_repr (2e / 2o node blocks)
+         "tiny_noaa", "tiny_2nd", "tiny_aa_2nd",   # tiny_*2nd: use_second_order_repr (2e / 2o node blocks)
+         "tiny_fourier", "tiny_tpw3",              # embedding_type='fourier'; tp_weights_layers=3
+         "tiny_aa_emb_nolig"]                      # AAModel: embedding layers without embed_also_ligand (zero-padded ligand rows)
 
 
 def gpu_model(cfg, sd):
@@ -51,7 +53,8 @@ def test_forward_matches_reference_fixture(name):
             assert rel_err(mine[:n, :ref_nodes.shape[1]], ref_nodes[:n]) < REL, l
 
 
-@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb", "tiny_2nd", "tiny_aa_2nd"])
+@pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb", "tiny_2nd", "tiny_aa_2nd", "tiny_fourier",
+                                  "tiny_tpw3", "tiny_aa_emb_nolig"])
 def test_device_loop_matches_reference_trajectory(name):
     fx, cfg, data_list = fixture_case(name)
     m = gpu_model(cfg, fx["state_dict"])
@@ -357,3 +360,27 @@ def test_large_pocket_stress_config():
     tr_s, rot_s, tor_s, _ = m(to_gpu(sb))
     R = tor.numel() // B
     assert rel_err(tr_s.cpu(), tr[:2].cpu()) < 1e-5 and rel_err(tor_s.cpu(), tor[:2 * R].cpu()) < 1e-5
+
+
+def test_sampling_crops_confidence_graphs_like_the_reference():
+    """sampling(..., confidence_model_args.crop_beyond) (utils/sampling.py:213-217): the confidence graphs are cropped around
+    the FINAL poses (18 A here: 18 / 4 / 40 of 40 residues survive for the three poses) before the confidence model runs.
+    Fixture = the reference's own sampling() + crop_beyond + both model classes executed (make_golden.py conf_crop)."""
+    import argparse
+    import copy
+    from diffdock_amd.sampling import sampling
+    fx = load_fixture("conf_crop")
+    fs, cfg, data_list = fixture_case("tiny_l1")
+    fc, ccfg, _ = fixture_case("tiny_conf_l2")
+    score = gpu_model(cfg, fs["state_dict"])
+    conf_model = MIScoreModel(ccfg, device="cuda:0")
+    conf_model.load_state_dict(fc["state_dict"])
+    B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
+    sched = get_t_schedule(fx["steps"])
+    cargs = argparse.Namespace(crop_beyond=fx["crop_beyond"], all_atoms=False)
+    out, conf = sampling(copy.deepcopy(data_list), score, fx["steps"], sched, sched, sched, model_args=cfg, confidence_model=conf_model,
+                         confidence_data_list=copy.deepcopy(data_list), confidence_model_args=cargs, batch_size=B,
+                         no_final_step_noise=True, noise=split_draws(fx["draws"], fx["steps"], B, R), device="cuda:0")
+    pos = torch.stack([d["ligand"].pos.cpu() for d in out])
+    assert (pos - fx["final_pos"]).abs().max() < 2e-3
+    assert conf.shape == fx["confidence"].shape and rel_err(conf.cpu(), fx["confidence"]) < 1e-4
