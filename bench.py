@@ -70,6 +70,19 @@ WORKLOADS = {
 }
 # last committed PMC pass for the dominant kernel (tools/round_profile.sh, separate --pmc passes, gfx950 corrections applied)
 TRAFFIC_RECORD = os.path.join(ROOT, "profiles", "traffic_latest.json")
+KERNEL_SOURCE = os.path.join(ROOT, "diffdock_amd", "csrc", "k_conv.hip")
+
+
+def traffic_from_record(rec, kernel_source=KERNEL_SOURCE):
+    """(bytes per launch, source note, L2 hit rate) of a counter record -- only when the record was collected on the kernel
+    source that is in the tree now (sha256 of k_conv.hip stored by tools/traffic_json.py): counters of an older kernel are not
+    replayed next to a newer one."""
+    import hashlib
+    want = rec.get("kernel_source_sha256")
+    have = hashlib.sha256(open(kernel_source, "rb").read()).hexdigest() if os.path.exists(kernel_source) else None
+    if want is None or want != have:
+        return None, f"stale: {rec.get('source')} was collected on another k_conv.hip (re-run tools/round_profile.sh)", None
+    return rec["bytes_per_launch"], rec["source"], rec.get("l2_hit_rate")
 
 
 def bench_cfg():
@@ -340,7 +353,7 @@ def main():
             if os.path.exists(TRAFFIC_RECORD):        # counter bytes are collected by a separate rocprofv3 --pmc pass (tools/round_profile.sh)
                 rec = json.load(open(TRAFFIC_RECORD))
                 if rec.get("kernel") == dom and rec.get("config") == args.config and args.samples is None and world == 1:
-                    traffic, traffic_src, l2_hit = rec["bytes_per_launch"], rec["source"], rec.get("l2_hit_rate")
+                    traffic, traffic_src, l2_hit = traffic_from_record(rec)
             conv_flops_fwd = sum(w["flops"] for w in w_dom) / len(jobs)                     # per forward of one complex
             wall_ach = conv_flops_fwd * n_forwards_timed / dt / 1e12                         # TFLOP/s over the timed region
             fwd_ms = timings.get("forward_total", (0.0, 0))[0] / max(n_forwards, 1)

@@ -34,7 +34,10 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     if (const char* e = getenv("DDMI_FUSED_SHARED")) h->m.fused_shared = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FC1_BATCH")) h->m.fc1_batch = atoi(e) != 0;
-    if (const char* e = getenv("DDMI_TP_APPLY")) h->m.tp_form = !strcmp(e, "wave") ? 0 : !strcmp(e, "edge") ? 1 : !strcmp(e, "thread") ? 2 : -1;
+    if (const char* e = getenv("DDMI_TP_APPLY")) {
+      h->m.tp_form = !strcmp(e, "wave") ? 0 : !strcmp(e, "edge") ? 1 : !strcmp(e, "thread") ? 2 : !strcmp(e, "auto") ? -1 : -2;
+      if (h->m.tp_form == -2) { delete h; throw Error(DDMI_ERR_ARG, std::string("DDMI_TP_APPLY: unknown form '") + e + "' (wave | edge | thread | auto)"); }
+    }
     if (const char* e = getenv("DDMI_FUSED_DENSE")) h->m.fused_dense = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_YS")) h->m.fused_ysplit = std::max(0, atoi(e));
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));
@@ -197,16 +200,20 @@ int ddmi_wigner_3j(int l1, int l2, int l3, double* out) {
 int ddmi_debug_philox(const uint32_t* counters, const uint32_t* keys, int n, uint32_t* host_out) {
   return guard([&] {
     DDMI_REQUIRE(counters && keys && host_out && n > 0, DDMI_ERR_ARG, "null argument");
-    unsigned *c = nullptr, *k = nullptr, *o = nullptr;
-    DDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&c), (size_t)n * 16));
-    DDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&k), (size_t)n * 8));
-    DDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&o), (size_t)n * 16));
-    DDMI_CHECK_HIP(hipMemcpy(c, counters, (size_t)n * 16, hipMemcpyHostToDevice));
-    DDMI_CHECK_HIP(hipMemcpy(k, keys, (size_t)n * 8, hipMemcpyHostToDevice));
-    launch_debug_philox(c, k, n, o, nullptr);
-    DDMI_CHECK_HIP(hipDeviceSynchronize());
-    DDMI_CHECK_HIP(hipMemcpy(host_out, o, (size_t)n * 16, hipMemcpyDeviceToHost));
-    (void)hipFree(c); (void)hipFree(k); (void)hipFree(o);
+    struct Buf {   // freed on every exit path, also when a later call throws
+      unsigned* p = nullptr;
+      explicit Buf(size_t bytes) { DDMI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&p), bytes)); }
+      ~Buf() { if (p) (void)hipFree(p); }
+    };
+    Buf c((size_t)n * 16), k((size_t)n * 8), o((size_t)n * 16);
+    hipStream_t st = nullptr;
+    DDMI_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{st};
+    DDMI_CHECK_HIP(hipMemcpyAsync(c.p, counters, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    DDMI_CHECK_HIP(hipMemcpyAsync(k.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    launch_debug_philox(c.p, k.p, n, o.p, st);
+    DDMI_CHECK_HIP(hipMemcpyAsync(host_out, o.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
+    DDMI_CHECK_HIP(hipStreamSynchronize(st));
   });
 }
 

@@ -45,7 +45,10 @@ struct Model::Cx {
   // rebuilt when the edge list they were built for changes (once per forward), and the hidden-row scratch
   struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr, *ne = nullptr;
                  float* rows = nullptr;   // per-edge rows of k_conv_fused (k_vn_rows)
-                 const int* built_goff = nullptr; long epoch = -1; };
+                 // what the lists and per-edge rows were built from (k_vn_rows bakes target slots, attribute rows, harmonics with
+                 // their sign and edge weights in): a group that reuses a list id with any other input rebuilds it
+                 const int *built_goff = nullptr, *built_tgt = nullptr, *built_tslot = nullptr, *built_arow = nullptr;
+                 const float *built_nvec = nullptr, *built_ew = nullptr; float built_sgn = 0.f; int built_tbase = -1; long epoch = -1; };
   VnSet vn[9];           // + 2 = ligand-ligand, 3 = rec<-lig (ligand gather nodes); all_atoms: 4 la, 5 ra, 6 aa, 7 al, 8 ar
   // ---- all_atoms (models/aa_model.py): receptor heavy atoms = third node type, node rows [nL + nR, N)
   int nA = 0, maxNa = 0, Eaa = 0, Ear = 0, Ela_cap = 0;
@@ -236,14 +239,16 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     }
     {
       Cx::VnSet& vs = c.vn[g.vn];
-      if (vs.built_goff != g.goff || vs.epoch != c.epoch) {
+      if (vs.built_goff != g.goff || vs.epoch != c.epoch || vs.built_tgt != g.tgt || vs.built_tslot != g.tslot || vs.built_arow != g.arow ||
+          vs.built_nvec != g.nvec || vs.built_ew != g.ew || vs.built_sgn != g.sgn || vs.built_tbase != g.tbase) {
         PhaseTimer t(m, "vn_build", gs);
         VnRowsArgs vr{};
         vr.arow = g.arow; vr.nvec = g.nvec; vr.ew = g.ew; vr.tslot = g.tslot; vr.sgn = g.sgn; vr.sh_lmax = m.cfg.sh_lmax;
         vr.tgt = g.tgt; vr.tbase = g.tbase;
         vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
         launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs);
-        vs.built_goff = g.goff; vs.epoch = c.epoch;
+        vs.built_goff = g.goff; vs.epoch = c.epoch; vs.built_tgt = g.tgt; vs.built_tslot = g.tslot; vs.built_arow = g.arow;
+        vs.built_nvec = g.nvec; vs.built_ew = g.ew; vs.built_sgn = g.sgn; vs.built_tbase = g.tbase;
       }
       const int* nvn = vs.voff + g.gcount;
       // dense-row loop: groups with >= 20 edges per gather node (both row tiles of every virtual node are multiplied)

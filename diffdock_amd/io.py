@@ -34,18 +34,22 @@ _Z = {e.upper(): i + 1 for i, e in enumerate(_ELEMENTS)}
 BOND_TYPES = {1: 0, 2: 1, 3: 2, 4: 3}     # SDF bond order -> index in {SINGLE, DOUBLE, TRIPLE, AROMATIC} (process_mols.py:21)
 
 
-# modified residues that ProDy's protein selection keeps although they are written as HETATM records
+# Modified residues that ProDy's `protein` selection keeps although they are written as HETATM records.  LIMITATION: this is a
+# hand-picked subset of ProDy's non-standard amino-acid table (not importable here); a file with another modified residue
+# (MLZ, M3L, CSX, OCS, ...) yields FEWER residues than the reference pipeline, which would shift the language-model
+# embedding alignment -- the length check of `complex_graph` (language-model rows vs residues) raises in that case instead of
+# misaligning.  Pass ProDy's list through `extra_het_residues` of the readers when such files appear.
 _HET_RESIDUES = {"MSE", "SEP", "TPO", "PTR", "CSO", "HYP", "MLY", "KCX", "CME", "CSD", "SEC", "PYL"}
 
 
-def _pdb_residues(path):
+def _pdb_residues(path, extra_het_residues=()):
     """Residues with a CA atom, in file order: {name, chain, N, CA, C}; alternate locations other than ' ' / 'A' are
     skipped; HETATM records count only for the modified amino acids ProDy's `protein` selection keeps (MSE, SEP, ...)."""
     res, order = {}, []
     with open(path) as f:
         for line in f:
             het = line.startswith("HETATM")
-            if not (line.startswith("ATOM") or (het and line[17:20].strip() in _HET_RESIDUES)):
+            if not (line.startswith("ATOM") or (het and (line[17:20].strip() in _HET_RESIDUES or line[17:20].strip() in extra_het_residues))):
                 continue
             atom = line[12:16].strip()
             if atom not in ("N", "CA", "C") or line[16] not in (" ", "A"):
@@ -58,10 +62,10 @@ def _pdb_residues(path):
     return [res[k] for k in order if "CA" in res[k]]
 
 
-def read_pdb_calpha(path):
+def read_pdb_calpha(path, extra_het_residues=()):
     """-> (coords float64 [n,3], residue type index int64 [n], chain ids list[str]) for every residue with a CA atom, in
     file order."""
-    rs = _pdb_residues(path)
+    rs = _pdb_residues(path, extra_het_residues)
     # the reference goes through one-letter codes (pdb.ca.getSequence -> aa_short2long): anything ProDy does not map
     # to one of the 20 letters becomes 'misc'
     types = [POSSIBLE_AMINO_ACIDS.index(r["name"]) if r["name"] in _STANDARD else len(POSSIBLE_AMINO_ACIDS) - 1 for r in rs]
@@ -69,9 +73,9 @@ def read_pdb_calpha(path):
             [r["chain"] for r in rs])
 
 
-def read_pdb_backbone(path):
+def read_pdb_backbone(path, extra_het_residues=()):
     """-> (N / CA / C coordinates float64 [n, 3, 3] (nan where an atom is missing), residue names) of the same residues."""
-    rs = _pdb_residues(path)
+    rs = _pdb_residues(path, extra_het_residues)
     nan = [float("nan")] * 3
     return np.asarray([[r.get("N", nan), r["CA"], r.get("C", nan)] for r in rs], dtype=np.float64).reshape(-1, 3, 3), [r["name"] for r in rs]
 

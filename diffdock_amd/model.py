@@ -35,6 +35,19 @@ def time_frequencies(sigma_embed_dim: int) -> torch.Tensor:
     return torch.exp(torch.arange(half, dtype=torch.float32) * -emb)
 
 
+def _mask_fingerprint(mr):
+    import hashlib
+    import numpy as np
+    if mr is None:
+        return None
+    h = hashlib.sha1()
+    for a in (mr if isinstance(mr, (list, tuple)) else [mr]):
+        a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+        h.update(str(a.shape).encode())
+        h.update(np.ascontiguousarray(a).view(np.uint8).tobytes() if a.size else b"")
+    return h.hexdigest()
+
+
 class MIScoreModel:
     def __init__(self, cfg: ModelConfig, device="cuda:0", lib_path: str | None = None):
         self.cfg = cfg
@@ -140,8 +153,9 @@ class MIScoreModel:
         static = self._static_tensors(data)
         # (tensors created under torch.inference_mode() carry no version counter: their slot of the key is 0)
         key = tuple((t.data_ptr(), 0 if t.is_inference() else t._version, tuple(t.shape)) for t in static) + (int(data.num_graphs),)
-        mr_obj = getattr(lig, "mask_rotate", None) if hasattr(lig, "mask_rotate") else None
-        key = key + (id(mr_obj), len(mr_obj) if hasattr(mr_obj, "__len__") else -1)    # rotatable-bond masks: identity + length
+        # rotatable-bond masks (numpy arrays / tensors, possibly a list per graph): keyed by CONTENT -- an id() can be recycled
+        # after the old list is collected, and in-place edits leave it unchanged
+        key = key + (_mask_fingerprint(getattr(lig, "mask_rotate", None)),)
         same_obj = self._complex_ref is not None and self._complex_ref() is data
         if same_obj and key == self._complex_key:
             return

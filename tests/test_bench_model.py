@@ -56,6 +56,21 @@ def test_committed_traffic_record_is_what_bench_reads():
     assert 1e8 < rec["bytes_per_launch"] < 1e10 and rec["source"].startswith("profiles/")
 
 
+def test_traffic_record_of_another_kernel_source_is_not_replayed(tmp_path):
+    """roofline.traffic is replayed from a committed counter record: only when the record names the k_conv.hip in the tree."""
+    import hashlib
+    b = load_bench()
+    src = tmp_path / "k.hip"
+    src.write_text("kernel v1")
+    rec = {"bytes_per_launch": 1.0e9, "source": "profiles/x.txt", "l2_hit_rate": 0.5,
+           "kernel_source_sha256": hashlib.sha256(b"kernel v1").hexdigest()}
+    assert b.traffic_from_record(rec, str(src)) == (1.0e9, "profiles/x.txt", 0.5)
+    src.write_text("kernel v2")
+    t, note, hit = b.traffic_from_record(rec, str(src))
+    assert t is None and hit is None and note.startswith("stale")
+    assert b.traffic_from_record({k: v for k, v in rec.items() if k != "kernel_source_sha256"}, str(src))[0] is None
+
+
 def test_roofline_constants_match_the_microarchitecture_guide():
     b = load_bench()
     assert b.MFMA_F32_PEAK_TFLOPS == 157.3 and b.HBM_PEAK_GBS == 8000.0

@@ -3,7 +3,9 @@
 usage: traffic_json.py fetch.db write.db <kernel-substring> <config> <source-note> [l2.db] > traffic.json
 bytes = FETCH_SIZE[KB] * 1024 * 2 (gfx950: FETCH_SIZE counts half of a wide coalesced stream, MI355X_MICROARCH.md HBM section)
       + WRITE_SIZE[KB] * 1024, launch-weighted mean over all dispatches of the kernel; l2_hit_rate = TCC_HIT / (TCC_HIT + TCC_MISS)."""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
 
@@ -25,6 +27,10 @@ out = {"kernel": sub, "config": config, "launches": n, "fetch_size_kb_per_launch
        "source": note,
        "corrections": "FETCH_SIZE doubled (gfx950 counts half of a wide coalesced read); WRITE_SIZE uncalibrated; counters come "
                       "from the L2's fabric side, so Infinity-Cache hits are included"}
+# the kernel source the counters were collected on: bench.py refuses to replay the record next to a different k_conv.hip
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffdock_amd", "csrc", "k_conv.hip")
+out["kernel_source"] = "diffdock_amd/csrc/k_conv.hip"
+out["kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
 if len(sys.argv) > 6:
     _, hit = counter(sys.argv[6], "TCC_HIT_sum", sub)
     _, miss = counter(sys.argv[6], "TCC_MISS_sum", sub)
