@@ -211,6 +211,9 @@ def main():
                     help="skip the extra one-stream pass behind roofline.serialised (kernel-trace profiles: one launch regime only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lib", default=None, help="path of an alternative libddmi build (kernel A/B experiments)")
+    ap.add_argument("--edge-product", default="f32", choices=["f32", "bf16x4"],
+                    help="arithmetic of the per-edge product of the interaction layers (ddmi_config.edge_product): f32 = exact fp32 chain "
+                         "(the headline), bf16x4 = split-bf16 operands on the bf16 matrix pipe, fp32 accumulation (secondary line, its own dtype)")
     ap.add_argument("--all-atoms", action="store_true",
                     help="secondary workload: the all-atom score model (models/aa_model.py), ~7.5 receptor atoms per residue")
     args = ap.parse_args()
@@ -233,6 +236,8 @@ def main():
     cfg = bench_cfg()
     if args.all_atoms:
         cfg = cfg.replace(all_atoms=True)
+    if args.edge_product != "f32":
+        cfg = cfg.replace(edge_product=args.edge_product)
     sd = init_state_dict(cfg, seed=1234)
     so3_t, tor_t = default_tables()
     S = args.samples or wl["samples"]              # poses per complex
@@ -358,7 +363,7 @@ def main():
             wall_ach = conv_flops_fwd * n_forwards_timed / dt / 1e12                         # TFLOP/s over the timed region
             fwd_ms = timings.get("forward_total", (0.0, 0))[0] / max(n_forwards, 1)
             streams = 1 if os.environ.get("DDMI_STREAMS") == "1" else 2
-            roof = {"kernel": dom, "bound": "mfma", "achieved": wall_ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            roof = {"kernel": dom, "bound": "mfma", "edge_product": args.edge_product, "achieved": wall_ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": wall_ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                     "frac_definition": "algorithmic flops of this kernel in every forward of the timed region / wall clock of the timed "
                                        "region (all kernels, both streams) / dense f32 MFMA peak",
@@ -439,7 +444,11 @@ def main():
             "value": total_poses * args.steps / dt,
             "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.edge_product == "f32" else
+                     "bf16x4-split edge product (operands as bf16 hi + bf16 lo, the four bf16 products of every f32 product on "
+                     "v_mfma_f32_16x16x32_bf16, f32 accumulate); node contraction and everything else f32 -- SECONDARY line, the headline is dtype f32",
+            "data": "synthetic",
             "config": {"workload": f"{wl['label']}: DDL-synth score model (ns=48 nv=10 6 layers sh_lmax=1), "
                                    f"{INFERENCE_STEPS} steps x {S} poses per complex, {shape}, cross graph pinned at its upper bound "
                                    f"(static 80 A cutoff), low-temperature SDE, random-init weights",

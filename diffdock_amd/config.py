@@ -76,6 +76,9 @@ class ModelConfig:
     # confidence checkpoint is (`old_confidence_model: true`).  Score and confidence mode; always sh_lmax = 2, one confidence output.
     old: bool = False
     use_old_atom_encoder: bool = True
+    # execution option (ddmi_config.edge_product, not a reference argument): arithmetic of the per-edge product of the
+    # interaction layers -- "f32" (exact fp32 chain, default) | "bf16x4" (split-bf16 operands, fp32 accumulation)
+    edge_product: str = "f32"
 
     # ------------------------------------------------------------------ derived
     @property

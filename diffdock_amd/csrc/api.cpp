@@ -28,6 +28,11 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     h->m.cfg = *cfg;
     h->m.device = device;
     try { build_weight_spec(h->m); } catch (...) { delete h; throw; }
+    if (const char* e = getenv("DDMI_EDGE_PRODUCT")) {
+      h->m.cfg.edge_product = !strcmp(e, "f32") ? 0 : !strcmp(e, "bf16x4") ? 1 : -1;
+      if (h->m.cfg.edge_product < 0) { delete h; throw Error(DDMI_ERR_ARG, std::string("DDMI_EDGE_PRODUCT: unknown route '") + e + "' (f32 | bf16x4)"); }
+    }
+    if (h->m.cfg.edge_product < 0 || h->m.cfg.edge_product > 1) { delete h; throw Error(DDMI_ERR_ARG, "ddmi_config.edge_product: 0 (f32) or 1 (bf16x4)"); }
     if (const char* e = getenv("DDMI_STREAMS")) h->m.two_streams = atoi(e) != 1;
     if (const char* e = getenv("DDMI_FUSED_PACK")) h->m.fused_pack = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_TRI")) h->m.fused_tri = atoi(e) != 0;

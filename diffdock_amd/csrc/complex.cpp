@@ -252,13 +252,15 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       }
       const int* nvn = vs.voff + g.gcount;
       // dense-row loop: groups with >= 20 edges per gather node (both row tiles of every virtual node are multiplied)
+      // split-bf16 edge product (ddmi_config.edge_product = 1): the static l <= 1 loops only; other layers keep the f32 route
+      const bool bf = m.cfg.edge_product == 1 && !L.fgran_generic && L.maxd <= 3 && m.cfg.sh_lmax <= 1;
       const bool dense_rows = m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount));
       if (fuse_mm) {
         PhaseTimer t(m, "k_edge_hidden", gs);
         EdgeHiddenArgs h{};
         h.nvn = nvn; h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
         h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = L.W1p[wg]; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
-        h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb;
+        h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb; h.bf = bf ? 1 : 0;
         h.zero_fill = (!L.fgran_generic && dense_rows) ? 1 : 0;
         if (m.cfg.sh_lmax <= 1) { h.vrows = vs.rows; h.vn_ne = vs.ne; }
         launch_edge_hidden_mm(h, gs);
@@ -272,10 +274,10 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
           gemm(cur, H, L.Wmid[wg][j], H, L.bmid[wg][j], nxt, H, g.ea_rows, H, H, 1, gs, g.ea_rows_dev);
           std::swap(cur, nxt);
         }
-        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, nullptr, g.tgt, g.tbase, cur, nullptr, nullptr, H, L.HKq / 8, Hb, gs);
+        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, nullptr, g.tgt, g.tbase, cur, nullptr, nullptr, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
       } else {
         PhaseTimer t(m, "k_edge_hidden", gs);
-        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs);
+        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
       }
       FusedConvArgs f{};
       f.nvn = nvn; f.vcap = vs.vcap; f.vn_node = vs.node; f.vrows = vs.rows; f.vn_ne = vs.ne;
@@ -283,6 +285,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.cgt = L.cgt;
       f.max_nb = L.max_nb; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
       f.dense = dense_rows ? 1 : 0;
+      f.bf = bf ? 1 : 0;
       // ligand gather nodes with >= 2 virtual nodes on average (rec<-lig): a tile of 16 virtual nodes holds few distinct nodes
       f.shared = (dense_rows && (m.fused_shared == 2 || (m.fused_shared == 1 && g.load && (long)g.ea_rows >= 48L * std::max(1, g.gcount)))) ? 1 : 0;
       f.prof_slot = (int)gi;

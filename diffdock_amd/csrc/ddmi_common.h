@@ -108,6 +108,65 @@ struct Error : std::runtime_error {
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 
+// ---- split-bf16 edge product (ddmi_config.edge_product = 1).  A float v is carried as ONE 32-bit word: bf16(v) in the upper
+// half, bf16(v - bf16(v)) in the lower half (both round-to-nearest-even: 16 significand bits, |error| <= 2^-17 |v|).  With
+// a = ah + al and b = bh + bl the four products ah*bh + al*bh + ah*bl + al*bl fill four K slots of v_mfma_f32_16x16x32_bf16
+// (products exact, f32 accumulation): A registers (wa, wa), B registers (bh|bh, bl|bl) per k, so one instruction multiplies an
+// 8-row k chunk (two k per lane group) -- the work of two v_mfma_f32_16x16x4_f32 (64 cycles) in 16.
+#ifdef DDMI_HIPEMU
+typedef u32x4_emu u32x4;
+static inline unsigned bf_rne16(float f) {   // bf16 bits of f, round to nearest even (finite inputs)
+  unsigned u; memcpy(&u, &f, 4);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static inline unsigned bf_pk(float a, float b) { return (bf_rne16(a) & 0xffffu) | (bf_rne16(b) << 16); }
+static inline unsigned bf_perm(unsigned s0, unsigned s1, unsigned sel) {
+  const unsigned long long v = ((unsigned long long)s0 << 32) | s1;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) { const unsigned b = (sel >> (8 * i)) & 0xffu; r |= (b < 8 ? (unsigned)((v >> (8 * b)) & 0xffu) : 0u) << (8 * i); }
+  return r;
+}
+static inline f32x4 bf_mfma_raw(u32x4 a, u32x4 b, f32x4 c) { return hipemu_mfma_f32_16x16x32_bf16(a, b, c); }
+static inline float bf_sub(float a, float b) { return a - b; }
+#else
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 ddmi_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ddmi_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float ddmi_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf_pk(float a, float b) {   // v_cvt_pk_bf16_f32: (bf16(a) | bf16(b) << 16)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(ddmi_f32x2{a, b}, ddmi_bf16x2));
+}
+__device__ __forceinline__ unsigned bf_perm(unsigned s0, unsigned s1, unsigned sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+__device__ __forceinline__ f32x4 bf_mfma_raw(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ddmi_bf16x8, a), __builtin_bit_cast(ddmi_bf16x8, b), c, 0, 0, 0);
+}
+// a - b as ONE v_sub_f32: left to itself the compiler pairs the subtractions of a split into v_pk_add_f32 (plus the register
+// copies that pair the operands), which costs issue slots next to MFMAs (MI355X_MICROARCH.md: packed f32 VALU is an anti-lever)
+__device__ __forceinline__ float bf_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#endif
+__device__ __forceinline__ float bf_word_f(unsigned w) { return __uint_as_float(w); }
+__device__ __forceinline__ unsigned bf_f_word(float f) { return __float_as_uint(f); }
+// packed words of two / one float(s)
+__device__ __forceinline__ void bf_split2(float v1, float v2, float& w1, float& w2) {
+  const unsigned hp = bf_pk(v1, v2);
+  const unsigned h1 = hp << 16, h2 = hp & 0xffff0000u;
+  const unsigned lp = bf_pk(bf_sub(v1, bf_word_f(h1)), bf_sub(v2, bf_word_f(h2)));
+  w1 = bf_word_f((lp & 0xffffu) | h1);
+  w2 = bf_word_f(bf_perm(hp, lp, 0x07060302u));   // bytes [hp.3, hp.2, lp.3, lp.2]
+}
+__device__ __forceinline__ float bf_split1(float v) {
+  const unsigned h = bf_pk(v, v) << 16;
+  const unsigned lp = bf_pk(bf_sub(v, bf_word_f(h)), 0.f);
+  return bf_word_f((lp & 0xffffu) | h);
+}
+// c += sum over the lane group's two k of a(k) * b(k): wa0, wa1 = packed A words, q0, q1 = packed B words of k0, k1
+__device__ __forceinline__ f32x4 bf_mfma(float wa0, float wa1, float q0, float q1, f32x4 c) {
+  const unsigned a0 = bf_f_word(wa0), a1 = bf_f_word(wa1), b0 = bf_f_word(q0), b1 = bf_f_word(q1);
+  const u32x4 A = {a0, a0, a1, a1};
+  const u32x4 B = {bf_perm(b0, b0, 0x03020302u), bf_perm(b0, b0, 0x01000100u), bf_perm(b1, b1, 0x03020302u), bf_perm(b1, b1, 0x01000100u)};
+  return bf_mfma_raw(A, B, c);
+}
+
 // wave-wide sum (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

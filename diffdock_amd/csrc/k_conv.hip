@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_edge_hidden(const int* __restrict__ nvn
                                                     const int* __restrict__ vn_e0, const int* __restrict__ goff,
                                                     const int* __restrict__ arow, const int* __restrict__ tgt, int tbase,
                                                     const float* __restrict__ HE, const float* __restrict__ P,
-                                                    const float* __restrict__ Q, int H, int NG8, float* __restrict__ Hb) {
+                                                    const float* __restrict__ Q, int H, int NG8, float* __restrict__ Hb, int bf) {
   const int v = blockIdx.x;
   if (v >= *nvn) return;
   const int d = vn_node[v], e0 = vn_e0[v];
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void k_edge_hidden(const int* __restrict__ nvn
         o = x;
       }
     }
+    if (bf) { bf_split2(o.x, o.y, o.x, o.y); bf_split2(o.z, o.w, o.z, o.w); }   // split-bf16 edge product: packed (hi | lo) words
     const int rt = el >> 4, r = el & 15, g = k >> 3, q0 = (k & 7) >> 1;
     *reinterpret_cast<float2*>(Hb + fc_hb_off(v, rt, g, q0 * 16 + r, NGP)) = make_float2(o.x, o.y);
     *reinterpret_cast<float2*>(Hb + fc_hb_off(v, rt, g, (q0 + 1) * 16 + r, NGP)) = make_float2(o.z, o.w);
@@ -262,10 +263,10 @@ void launch_edge_rows(const int* nvn, int vcap, const int* vn_node, const int* v
 }
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                         const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
-                        float* Hb, hipStream_t s) {
+                        float* Hb, hipStream_t s, int bf) {
   if (vcap <= 0) return;
   hipLaunchKernelGGL(k_edge_hidden, dim3(vcap), dim3(256), 0, s, nvn, vn_node, vn_e0, goff, arow, tgt, tbase, HE, P, Q, H,
-                     NG8, Hb);
+                     NG8, Hb, bf);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
         float4 o;
         o.x = live ? fmaxf(acc[0] + acc2[0], 0.f) : 0.f; o.y = live ? fmaxf(acc[1] + acc2[1], 0.f) : 0.f;
         o.z = live ? fmaxf(acc[2] + acc2[2], 0.f) : 0.f; o.w = live ? fmaxf(acc[3] + acc2[3], 0.f) : 0.f;
+        if (a.bf) { bf_split2(o.x, o.y, o.x, o.y); bf_split2(o.z, o.w, o.z, o.w); }   // split-bf16 edge product: packed (hi | lo) words
         *reinterpret_cast<float4*>(hp + (size_t)nb * 256) = o;
       }
     }
@@ -596,7 +598,9 @@ struct FcOrder {   // issue order of the slot chains: slot 0 alternating with th
 #ifndef FC_R0B_ALL
 #define FC_R0B_ALL 1
 #endif
-template <int NBK, int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3, bool SH = false>
+// BF: edge product of a chunk as ONE v_mfma_f32_16x16x32_bf16 per (virtual node, row tile, column block) on split operands
+// (ddmi_common.h, bf_mfma): the hidden rows arrive as packed words, the contracted chunk is stored as packed words.
+template <int NBK, int S0, int SN, bool DENSE, int DUP = 0, int NLV = 3, bool SH = false, bool BF = false>
 __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const FcSlotRt (&sl)[4], const float* __restrict__ wpack,
                                                   int KS, int HK, int NG8, int wave, int lane,
                                                   const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr,
@@ -682,20 +686,35 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   f32x4 r[4];
   // live 16-column blocks of the granule: a (12,-,-,-) granule (one item column) multiplies only block 0 in the edge product
   constexpr int NCB = SN == 0 ? 1 : 1 + NLV, NE = 8 * NCB, NP = SH ? NCB : (SN == 0 || NLV == 1) ? 4 : 8;
-  float q[2][NCB];             // B fragments of the edge product: [parity of the (virtual node, k pair) group][column block]
+  constexpr int NEB = 4 * NCB;   // BF: edge-product MFMAs of a step
+  float q[2][BF ? 2 * NCB : NCB];   // B fragments of the edge product: [parity of the (virtual node, k pair) group][column block]; BF: [virtual node][k0 | k1][column block]
   auto readq = [&](int par, int buf, int grp) __attribute__((always_inline)) {
-    const float* __restrict__ yb = yrd + buf * FC_YB + ynoff[grp >> 1] + (grp & 1) * FC_YROW;
+    if constexpr (BF) {   // grp = virtual node: both k rows of the lane group
+      const float* __restrict__ yb = yrd + buf * FC_YB + ynoff[grp];
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) q[par][c] = yb[16 * c];
+      for (int c = 0; c < NCB; ++c) { q[par][c] = yb[16 * c]; q[par][NCB + c] = yb[FC_YROW + 16 * c]; }
+    } else {
+      const float* __restrict__ yb = yrd + buf * FC_YB + ynoff[grp >> 1] + (grp & 1) * FC_YROW;
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) q[par][c] = yb[16 * c];
+    }
   };
   auto store_piece = [&](int buf, int piece) __attribute__((always_inline)) {   // rows of node quarter `rr`, slots 2h and 2h+1
     float* yw = ywr + buf * FC_YB;
     if constexpr (SH) {   // one chain per piece
-      yw[16 * piece] = rsc(r[piece]);
+      const float v = rsc(r[piece]);
+      yw[16 * piece] = BF ? bf_split1(v) : v;
     } else {
       const int rr = piece & 3, h = piece >> 2;
-      if (2 * h < NCB) yw[rr * FC_YVN + 16 * (2 * h)] = r[2 * h][rr];
-      if (2 * h + 1 < NCB) yw[rr * FC_YVN + 16 * (2 * h + 1)] = r[2 * h + 1][rr];
+      float v0 = 0.f, v1 = 0.f;
+      if (2 * h < NCB) v0 = r[2 * h][rr];
+      if (2 * h + 1 < NCB) v1 = r[2 * h + 1][rr];
+      if constexpr (BF) {
+        if (2 * h + 1 < NCB) bf_split2(v0, v1, v0, v1);
+        else if (2 * h < NCB) v0 = bf_split1(v0);
+      }
+      if (2 * h < NCB) yw[rr * FC_YVN + 16 * (2 * h)] = v0;
+      if (2 * h + 1 < NCB) yw[rr * FC_YVN + 16 * (2 * h + 1)] = v1;
     }
   };
   static_assert(NCB <= NBK, "column blocks of the granule exceed the chunk buffer");
@@ -705,7 +724,12 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+      for (int rt = 0; rt < 2; ++rt) {
+        hC[vi][rt] = hN[vi][rt];
+        // BF: the A tuples {w, w, w', w'} are register copies of these words; without this the compiler places the copies right
+        // behind the requests of hN (an s_waitcnt vmcnt(0) per request in the middle of the edge product: round-4 defect)
+        if constexpr (BF) { DDMI_OPAQUE(hC[vi][rt].x); DDMI_OPAQUE(hC[vi][rt].y); DDMI_OPAQUE(hC[vi][rt].z); DDMI_OPAQUE(hC[vi][rt].w); }
+      }
   };
   // (do_roll: the hidden rows requested during the previous pair become the current ones BEHIND this step's contraction --
   // the copy is where the compiler waits for those slow requests, and the contraction does not need them)
@@ -730,6 +754,31 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       readq(0, eb, 0);
     }
     if constexpr (decltype(do_roll)::value) { roll(); DDMI_SCHED_FENCE(); }
+    if constexpr (BF) {
+      // slot m = (virtual node vi, column block c, row tile rt): the B tuple of (vi, c) serves both row tiles.  Side work per
+      // slot: weight request m (slots 0 .. NL-1), the four hidden-row requests behind them, the row stores from slot 1 on
+      fc_sfor<0, NEB>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int vi = m / (2 * NCB), t8 = m % (2 * NCB), c = t8 >> 1, rt = t8 & 1;
+        if (DENSE || rt == 0 || two[vi]) {
+          const float a0 = ODD ? hC[vi][rt].z : hC[vi][rt].x, a1 = ODD ? hC[vi][rt].w : hC[vi][rt].y;
+          acc[vi][rt][c] = bf_mfma(a0, a1, q[vi][c], q[vi][NCB + c], acc[vi][rt][c]);
+        }
+        if constexpr (DO_W) fc_sfor<0, NL>([&](auto ic) { if constexpr ((decltype(ic)::value < NEB ? decltype(ic)::value : NEB - 1) == m) loadw(ic); });
+        if constexpr (DO_H) {   // (after this step's weight requests: vmcnt retires in order)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (m == (NL + j < NEB - 1 ? NL + j : NEB - 1)) loadh(hN, j);
+        }
+        if constexpr (DO_C) {
+#pragma unroll
+          for (int pc = 0; pc < NP; ++pc)
+            if (m == (1 + pc < NEB - 1 ? 1 + pc : NEB - 1)) store_piece(cb, pc);
+        }
+        if (m == 0) readq(1, eb, 1);
+        DDMI_SCHED_FENCE();
+      });
+    } else {
     static_assert(NE >= 2 * NL && NE >= NP + 2, "edge-product slots for the weight requests and the row stores");
     fc_sfor<0, NE>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
@@ -751,6 +800,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
       DDMI_SCHED_FENCE();
     });
+    }
 #ifndef FCV_SAMEW
     if constexpr (DO_W) {
 #pragma unroll
@@ -907,7 +957,7 @@ struct FcPackOrder {   // issue order of the contraction: the 12-step chain spre
   static constexpr int step(int i) { return is_c0(i) ? rank(i, true) : (rank(i, false) % 9) / 3; }
   static constexpr int last_pos(int t) { int p = 0; for (int i = 0; i < NC; ++i) if (slot(i) == t) p = i; return p; }   // position of slot t's last step
 };
-template <int NBK, int S0, int NG, bool DENSE>
+template <int NBK, int S0, int NG, bool DENSE, bool BF = false>
 __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], const FcPackRt& P, const float* __restrict__ wpack,
                                                    int KS, int HK, int NG8, int wave, int lane,
                                                    const float* __restrict__ hb_tile, const int (&vne)[2], float* ywr0,
@@ -977,15 +1027,23 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
   constexpr int EPP = NEARLY ? (4 * NEARLY + (NC - EARLY0) - 1) / (NC - EARLY0) : 1;   // early stores per contraction position
   static_assert(NEARLY == 0 || (EARLY0 < NC && EPP <= 2), "early stores fit behind their chains");
   constexpr int NE = 8 * NB, NP = 4 * (NS - NEARLY);
-  static_assert(NE >= 2 * NL + 8 && NE >= NP + 2, "edge-product slots for the requests and the row stores");
-  float q[2][NB];
+  constexpr int NEB = 4 * NB, SPS = (NP + NEB - 3) / (NEB - 2);   // BF: edge-product MFMAs of a step, late stores per slot
+  static_assert(BF || (NE >= 2 * NL + 8 && NE >= NP + 2), "edge-product slots for the requests and the row stores");
+  static_assert(NEB >= NL + 5 && NEB >= XW, "BF: edge-product slots for the requests and the x window");
+  float q[2][BF ? 2 * NB : NB];   // (BF: [virtual node][k0 | k1][column block], see fc_mainloop_dense)
   auto readq = [&](int par, int buf, int grp) __attribute__((always_inline)) {
-    const float* __restrict__ yb = yrd + buf * FC_YB + (grp >> 1) * FC_YVN + (grp & 1) * FC_YROW;
+    if constexpr (BF) {
+      const float* __restrict__ yb = yrd + buf * FC_YB + grp * FC_YVN;
 #pragma unroll
-    for (int c = 0; c < NB; ++c) q[par][c] = yb[16 * c];
+      for (int c = 0; c < NB; ++c) { q[par][c] = yb[16 * c]; q[par][NB + c] = yb[FC_YROW + 16 * c]; }
+    } else {
+      const float* __restrict__ yb = yrd + buf * FC_YB + (grp >> 1) * FC_YVN + (grp & 1) * FC_YROW;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) q[par][c] = yb[16 * c];
+    }
   };
   auto store_slot = [&](int buf, int s_, int rr) __attribute__((always_inline)) {   // node quarter rr of slot s_
-    ywr[buf * FC_YB + rr * FC_YVN + cs * s_] = r[s_][rr];
+    ywr[buf * FC_YB + rr * FC_YVN + cs * s_] = BF ? bf_split1(r[s_][rr]) : r[s_][rr];
   };
   // late stores: slot 0 (long chain) and the slots behind the early ones
   auto late_slot = [](int piece) constexpr { const int k = piece >> 2; return (C0 && k == 0) ? 0 : C0 + NEARLY + (k - C0); };
@@ -1009,7 +1067,12 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) hC[vi][rt] = hN[vi][rt];
+      for (int rt = 0; rt < 2; ++rt) {
+        hC[vi][rt] = hN[vi][rt];
+        // BF: the A tuples {w, w, w', w'} are register copies of these words; without this the compiler places the copies right
+        // behind the requests of hN (an s_waitcnt vmcnt(0) per request in the middle of the edge product: round-4 defect)
+        if constexpr (BF) { DDMI_OPAQUE(hC[vi][rt].x); DDMI_OPAQUE(hC[vi][rt].y); DDMI_OPAQUE(hC[vi][rt].z); DDMI_OPAQUE(hC[vi][rt].w); }
+      }
   };
   auto step = [&](auto do_c, auto do_w, auto do_h, auto odd, auto do_roll) __attribute__((always_inline)) {
     constexpr bool DO_C = decltype(do_c)::value, DO_W = decltype(do_w)::value, DO_H = decltype(do_h)::value;
@@ -1026,6 +1089,30 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
       readq(0, eb, 0);
     }
     if constexpr (decltype(do_roll)::value) { roll(); DDMI_SCHED_FENCE(); }   // (see fc_mainloop_dense)
+    if constexpr (BF) {
+      fc_sfor<0, NEB>([&](auto mc) {   // slot m = (virtual node, column block, row tile), see fc_mainloop_dense
+        constexpr int m = decltype(mc)::value;
+        constexpr int vi = m / (2 * NB), t8 = m % (2 * NB), c = t8 >> 1, rt = t8 & 1;
+        if (DENSE || rt == 0 || two[vi]) {
+          const float a0 = ODD ? hC[vi][rt].z : hC[vi][rt].x, a1 = ODD ? hC[vi][rt].w : hC[vi][rt].y;
+          acc[vi][rt][c] = bf_mfma(a0, a1, q[vi][c], q[vi][NB + c], acc[vi][rt][c]);
+        }
+        if constexpr (DO_W) { if constexpr (m < NL) loadw(std::integral_constant<int, m>{}); }
+        if constexpr (DO_H) {   // (after this step's weight requests: vmcnt retires in order)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (m == NL + j) loadh(hN, j);
+        }
+        if constexpr (DO_C) {
+#pragma unroll
+          for (int pc = 0; pc < NP; ++pc)
+            if (m == 2 + pc / SPS) store_slot(cb_, late_slot(pc), pc & 3);
+        }
+        if constexpr (DO_C && m >= NEB - XW) xread(std::integral_constant<int, m - (NEB - XW)>{});   // window of the next contraction
+        if (m == 0) readq(1, eb, 1);
+        DDMI_SCHED_FENCE();
+      });
+    } else {
     fc_sfor<0, NE>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       constexpr int grp = m / (2 * NB), t8 = m % (2 * NB), vi = grp >> 1, sub = grp & 1, rt = t8 / NB, c = t8 % NB;
@@ -1044,6 +1131,7 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
       if (t8 == 1 && grp < 3) readq((grp + 1) & 1, eb, grp + 1);
       DDMI_SCHED_FENCE();
     });
+    }
 #ifndef FCV_SAMEW
     if constexpr (DO_W) {
 #pragma unroll
@@ -1162,8 +1250,9 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
 // every virtual node are multiplied: straight-line chunk body), 4: mode 3 for gather nodes with several virtual nodes each
 // (ligand atoms in the rec<-lig group): the x tile holds the tile's DISTINCT gather nodes and the classic granules contract
 // them on the 4x4x1 MFMA (fc_mainloop_dense<SH>).  NBK = column blocks of the chunk buffer (widest granule).
-template <int MAXD, int SHD, int MODE, int NBK>
+template <int MAXD, int SHD, int MODE, int NBK, bool BF = false>
 __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
+  static_assert(!BF || (MODE != 1 && MAXD == 3 && SHD == 4), "the bf16 edge product exists in the static l <= 1 loops");
   DDMI_DYN_SMEM(float, smem);
   using D = FcDim<NBK>;
   constexpr int FC_YROW = D::YROW, FC_YVN = D::YVN, FC_YB = D::YB;
@@ -1286,7 +1375,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         const FcPackRt P = fc_pack_setup(Gd, xbuf, lr, lq, xr);
         FC_STAMP(pf, 1);
         constexpr bool DN = MODE == 3 || MODE == 4;
-#define FC_MLP(S0_, NG_) fc_mainloop_packed<NBK, S0_, NG_, DN>(acc, P, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr0, yrd, pf, gscr)
+#define FC_MLP(S0_, NG_) fc_mainloop_packed<NBK, S0_, NG_, DN, BF>(acc, P, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr0, yrd, pf, gscr)
         if constexpr (NBK >= 5) { if (Gd.shape == 4) FC_MLP(12, 2); }
         if (Gd.shape == 5) FC_MLP(0, 2);
         else if (Gd.shape == 6) FC_MLP(12, 1);
@@ -1302,8 +1391,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         FC_STAMP(pf, 1);
 #define FC_ML(S0_, SN_, DUP_, NLV_)                                                                                                  \
   do {                                                                                                                                \
-    if (SHM && sh_tile) fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_, SHM>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr_sh, yrd_sh, pf, gscr, dsl); \
-    else fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_, false>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd, pf, gscr, dsl); \
+    if (SHM && sh_tile) fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_, SHM, BF>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr_sh, yrd_sh, pf, gscr, dsl); \
+    else fc_mainloop_dense<NBK, S0_, SN_, DN, DUP_, NLV_, false, BF>(acc, sl, a.wpack, a.KS, a.HK, NG8, wave, lane, hb_tile, vne, ywr, yrd, pf, gscr, dsl); \
   } while (0)
         int dup, nlv;
         fc_variant(Gd, dup, nlv);
@@ -1572,7 +1661,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 #endif
 }
 
-template <int MAXD, int SHD, int MODE, int NBK>
+template <int MAXD, int SHD, int MODE, int NBK, bool BF = false>
 static void launch_conv_fused_k(const FusedConvArgs& a, hipStream_t s) {
   constexpr bool PACK = MODE != 1 && MAXD == 3 && SHD == 4;
   constexpr int GS2 = PACK ? 8 * MAXD + 12 : 4 * MAXD + 8, ES = SHD == 4 ? 8 : SHD + 3, CGN = FC_MAXSLOT * MAXD * SHD;
@@ -1583,11 +1672,11 @@ static void launch_conv_fused_k(const FusedConvArgs& a, hipStream_t s) {
   if (smem > 160 * 1024) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: LDS budget exceeded (raise DDMI_FUSED_YS)");
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per instantiation)
   if (!lds_opt_in) {
-    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, MODE, NBK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, MODE, NBK, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     lds_opt_in = true;
   }
   dim3 grid(cdiv(a.vcap, FC_VN), a.ysplit);
-  hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, MODE, NBK>), grid, dim3(64 * FC_WAVES), smem, s, a);
+  hipLaunchKernelGGL((k_conv_fused<MAXD, SHD, MODE, NBK, BF>), grid, dim3(64 * FC_WAVES), smem, s, a);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -1598,8 +1687,17 @@ void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
   // the predicated variant (MODE 1) walks classic 4-slot granules only: a packed / merged granule there would be mis-read
   if (a.generic && a.max_nb > 4) throw Error(DDMI_ERR_ARG, "k_conv_fused: packed granule in a generic layer (weights.cpp builds those layers unpacked)");
   if (a.maxd <= 3 && a.sh_lmax <= 1) {   // the l <= 1 tensor product (FasterTensorProduct structure): static chain shapes, packed granules
+    if (a.bf && a.generic) throw Error(DDMI_ERR_ARG, "k_conv_fused: bf16 edge product requested for a generic layer (complex.cpp falls back to f32 there)");
     if (a.generic) launch_conv_fused_k<3, 4, 1, 4>(a, s);
-    else if (a.max_nb > 4) {
+    else if (a.bf && a.max_nb > 4) {
+      if (a.dense && a.shared) launch_conv_fused_k<3, 4, 4, 5, true>(a, s);
+      else if (a.dense) launch_conv_fused_k<3, 4, 3, 5, true>(a, s);
+      else launch_conv_fused_k<3, 4, 0, 5, true>(a, s);
+    } else if (a.bf) {
+      if (a.dense && a.shared) launch_conv_fused_k<3, 4, 4, 4, true>(a, s);
+      else if (a.dense) launch_conv_fused_k<3, 4, 3, 4, true>(a, s);
+      else launch_conv_fused_k<3, 4, 0, 4, true>(a, s);
+    } else if (a.max_nb > 4) {
       if (a.dense && a.shared) launch_conv_fused_k<3, 4, 4, 5>(a, s);
       else if (a.dense) launch_conv_fused_k<3, 4, 3, 5>(a, s);
       else launch_conv_fused_k<3, 4, 0, 5>(a, s);
@@ -1608,6 +1706,8 @@ void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
       else if (a.dense) launch_conv_fused_k<3, 4, 3, 4>(a, s);
       else launch_conv_fused_k<3, 4, 0, 4>(a, s);
     }
+  } else if (a.bf) {
+    throw Error(DDMI_ERR_ARG, "k_conv_fused: bf16 edge product requested with sh_lmax > 1 (complex.cpp falls back to f32 there)");
   } else if (a.maxd <= 3) {
     if (a.generic) launch_conv_fused_k<3, 9, 1, 4>(a, s);
     else if (a.dense) launch_conv_fused_k<3, 9, 3, 4>(a, s);

@@ -83,7 +83,7 @@ void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* 
                      hipStream_t s);
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                         const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
-                        float* Hb, hipStream_t s);   // P == Q == nullptr: HE[arow ? arow[e] : e] is the finished hidden row
+                        float* Hb, hipStream_t s, int bf = 0);   // P == Q == nullptr: HE[arow ? arow[e] : e] is the finished hidden row; bf: packed split-bf16 words
 void launch_edge_rows(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                       const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, float* rows, hipStream_t s);
 // Hidden rows of the edge MLP from the edge attributes in one pass (ns % 16 == 0): first Linear split over its inputs,
@@ -102,6 +102,7 @@ struct EdgeHiddenArgs {
   int zero_fill;   // write zero fragments for empty row tiles (the dense-row loop multiplies them; the other loops skip them)
   const float* vrows; const int* vn_ne;   // l <= 1: per-edge rows of k_vn_rows (words 6, 7 = attribute row, target row) and edge counts; nullptr = index chain
   float* Hb;
+  int bf;          // hidden values as packed split-bf16 words (ddmi_common.h: bf_split2) for the bf16 edge product of k_conv_fused
 };
 void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s);
 
@@ -123,6 +124,7 @@ struct FusedConvArgs {
   int n_units; short ustart[48];         // first granule of every (output block, w tile) unit: workgroups rotate their visiting order by units
   short ufirst[8], ucount[8];            // units of granule range y: ustart[ufirst[y] .. + ucount[y])
   float* msg;                            // [E][XS]
+  int bf = 0;                            // edge product on v_mfma_f32_16x16x32_bf16 with split operands (Hb holds packed words); static l <= 1 loops only
   int dbg = 0;
   int prof_slot = 0;                     // profiling builds: edge-group slot of the in-kernel phase clocks
 };

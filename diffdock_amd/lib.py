@@ -21,6 +21,9 @@ class DdmiError(RuntimeError):
     pass
 
 
+EDGE_PRODUCTS = {"f32": 0, "bf16x4": 1}   # ddmi_config.edge_product (include/ddmi.h)
+
+
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("ns", "nv", "num_conv_layers", "num_prot_emb_layers", "sh_lmax",
                                          "sigma_embed_dim", "distance_embed_dim", "cross_distance_embed_dim",
@@ -33,7 +36,8 @@ class Config(C.Structure):
                                          "rot_sigma_max", "tor_sigma_min", "tor_sigma_max")] + \
                [("all_atoms", C.c_int32), ("confidence_mode", C.c_int32), ("num_confidence_outputs", C.c_int32),
                 ("old_model", C.c_int32), ("atom_confidence", C.c_int32), ("atom_num_confidence_outputs", C.c_int32),
-                ("affinity_prediction", C.c_int32), ("embedding_type", C.c_int32), ("tp_weights_layers", C.c_int32)]
+                ("affinity_prediction", C.c_int32), ("embedding_type", C.c_int32), ("tp_weights_layers", C.c_int32),
+                ("edge_product", C.c_int32)]
 
 
 class Complex(C.Structure):
@@ -62,6 +66,8 @@ def make_config(cfg) -> Config:
             c.old_model = int(cfg.old)
         elif name == "embedding_type":
             c.embedding_type = {"sinusoidal": 0, "fourier": 1}[cfg.embedding_type]
+        elif name == "edge_product":
+            c.edge_product = EDGE_PRODUCTS[cfg.edge_product]
         else:
             setattr(c, name, getattr(cfg, name))
     return c

@@ -70,6 +70,15 @@ typedef struct ddmi_config {
   /* FCBlock depth of the per-edge weight MLP of the embedding / interaction layers (models/layers.py:10-17,
    * tensor_layers.py:302-304): 2 (or 0) = Linear, ReLU, Linear; n > 2 adds n - 2 hidden Linear + ReLU (keys fc.3 .. fc.3(n-1)) */
   int32_t tp_weights_layers;
+  /* ---- execution options (not arguments of the reference's get_model; 0 = default).
+   * edge_product: arithmetic of the per-edge product T_e = h_e . Y_d in the interaction layers (k_conv_fused):
+   *   0 = v_mfma_f32_16x16x4_f32, an exact fp32 fma chain (the headline route);
+   *   1 = split-bf16: both operands carried as bf16 hi + bf16 lo (16 significand bits), the four bf16 products of every
+   *       f32 product on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- a quarter of the matrix-core time of route 0;
+   *       applies to the static l <= 1 loops (sh_lmax = 1, ns % 16 == 0), other layers run route 0.  Same 1e-4 parity bar,
+   *       reported as its own bench line (dtype "bf16x4-split edge product, f32 accumulate").
+   * The environment variable DDMI_EDGE_PRODUCT (f32 | bf16x4) overrides the field at ddmi_create (test harness). */
+  int32_t edge_product;
 } ddmi_config;
 
 /* Static description of one collated batch of complexes = the fields of the PyG Batch the

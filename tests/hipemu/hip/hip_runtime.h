@@ -48,6 +48,7 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef float f32x4_emu __attribute__((ext_vector_type(4)));
 typedef float f32x16_emu __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_emu __attribute__((ext_vector_type(4)));
 
 // ---- runtime API subset --------------------------------------------------------------
 typedef int hipError_t;
@@ -102,6 +103,7 @@ int __shfl_down(int v, unsigned delta, int width = 64);
 int __shfl(int v, int lane, int width = 64);
 f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_emu c, int, int, int);
 f32x4_emu __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, f32x4_emu c, int, int, int);
+f32x4_emu hipemu_mfma_f32_16x16x32_bf16(u32x4_emu a, u32x4_emu b, f32x4_emu c);
 unsigned long long __ballot(int pred);
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int);

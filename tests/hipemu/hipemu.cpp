@@ -29,6 +29,7 @@ struct Wave {
   unsigned gen = 0;
   int alive = 0;
   float fa[64], fb[64];
+  unsigned ua[64][4], ub[64][4];   // 8 bf16 per lane (v_mfma_f32_16x16x32_bf16)
   int ia[64];
 };
 std::vector<Wave> waves;
@@ -191,6 +192,32 @@ f32x4_emu __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, f32x4_emu c, int,
   w.fb[l] = b;
   wave_sync();
   for (int i = 0; i < 4; ++i) c[i] = fmaf(w.fa[(l & ~3) + i], w.fb[l], c[i]);
+  wave_sync();
+  threadIdx = fibers[cur].tid;
+  return c;
+}
+
+// v_mfma_f32_16x16x32_bf16: lane l holds row (A) / column (B) l & 15 and the eight K slots 8 (l >> 4) .. + 7 (two bf16 per
+// register, element 2i in the low half of register i); products exact in f32, accumulated in f32 (the order of the hardware's
+// internal sum is not modelled: the tests compare at a tolerance)
+static inline float bf16_bits(unsigned h) { unsigned u = h << 16; float f; memcpy(&f, &u, 4); return f; }
+f32x4_emu hipemu_mfma_f32_16x16x32_bf16(u32x4_emu a, u32x4_emu b, f32x4_emu c) {
+  Wave& w = waves[cur / 64];
+  int l = lane();
+  for (int i = 0; i < 4; ++i) { w.ua[l][i] = a[i]; w.ub[l][i] = b[i]; }
+  wave_sync();
+  int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * (l >> 4) + r;
+    float acc = c[r];
+    for (int g = 0; g < 4; ++g)
+      for (int i = 0; i < 4; ++i) {
+        const unsigned ar = w.ua[row + 16 * g][i], br = w.ub[col + 16 * g][i];
+        acc += bf16_bits(ar & 0xffffu) * bf16_bits(br & 0xffffu);
+        acc += bf16_bits(ar >> 16) * bf16_bits(br >> 16);
+      }
+    c[r] = acc;
+  }
   wave_sync();
   threadIdx = fibers[cur].tid;
   return c;

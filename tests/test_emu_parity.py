@@ -343,6 +343,37 @@ def test_shared_node_contraction_matches_oracle(emu_lib, monkeypatch):
             assert rel_err(a_, b_) < 1e-5
 
 
+def test_split_bf16_edge_product_matches_f32_route_and_oracle(emu_lib, monkeypatch):
+    """ddmi_config.edge_product = 1 ("bf16x4"): the per-edge product of the static l <= 1 loops on v_mfma_f32_16x16x32_bf16 with
+    both operands split into bf16 hi + bf16 lo (hidden rows and contracted chunks as packed words, four bf16 products per f32
+    product, f32 accumulation).  DDL-synth widths, four layers (classic, merged and packed granules), shared-node tiles for the
+    rec<-lig group, dense and sparse row loops: same 1e-4 bar against the oracle as the f32 route, and within 2e-5 of it."""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    from util import elem_excess
+    cfg = replace(DDL_SYNTH, num_conv_layers=4, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_max=5.0)
+    sd = init_state_dict(cfg, seed=3)
+    g = make_complex(seed=2, n_res=75, n_lig=7, lm_dim=0)     # 75 receptor neighbours per ligand atom: shared-node tiles; 7 <= 16: sparse rows
+    b = HeteroBatch.from_data_list(make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.3))
+    set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+    ref = CGModelOracle(cfg, sd, *tables())(b)[:3]
+    f32 = make_model(cfg, sd, emu_lib)(b)[:3]
+    bf = make_model(cfg.replace(edge_product="bf16x4"), sd, emu_lib)(b)[:3]
+    for o, f, r in zip(bf, f32, ref):
+        assert rel_err(o, r) < 1e-4 and elem_excess(o, r) <= 1.0
+        assert 0 < rel_err(o, f) < 2e-5      # another arithmetic route (not bit-equal), at fp32-level distance
+    monkeypatch.setenv("DDMI_EDGE_PRODUCT", "bf16x4")          # the environment override of the test harness selects the same route
+    env = make_model(cfg, sd, emu_lib)(b)[:3]
+    for o, e in zip(bf, env):
+        assert torch.equal(o, e)
+    monkeypatch.setenv("DDMI_EDGE_PRODUCT", "fp8")
+    from diffdock_amd.lib import DdmiError
+    with pytest.raises(DdmiError):
+        make_model(cfg, sd, emu_lib)
+
+
 @pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2"])
 def test_readout_tensor_product_forms_agree(name, emu_lib, monkeypatch):
     """final_conv / tor_bond_conv in the direct (per-edge-weight) form: the wave-per-item, thread-per-item and
