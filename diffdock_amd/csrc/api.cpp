@@ -36,6 +36,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     if (const char* e = getenv("DDMI_STREAMS")) h->m.two_streams = atoi(e) != 1;
     if (const char* e = getenv("DDMI_FUSED_PACK")) h->m.fused_pack = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_TRI")) h->m.fused_tri = atoi(e) != 0;
+    if (const char* e = getenv("DDMI_FUSED_PRERED")) h->m.fused_prered = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FUSED_SHARED")) h->m.fused_shared = atoi(e);
     if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;
     if (const char* e = getenv("DDMI_FC1_BATCH")) h->m.fc1_batch = atoi(e) != 0;

@@ -45,10 +45,12 @@ struct Model::Cx {
   // rebuilt when the edge list they were built for changes (once per forward), and the hidden-row scratch
   struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr, *ne = nullptr;
                  float* rows = nullptr;   // per-edge rows of k_conv_fused (k_vn_rows)
+                 int* tile_hdr = nullptr; unsigned char* live = nullptr;   // in-tile pre-reduction (launch_vn_tiles): tile headers, rows that get written
                  // what the lists and per-edge rows were built from (k_vn_rows bakes target slots, attribute rows, harmonics with
                  // their sign and edge weights in): a group that reuses a list id with any other input rebuilds it
                  const int *built_goff = nullptr, *built_tgt = nullptr, *built_tslot = nullptr, *built_arow = nullptr;
                  const float *built_nvec = nullptr, *built_ew = nullptr; float built_sgn = 0.f; int built_tbase = -1; long epoch = -1; };
+  bool prered = false;   // the lig<-rec group (list 0) leaves one message row per (tile, target) instead of one per edge
   VnSet vn[9];           // + 2 = ligand-ligand, 3 = rec<-lig (ligand gather nodes); all_atoms: 4 la, 5 ra, 6 aa, 7 al, 8 ar
   // ---- all_atoms (models/aa_model.py): receptor heavy atoms = third node type, node rows [nL + nR, N)
   int nA = 0, maxNa = 0, Eaa = 0, Ear = 0, Ela_cap = 0;
@@ -247,6 +249,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         vr.tgt = g.tgt; vr.tbase = g.tbase;
         vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
         launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs);
+        if (g.vn == 0 && c.prered) launch_vn_tiles(vs.voff + g.gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
         vs.built_goff = g.goff; vs.epoch = c.epoch; vs.built_tgt = g.tgt; vs.built_tslot = g.tslot; vs.built_arow = g.arow;
         vs.built_nvec = g.nvec; vs.built_ew = g.ew; vs.built_sgn = g.sgn; vs.built_tbase = g.tbase;
       }
@@ -286,6 +289,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       f.max_nb = L.max_nb; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
       f.dense = dense_rows ? 1 : 0;
       f.bf = bf ? 1 : 0;
+      f.tile_hdr = (g.vn == 0 && c.prered) ? vs.tile_hdr : nullptr;
       // ligand gather nodes with >= 2 virtual nodes on average (rec<-lig): a tile of 16 virtual nodes holds few distinct nodes
       f.shared = (dense_rows && (m.fused_shared == 2 || (m.fused_shared == 1 && g.load && (long)g.ea_rows >= 48L * std::max(1, g.gcount)))) ? 1 : 0;
       f.prof_slot = (int)gi;
@@ -626,6 +630,15 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
       const int shd = (cfg.sh_lmax + 1) * (cfg.sh_lmax + 1);
       vs.ne = dalloc<int>(m, nullptr, {round_up(vs.vcap, 16)});
       vs.rows = dalloc<float>(m, nullptr, {round_up(vs.vcap, 16), 32, shd == 4 ? 8 : shd + 3});
+      if (i == 0) {
+        // in-tile pre-reduction of the lig<-rec messages: every interaction layer must run the static l <= 1 kernel variants
+        c.prered = m.fused_prered && shd == 4 && !cfg.old_model && !m.conv_layers.empty() && m.fused_shared != 2;   // (shared == 2: test mode, mode-4 tiles everywhere)
+        for (auto& L : m.conv_layers) c.prered = c.prered && !L.fgran_generic && L.maxd <= 3 && L.n_fgran > 0;
+        if (c.prered) {
+          vs.tile_hdr = dalloc<int>(m, "prered_tile_hdr", {round_up(vs.vcap, 16) / 16, FC_TILE_HDR}, true);
+          vs.live = dalloc<unsigned char>(m, nullptr, {ecap_v[0]}, true);
+        }
+      }
       vmax = std::max(vmax, vs.vcap);
       if (lig_v[i]) vmax_b = std::max(vmax_b, vs.vcap);
     }
@@ -637,6 +650,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   {
     std::vector<ReduceGroup> rg = {{c.toff_ll, c.msg[0], 0, nL}, {c.offs_l, c.msg[1], 0, nL},
                                    {c.rr_toff, c.msg[2], nL, nR}, {c.offs_r, c.msg[3], nL, nR}};
+    rg[1].live = c.prered ? c.vn[0].live : nullptr;   // (copied into every list that holds the lig<-rec group)
     c.rg_all = m.cpool.upload(rg);
     std::vector<ReduceGroup> rl(rg.begin(), rg.begin() + 2);
     c.rg_lig = m.cpool.upload(rl);
@@ -669,6 +683,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
                                      {c.rr_toff, c.msg_aa[3], nL, nR}, {c.offs_r, c.msg_aa[4], nL, nR}, {c.se_ra.toff, c.msg_aa[5], nL, nR},
                                      {c.se_aa.toff, c.msg_aa[6], nL + nR, nA}, {c.la_offs_a, c.msg_aa[7], nL + nR, nA},
                                      {c.se_ar.toff, c.msg_aa[8], nL + nR, nA}};
+      r9[1].live = c.prered ? c.vn[0].live : nullptr;
       c.rg_aa_all = m.cpool.upload(r9);
       std::vector<ReduceGroup> r3(r9.begin(), r9.begin() + 3);
       c.rg_aa_lig = m.cpool.upload(r3);

@@ -197,6 +197,51 @@ void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* 
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
+// Tile headers of the in-tile pre-reduction (kernels.h, launch_vn_tiles): one workgroup per tile of 16 virtual nodes, thread
+// per pair of edge rows.  The representative of a target is the tile's FIRST edge (virtual node, row) that addresses it.
+__global__ __launch_bounds__(256) void k_vn_tiles(const int* __restrict__ nvn_p, const float* __restrict__ vrows,
+                                                 const int* __restrict__ vn_ne, int* __restrict__ hdr, unsigned char* __restrict__ live) {
+  __shared__ int smin, smax, key[FC_TILE_NT];
+  const int nvn = *nvn_p, v0 = blockIdx.x * 16, tid = threadIdx.x;
+  if (v0 >= nvn) return;
+  if (tid == 0) { smin = 0x7fffffff; smax = -0x7fffffff; }
+  if (tid < FC_TILE_NT) key[tid] = 0x7fffffff;
+  __syncthreads();
+  const int* __restrict__ rw = reinterpret_cast<const int*>(vrows);
+  int tg[2], ts[2]; bool ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 256 * i, v = v0 + (e >> 5), r = e & 31;
+    ok[i] = v < nvn && r < vn_ne[v];
+    tg[i] = ok[i] ? rw[((size_t)v * 32 + r) * 8 + 7] : 0;
+    ts[i] = ok[i] ? rw[((size_t)v * 32 + r) * 8 + 5] : 0;
+    if (ok[i]) { atomicMin(&smin, tg[i]); atomicMax(&smax, tg[i]); }
+  }
+  __syncthreads();
+  const int t0 = smin, nt = smax - smin + 1;
+  const bool pre = smin <= smax && nt <= FC_TILE_NT;
+  if (pre) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (ok[i]) atomicMin(&key[tg[i] - t0], tid + 256 * i);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (ok[i]) live[ts[i]] = (!pre || key[tg[i] - t0] == tid + 256 * i) ? 1 : 0;
+  int* __restrict__ h = hdr + (size_t)blockIdx.x * FC_TILE_HDR;
+  if (tid < FC_TILE_NT) {
+    const int k = key[tid];
+    h[4 + tid] = (pre && k != 0x7fffffff) ? rw[((size_t)(v0 + (k >> 5)) * 32 + (k & 31)) * 8 + 5] : -1;
+  }
+  if (tid == 0) { h[0] = pre ? 1 : 0; h[1] = t0; h[2] = pre ? nt : 0; h[3] = 0; }
+}
+void launch_vn_tiles(const int* nvn, int vcap, const float* vrows, const int* vn_ne, int* tile_hdr, unsigned char* live, hipStream_t s) {
+  if (vcap <= 0) return;
+  hipLaunchKernelGGL(k_vn_tiles, dim3(cdiv(vcap, 16)), dim3(256), 0, s, nvn, vrows, vn_ne, tile_hdr, live);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 // Hidden rows of the edge MLP in virtual-node order and in the A-fragment order of k_conv_fused, two 8-k groups per float4:
 //   Hb[v][rt][g >> 1][lane = 16q + r][2 (g & 1) + sub] = relu(HE[arow] + P[tgt] + Q[d])[k = 8g + 2q + sub]   (edge row el = 16rt + r)
 // (zero for k >= H and for the padding rows el >= ne): a wave fetches one (row tile, PAIR of 8-k groups) as 1 KB contiguous,
@@ -538,6 +583,10 @@ __device__ __forceinline__ float3 fc_buf_ld3(const FcBuf& b, unsigned voff, unsi
   const float* q = reinterpret_cast<const float*>(b.p + voff + soff);
   return make_float3(q[0], q[1], q[2]);
 }
+__device__ __forceinline__ f32x4 fc_buf_ld4v(const FcBuf& b, unsigned voff, unsigned soff) {
+  const float* q = reinterpret_cast<const float*>(b.p + voff + soff);
+  return f32x4{q[0], q[1], q[2], q[3]};
+}
 #else
 // (declared by name: the __builtin_amdgcn_raw_buffer_load_b128 of this toolchain is lowered to a one-dword load)
 typedef int fc_i32x4 __attribute__((ext_vector_type(4)));
@@ -558,6 +607,8 @@ __device__ __forceinline__ float3 fc_buf_ld3(const FcBuf& b, unsigned voff, unsi
   const fc_f32x3 v = fc_raw_buffer_load_x3(b.r, (int)voff, (int)soff, 0);
   return make_float3(v[0], v[1], v[2]);
 }
+// the four dwords kept as ONE register tuple (see roll() of the BF loops)
+__device__ __forceinline__ f32x4 fc_buf_ld4v(const FcBuf& b, unsigned voff, unsigned soff) { return fc_raw_buffer_load_x4(b.r, (int)voff, (int)soff, 0); }
 #endif
 template <int I, int N, class F>
 __device__ __forceinline__ void fc_sfor(F&& f) {
@@ -680,8 +731,14 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   const FcBuf hbuf = fc_buf(hb_tile, (unsigned)FC_VN * 2u * rts);
   unsigned hoff = (unsigned)(2 * wave) * 2u * rts;                       // uniform: this wave's two virtual nodes, pair 0
   const unsigned hlane = (unsigned)lane * 16u;
+  f32x4 hNv[2][2];             // BF: the next pair's words as they arrive (whole register tuples until roll())
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) hNv[pc >> 1][pc & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto loadh = [&](float4 (&dst)[2][2], int piece) __attribute__((always_inline)) {
-    if (DENSE || !(piece & 1) || two[piece >> 1]) dst[piece >> 1][piece & 1] = fc_buf_ld4(hbuf, hlane, hoff + (unsigned)piece * rts);
+    if (DENSE || !(piece & 1) || two[piece >> 1]) {
+      if (BF && &dst == &hN) hNv[piece >> 1][piece & 1] = fc_buf_ld4v(hbuf, hlane, hoff + (unsigned)piece * rts);
+      else dst[piece >> 1][piece & 1] = fc_buf_ld4(hbuf, hlane, hoff + (unsigned)piece * rts);
+    }
   };
   f32x4 r[4];
   // live 16-column blocks of the granule: a (12,-,-,-) granule (one item column) multiplies only block 0 in the edge product
@@ -725,10 +782,15 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
     for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        hC[vi][rt] = hN[vi][rt];
-        // BF: the A tuples {w, w, w', w'} are register copies of these words; without this the compiler places the copies right
-        // behind the requests of hN (an s_waitcnt vmcnt(0) per request in the middle of the edge product: round-4 defect)
-        if constexpr (BF) { DDMI_OPAQUE(hC[vi][rt].x); DDMI_OPAQUE(hC[vi][rt].y); DDMI_OPAQUE(hC[vi][rt].z); DDMI_OPAQUE(hC[vi][rt].w); }
+        // BF: the A tuples {w, w, w', w'} are register copies of these words; unless the words pass through an opaque point HERE
+        // the compiler places those copies right behind the requests of hN (an s_waitcnt vmcnt(0) per request in the middle of
+        // the edge product, measured: 10 % slower than the f32 route)
+        if constexpr (BF) {
+          DDMI_OPAQUE(hNv[vi][rt]);   // (the request's own register tuple: the wait for it sits here, the copies behind it)
+          hC[vi][rt] = make_float4(hNv[vi][rt][0], hNv[vi][rt][1], hNv[vi][rt][2], hNv[vi][rt][3]);
+        } else {
+          hC[vi][rt] = hN[vi][rt];
+        }
       }
   };
   // (do_roll: the hidden rows requested during the previous pair become the current ones BEHIND this step's contraction --
@@ -1016,8 +1078,14 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
   const FcBuf hbuf = fc_buf(hb_tile, (unsigned)FC_VN * 2u * rts);
   unsigned hoff = (unsigned)(2 * wave) * 2u * rts;
   const unsigned hlane = (unsigned)lane * 16u;
+  f32x4 hNv[2][2];             // BF: the next pair's words as they arrive (whole register tuples until roll())
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) hNv[pc >> 1][pc & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto loadh = [&](float4 (&dst)[2][2], int piece) __attribute__((always_inline)) {
-    if (DENSE || !(piece & 1) || two[piece >> 1]) dst[piece >> 1][piece & 1] = fc_buf_ld4(hbuf, hlane, hoff + (unsigned)piece * rts);
+    if (DENSE || !(piece & 1) || two[piece >> 1]) {
+      if (BF && &dst == &hN) hNv[piece >> 1][piece & 1] = fc_buf_ld4v(hbuf, hlane, hoff + (unsigned)piece * rts);
+      else dst[piece >> 1][piece & 1] = fc_buf_ld4(hbuf, hlane, hoff + (unsigned)piece * rts);
+    }
   };
   f32x4 r[NS];
   // results leave for the chunk buffer as soon as their chain is complete: the slots finished >= 12 positions before the
@@ -1068,10 +1136,15 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
     for (int vi = 0; vi < 2; ++vi)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        hC[vi][rt] = hN[vi][rt];
-        // BF: the A tuples {w, w, w', w'} are register copies of these words; without this the compiler places the copies right
-        // behind the requests of hN (an s_waitcnt vmcnt(0) per request in the middle of the edge product: round-4 defect)
-        if constexpr (BF) { DDMI_OPAQUE(hC[vi][rt].x); DDMI_OPAQUE(hC[vi][rt].y); DDMI_OPAQUE(hC[vi][rt].z); DDMI_OPAQUE(hC[vi][rt].w); }
+        // BF: the A tuples {w, w, w', w'} are register copies of these words; unless the words pass through an opaque point HERE
+        // the compiler places those copies right behind the requests of hN (an s_waitcnt vmcnt(0) per request in the middle of
+        // the edge product, measured: 10 % slower than the f32 route)
+        if constexpr (BF) {
+          DDMI_OPAQUE(hNv[vi][rt]);   // (the request's own register tuple: the wait for it sits here, the copies behind it)
+          hC[vi][rt] = make_float4(hNv[vi][rt][0], hNv[vi][rt][1], hNv[vi][rt][2], hNv[vi][rt][3]);
+        } else {
+          hC[vi][rt] = hN[vi][rt];
+        }
       }
   };
   auto step = [&](auto do_c, auto do_w, auto do_h, auto odd, auto do_roll) __attribute__((always_inline)) {
@@ -1266,7 +1339,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   float* escr = gscr + FC_WAVES * 16 * GS2;            // per wave: [2][32][ES] edge rows: sh (SHD), weight, message row
   int* gdesc = reinterpret_cast<int*>(escr + FC_WAVES * 2 * 32 * ES);   // [granules of this workgroup] FGran copies (see below)
   int* gorder = gdesc + FC_MAXG * FC_GWORDS;            // [granules of this workgroup] visiting order (rotated per workgroup, see below)
-  float* cgt = reinterpret_cast<float*>(gorder + FC_MAXG);   // [granules of this workgroup][8 slots][MAXD][SHD] dense coupling rows
+  int* prep = gorder + FC_MAXG;                         // [FC_TILE_NT] pre-reduction: message row of every target of the tile
+  float* cgt = reinterpret_cast<float*>(prep + FC_TILE_NT);   // [granules of this workgroup][8 slots][MAXD][SHD] dense coupling rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = DDMI_UNIFORM(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -1333,6 +1407,22 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
   }
   // dense coupling rows of this workgroup's granules (host-built, weights.cpp): cgt[g][s][k'][j]
   for (int idx = tid; idx < (g_end - g_begin) * CGN; idx += 64 * FC_WAVES) cgt[idx] = a.cgt[(size_t)g_begin * CGN + idx];
+  // In-tile pre-reduction (launch_vn_tiles): this tile's targets span <= 32 rows -> every wave sums its message rows per target
+  // in LDS, the eight partial sums meet in a fixed order and ONE row per target leaves the tile.
+  constexpr bool PRE_OK = (MODE == 0 || MODE == 3) && SHD == 4;
+  bool pre = false;
+  int pre_t0 = 0, pre_nt = 0;
+  const int* pre_rep = nullptr;
+  if constexpr (PRE_OK) {
+    if (a.tile_hdr) {
+      const int* __restrict__ th = a.tile_hdr + (size_t)blockIdx.x * FC_TILE_HDR;
+      pre = DDMI_UNIFORM(th[0]) != 0;
+      pre_t0 = DDMI_UNIFORM(th[1]); pre_nt = DDMI_UNIFORM(th[2]);
+      pre_rep = th + 4;
+      if (pre && tid < FC_TILE_NT) prep[tid] = pre_rep[tid];   // (to LDS before the first message store, like the granule descriptors)
+    }
+  }
+  (void)pre_t0; (void)pre_nt; (void)pre_rep; (void)prep;
   int vne[2];
   float* gw = gscr + wave * 16 * GS2;
   float* ew_ = escr + wave * 2 * 32 * ES;
@@ -1516,10 +1606,16 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     const int lr_e = lane_e & 15, lq_e = lane_e >> 4;
     const float* __restrict__ cg = cgt + (gi - g_begin) * CGN;
     float* stg = ybuf + wave * ((2 * FC_YB) / FC_WAVES);   // the chunk buffers are idle during the coupling phase: [16][RS] message rows
-    float* tT = stg + 16 * 16 * MAXD;                      // packed: [16 rows][2 channels][8 slots] accumulators of the tail block
+    float* tT = stg + (pre ? FC_TILE_NT * 48 : 16 * 16 * MAXD);   // packed: [16 rows][2 channels][8 slots] accumulators of the tail block
+    float* const pw = stg;                                 // pre-reduction: this wave's partial sums [targets of the tile][RS] (instead of the staged rows)
     const bool tri = Gd.shape == 7;                        // merged granule: slot c = output channels 16c .. 16c+15 (dout = 1)
     const int RS = tri ? 48 : 16 * Gd.dout, L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
     const int V = ((c0 | L) & 3) == 0 ? 4 : ((c0 | L) & 1) == 0 ? 2 : 1;
+    if (PRE_OK && pre) {   // partial sums start from zero (RS = 16 or 48 here: whole 16-B pieces)
+      for (int idx = lane_e; idx < pre_nt * RS / 4; idx += 64) reinterpret_cast<float4*>(pw)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // one message value: staged in the row's place, or added to the partial sum of the row's target
+    auto put = [&](float* __restrict__ p, float v) __attribute__((always_inline)) { if (PRE_OK && pre) *p += v; else *p = v; };
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi) {
       const int ne = vne[vi];
@@ -1560,6 +1656,17 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
         }
         DDMI_WAVE_SYNC();
         FC_STAMP(pf, 6);
+        // destination of the lane's four rows 4 lq + r: the staged row, or (pre-reduction) the partial-sum row of its target
+        float* orow[4]; bool rok[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * lq_e + r, el = 16 * rt + row;
+          rok[r] = true; orow[r] = stg + row * RS;
+          if (PRE_OK && pre) {
+            rok[r] = el < ne;
+            orow[r] = pw + (rok[r] ? reinterpret_cast<const int*>(erow)[el * ES + 7] - pre_t0 : 0) * RS;
+          }
+        }
         if (PACK && packed) {
           if constexpr (PACK) {
             const int hi = lr_e >> 3, NS = Gd.nslot;
@@ -1579,9 +1686,9 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
                   if (c < NB - 1) v = fmaf(gq[c], 2 * c + hi < NS ? acc[vi][rt][c][r] : 0.f, v);
                 m[k] = v + DDMI_ROW_XOR8(v);
               }
-              if (lr_e < 8) {
+              if (lr_e < 8 && rok[r]) {
 #pragma unroll
-                for (int k = 0; k < MAXD; ++k) stg[row * RS + lr_e * MAXD + k] = m[k];   // (packed granules: dout = MAXD = 3)
+                for (int k = 0; k < MAXD; ++k) put(orow[r] + lr_e * MAXD + k, m[k]);   // (packed granules: dout = MAXD = 3)
               }
               // tail block: lane_e lr_e = 2*slot + (channel - 8) -> transposed through LDS
               float tv = 0.f;
@@ -1592,6 +1699,11 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
             DDMI_WAVE_SYNC();
             if (lane_e < 32) {   // lane_e = (row, channel 8 + wb): all slots of one output channel
               const int row = lane_e >> 1, wb = lane_e & 1;
+              float* o2 = stg + row * RS; bool ok2 = true;
+              if (PRE_OK && pre) {
+                ok2 = 16 * rt + row < ne;
+                o2 = pw + (ok2 ? reinterpret_cast<const int*>(erow)[(16 * rt + row) * ES + 7] - pre_t0 : 0) * RS;
+              }
               const float4 ta = *reinterpret_cast<const float4*>(tT + row * 16 + wb * 8), tb = *reinterpret_cast<const float4*>(tT + row * 16 + wb * 8 + 4);
 #pragma unroll
               for (int k = 0; k < MAXD; ++k) {
@@ -1599,7 +1711,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
                 float v = ge.x * ta.x;           // slots 0, 2, 4, 6 = ge.xyzw; 1, 3, 5, 7 = go_.xyzw; tT holds slot order 0..7
                 v = fmaf(go_.x, ta.y, v); v = fmaf(ge.y, ta.z, v); v = fmaf(go_.y, ta.w, v);
                 v = fmaf(ge.z, tb.x, v); v = fmaf(go_.z, tb.y, v); v = fmaf(ge.w, tb.z, v); v = fmaf(go_.w, tb.w, v);
-                if (8 + wb < Gd.n_w) stg[row * RS + (8 + wb) * MAXD + k] = v;
+                if (8 + wb < Gd.n_w && ok2) put(o2 + (8 + wb) * MAXD + k, v);
               }
             }
           }
@@ -1617,25 +1729,26 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
             const int row = 4 * lq_e + r;
             const float* __restrict__ G = gw + row * GS2;
             const float t0 = acc[vi][rt][0][r], t1 = acc[vi][rt][1][r], t2 = acc[vi][rt][2][r], t3 = acc[vi][rt][3][r];
+            if (!rok[r]) continue;
             if (tri) {                   // three scalar channel tiles: every slot is its own output
               const float4 g4 = *reinterpret_cast<const float4*>(G);
-              float* __restrict__ o = stg + row * 48 + lr_e;
-              o[0] = g4.x * t0; o[16] = g4.y * t1; o[32] = g4.z * t2;
+              float* __restrict__ o = orow[r] + lr_e;
+              put(o, g4.x * t0); put(o + 16, g4.y * t1); put(o + 32, g4.z * t2);
             } else if (Gd.dout == 1) {   // scalar output blocks
-              stg[row * 16 + lr_e] = couple(G, 0, t0, t1, t2, t3);
+              put(orow[r] + lr_e, couple(G, 0, t0, t1, t2, t3));
             } else if (Gd.dout == 3) {   // vector output blocks: the three components of (row, w) side by side
-              float* __restrict__ o = stg + row * 48 + lr_e * 3;
-              o[0] = couple(G, 0, t0, t1, t2, t3); o[1] = couple(G, 1, t0, t1, t2, t3); o[2] = couple(G, 2, t0, t1, t2, t3);
+              float* __restrict__ o = orow[r] + lr_e * 3;
+              put(o, couple(G, 0, t0, t1, t2, t3)); put(o + 1, couple(G, 1, t0, t1, t2, t3)); put(o + 2, couple(G, 2, t0, t1, t2, t3));
             } else {
 #pragma unroll
               for (int k = 0; k < MAXD; ++k)
-                if (k < Gd.dout) stg[row * RS + lr_e * Gd.dout + k] = couple(G, k, t0, t1, t2, t3);
+                if (k < Gd.dout) put(orow[r] + lr_e * Gd.dout + k, couple(G, k, t0, t1, t2, t3));
             }
           }
         }
         DDMI_WAVE_SYNC();
         FC_STAMP(pf, 7);
-        if (!DDMI_ABL(a.dbg, 256)) {
+        if (!DDMI_ABL(a.dbg, 256) && !(PRE_OK && pre)) {
           const int nrows = min(16, ne - 16 * rt);
           const float* __restrict__ er = erow + rt * 16 * ES;
           const int accum = DDMI_ABL(a.dbg, 8192) ? 0 : Gd.accumulate;   // (timing-only: later granules of a unit overwrite instead of adding)
@@ -1648,6 +1761,23 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       }
     }
     FC_STAMP(pf, 7);
+    if (PRE_OK && pre) {   // the eight partial sums of every (target, column), in wave order; one message row per target leaves the tile
+      __syncthreads();
+      constexpr int WST = (2 * FC_YB) / FC_WAVES;
+      const int accum = Gd.accumulate;
+      for (int e = tid; e < pre_nt * L; e += 64 * FC_WAVES) {
+        const int j = e / L, cc = e - j * L;
+        const float* __restrict__ pp = ybuf + j * RS + cc;
+        float sum = pp[0];
+#pragma unroll
+        for (int w = 1; w < FC_WAVES; ++w) sum += pp[w * WST];
+        const int row = prep[j];
+        if (row >= 0) {
+          float* __restrict__ q = a.msg + (size_t)row * XS + c0 + cc;
+          *q = accum ? *q + sum : sum;
+        }
+      }
+    }
     __syncthreads();   // chunk buffers / coupling scratch are reused by the next granule
     FC_STAMP(pf, 9);
   }
@@ -1668,7 +1798,7 @@ static void launch_conv_fused_k(const FusedConvArgs& a, hipStream_t s) {
   int max_local = 0;
   for (int y = 0; y < a.ysplit; ++y) max_local = std::max(max_local, a.gsplit[y + 1] - a.gsplit[y]);
   if (max_local > FC_MAXG) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: more granules per workgroup than descriptor slots (raise DDMI_FUSED_YS)");
-  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FcDim<NBK>::YB + FC_WAVES * 16 * GS2 + FC_WAVES * 2 * 32 * ES + FC_MAXG * FC_GWORDS + FC_MAXG + max_local * CGN) * sizeof(float);
+  const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FcDim<NBK>::YB + FC_WAVES * 16 * GS2 + FC_WAVES * 2 * 32 * ES + FC_MAXG * FC_GWORDS + FC_MAXG + FC_TILE_NT + max_local * CGN) * sizeof(float);
   if (smem > 160 * 1024) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: LDS budget exceeded (raise DDMI_FUSED_YS)");
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per instantiation)
   if (!lds_opt_in) {
@@ -1684,6 +1814,10 @@ void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
   if (a_in.vcap <= 0 || a_in.ysplit <= 0) return;
   FusedConvArgs a = a_in;
   a.dbg = ablate_mask();
+#ifdef FCV_QUICK   // ISA inspection builds: one instantiation only (hipcc -DFCV_QUICK -save-temps; never linked into the library)
+  launch_conv_fused_k<3, 4, 3, 4, true>(a, s);
+  return;
+#endif
   // the predicated variant (MODE 1) walks classic 4-slot granules only: a packed / merged granule there would be mis-read
   if (a.generic && a.max_nb > 4) throw Error(DDMI_ERR_ARG, "k_conv_fused: packed granule in a generic layer (weights.cpp builds those layers unpacked)");
   if (a.maxd <= 3 && a.sh_lmax <= 1) {   // the l <= 1 tensor product (FasterTensorProduct structure): static chain shapes, packed granules
@@ -1740,7 +1874,32 @@ __global__ __launch_bounds__(256) void k_reduce_bn(const ReduceGroup* __restrict
     if (sl < 0 || sl >= G.tcount) continue;
     const int b = G.toff[sl], e = G.toff[sl + 1];
     cnt += e - b;
-    if (live) {
+    if (G.live) {   // pre-reduced group: only the rows flagged live hold (partial) sums; wave w takes the live rows of ordinal w, w + 4, ...
+      const float* __restrict__ mp = G.msg + 4 * lane;
+      int ord = 0;
+      for (int base = b; base < e; base += 64) {
+        const int rr = base + lane;
+        unsigned long long mask = __ballot(rr < e && G.live[rr] != 0);
+        while (mask) {   // up to four of this wave's rows in flight (wave-uniform control flow)
+          int rows[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            rows[i] = -1;
+            while (mask && rows[i] < 0) {
+              const int bit = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              if ((ord++ & 3) == wave) rows[i] = base + bit;
+            }
+          }
+          float4 v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = (live && rows[i] >= 0) ? nt_load4(mp + (size_t)rows[i] * XS) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (rows[i] >= 0) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+        }
+      }
+    } else if (live) {
       const float* __restrict__ mp = G.msg + 4 * lane;
       int r = b + wave;
       for (; r + 12 < e; r += 16) {

@@ -81,6 +81,13 @@ struct VnRowsArgs {
 };
 void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, const VnRowsArgs& rows,
                      hipStream_t s);
+// In-tile pre-reduction of the messages (groups whose 16 virtual nodes of a tile send to the same few targets: lig<-rec, where
+// 16 residues address the <= 32 atoms of one ligand).  Per tile a header of FC_TILE_HDR ints: [0] = 1 when the tile's targets
+// span <= 32 consecutive target rows (else the tile stores one message row per edge as before), [1] = first target row,
+// [2] = span, [4 + j] = message row that receives the tile's sum for target [1] + j (the row of the tile's first edge with that
+// target; -1: none).  live[message row] = 1 for every row that will be written (k_reduce_bn skips the others).  l <= 1 rows only.
+constexpr int FC_TILE_HDR = 36, FC_TILE_NT = 32;
+void launch_vn_tiles(const int* nvn, int vcap, const float* vrows, const int* vn_ne, int* tile_hdr, unsigned char* live, hipStream_t s);
 void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
                         const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
                         float* Hb, hipStream_t s, int bf = 0);   // P == Q == nullptr: HE[arow ? arow[e] : e] is the finished hidden row; bf: packed split-bf16 words
@@ -124,6 +131,7 @@ struct FusedConvArgs {
   int n_units; short ustart[48];         // first granule of every (output block, w tile) unit: workgroups rotate their visiting order by units
   short ufirst[8], ucount[8];            // units of granule range y: ustart[ufirst[y] .. + ucount[y])
   float* msg;                            // [E][XS]
+  const int* tile_hdr = nullptr;         // in-tile pre-reduction headers (launch_vn_tiles); nullptr: one message row per edge
   int bf = 0;                            // edge product on v_mfma_f32_16x16x32_bf16 with split operands (Hb holds packed words); static l <= 1 loops only
   int dbg = 0;
   int prof_slot = 0;                     // profiling builds: edge-group slot of the in-kernel phase clocks
@@ -133,7 +141,7 @@ void fc_prof_report();                   // prints and clears the phase clocks o
 #endif
 void launch_conv_fused(const FusedConvArgs& a, hipStream_t s);
 
-struct ReduceGroup { const int* toff; const float* msg; int tbase, tcount; };
+struct ReduceGroup { const int* toff; const float* msg; int tbase, tcount; const unsigned char* live = nullptr; };   // live: rows to read (nullptr: all)
 // X_out[s] = BN(mean over all groups' incoming messages) + pad(X_in[s]) for s in [nbase, nbase+ncount)
 void launch_reduce_bn(const ReduceGroup* groups_dev, int n_groups, int nbase, int ncount, int D_in, int D_out,
                       const float* bn_mean, const float* bn_scale, const float* bn_bias, int residual,

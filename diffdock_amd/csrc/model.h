@@ -101,6 +101,7 @@ struct Model {
   bool fc1_batch = true;    // per-node / per-graph terms of the first Linear of all groups of a layer in one launch (DDMI_FC1_BATCH=0: per group)
   bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden
   int fused_dense = 1;      // branch-free dense-row main loop: 0 never, 1 groups with >= 20 edges per gather node, 2 always
+  bool fused_prered = true; // in-tile pre-reduction of the lig<-rec messages (DDMI_FUSED_PRERED=0: one message row per edge)
   int fused_ysplit = 0;     // workgroups per 16-virtual-node tile (granule ranges); 0 = spread launches with few tiles over the CUs
   double crop_cutoff = 0.0;  // > 0: receptor cropped to this distance from the ligand in ddmi_forward (crop_beyond)
   DevicePool cpool;

@@ -110,6 +110,7 @@ f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, 
 
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 using std::isinf; using std::isnan;
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

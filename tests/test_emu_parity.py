@@ -374,6 +374,37 @@ def test_split_bf16_edge_product_matches_f32_route_and_oracle(emu_lib, monkeypat
         make_model(cfg, sd, emu_lib)
 
 
+def test_in_tile_pre_reduction_of_lig_rec_messages(emu_lib, monkeypatch):
+    """lig<-rec group: the 16 residues of a tile send to the same <= 32 ligand atoms, so a tile sums its message rows per target in
+    LDS (per wave, then the eight partial sums in wave order) and ONE row per (tile, target) leaves it; k_reduce_bn reads only the
+    rows flagged live (tensor_layers.py:144,220-221: the scatter-mean itself is unchanged -- counts are the true edge counts).
+    3 poses x 12 residues x 20 atoms: tiles 0 and 1 straddle two poses (targets span 40 rows: one row per edge as before), tile 2
+    is pre-reduced.  Against the oracle and against the per-edge route (DDMI_FUSED_PRERED=0)."""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = replace(DDL_SYNTH, num_conv_layers=4, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_max=5.0)
+    sd = init_state_dict(cfg, seed=3)
+    g = make_complex(seed=1, n_res=12, n_lig=20, lm_dim=0)
+    b = HeteroBatch.from_data_list(make_pose_list(g, 3, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.3))
+    set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+    ref = CGModelOracle(cfg, sd, *tables())(b)[:3]
+    outs = {}
+    for pre in ("1", "0"):
+        monkeypatch.setenv("DDMI_FUSED_PRERED", pre)
+        m = make_model(cfg, sd, emu_lib)
+        outs[pre] = m(b)[:3]
+        if pre == "1":
+            hdr = m.debug_buffer("prered_tile_hdr")
+            assert hdr[:3, 0].tolist() == [0, 0, 1] and hdr[2, 1:3].tolist() == [40, 20]   # (mode, first target row, span)
+            assert (hdr[2, 4:24] >= 0).all() and (hdr[2, 24:36] == -1).all()            # one message row per target of the tile
+        for o, r in zip(outs[pre], ref):
+            assert rel_err(o, r) < 1e-4
+    for a_, b_ in zip(outs["1"], outs["0"]):
+        assert rel_err(a_, b_) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2"])
 def test_readout_tensor_product_forms_agree(name, emu_lib, monkeypatch):
     """final_conv / tor_bond_conv in the direct (per-edge-weight) form: the wave-per-item, thread-per-item and

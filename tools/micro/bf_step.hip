@@ -10,6 +10,9 @@
 //           results split with scalar subtracts + stored in phase B
 //   mode 5  mode 4 with split + store of chunk t deferred into phase A of step t + 1 (edge product one step later)
 //   mode 6  mode 5 without any LDS traffic / split (MFMAs and barrier only)
+//   mode 7  mode 1 (scalar split) with waves 4..7 running [edge product, contraction]: the two waves of a SIMD are in complementary phases;
+//           their results leave during the contraction, chain by chain (chains reordered so that they complete one after the other)
+//   mode 8  mode 7 for ALL waves (order only, no complement)          mode 9  mode 1 with scalar subtracts
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -56,8 +59,9 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ g, float* out
   extern __shared__ float lds[];
   constexpr int NCB = 4, NCT = 21;
   constexpr int YROW = 16 * NCB + 8, YVN = 8 * YROW + 4, YB = 16 * YVN;
-  constexpr bool BF = MODE != 0, PERM_B = MODE >= 1 && MODE <= 2, DUP_B = MODE >= 4, A_EARLY = MODE >= 4;
-  constexpr bool SPLIT = MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5, SCALAR = MODE >= 4, DEFER = MODE >= 5, NOLDS = MODE == 6;
+  constexpr bool SWAP = MODE == 7 || MODE == 8;
+  constexpr bool BF = MODE != 0, PERM_B = (MODE >= 1 && MODE <= 2) || SWAP || MODE == 9, DUP_B = MODE >= 4 && MODE <= 6, A_EARLY = MODE >= 4 && MODE <= 6;
+  constexpr bool SPLIT = MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5 || SWAP || MODE == 9, SCALAR = MODE >= 4, DEFER = MODE == 5 || MODE == 6, NOLDS = MODE == 6;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   f32x4 acc[2][2][NCB];
@@ -94,6 +98,66 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ g, float* out
 #pragma unroll
       for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(hN[i >> 1][i & 1].x), "+v"(hN[i >> 1][i & 1].y), "+v"(hN[i >> 1][i & 1].z), "+v"(hN[i >> 1][i & 1].w));
     }
+#pragma unroll
+    for (int i = 0; i < NCT; ++i) asm volatile("" : "+v"(bw[i]));   // new weight fragments every step
+    bool swapped = false;
+    if constexpr (SWAP) swapped = MODE == 8 || wave >= 4;
+    if (swapped) {
+      if constexpr (SWAP) {
+        // ---- edge product first
+        float q[2][2 * NCB];
+        auto readq = [&](int vi) __attribute__((always_inline)) {
+          const float* yb = yrd + eb * YB + vi * YVN;
+#pragma unroll
+          for (int c = 0; c < NCB; ++c) { q[vi][c] = yb[16 * c]; q[vi][NCB + c] = yb[YROW + 16 * c]; }
+        };
+        readq(0);
+        sfor<0, 4 * NCB>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value;
+          constexpr int vi = m / (2 * NCB), t8 = m % (2 * NCB), c = t8 >> 1, rt = t8 & 1;
+          const float4 h = hN[vi][rt];
+          const unsigned w0_ = __float_as_uint(eb ? h.z : h.x), w1_ = __float_as_uint(eb ? h.w : h.y);
+          const u32x4 A = u32x4{w0_, w0_, w1_, w1_};
+          const unsigned b0 = __float_as_uint(q[vi][c]), b1 = __float_as_uint(q[vi][NCB + c]);
+          const u32x4 B = u32x4{__builtin_amdgcn_perm(b0, b0, 0x03020302u), __builtin_amdgcn_perm(b0, b0, 0x01000100u),
+                                __builtin_amdgcn_perm(b1, b1, 0x03020302u), __builtin_amdgcn_perm(b1, b1, 0x01000100u)};
+          acc[vi][rt][c] = mfma_bf(A, B, acc[vi][rt][c]);
+          if (m == 0) readq(1);
+          FENCE();
+        });
+        // ---- contraction: chains 1, 2 first (alternating), then 3 with the long chain, then the rest of the long chain
+        constexpr int ORD[21] = {1, 2, 1, 2, 1, 2, 3, 0, 3, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 r0b = f32x4{0.f, 0.f, 0.f, 0.f};
+        float* yw = ywr + cb * YB;
+        sfor<0, NCT>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int sl = ORD[i];
+          if constexpr (sl == 0 && (i & 1)) r0b = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[i], r0b, 0, 0, 0);
+          else r[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], bw[i], r[sl], 0, 0, 0);
+          if constexpr (i >= 8 && i < 12) {   // chains 1, 2 complete at position 5: pair (1, 2), node quarter i - 8
+            constexpr int rr = i - 8;
+            float v0 = r[1][rr], v1 = r[2][rr];
+            split2<true>(v0, v1, v0, v1);
+            yw[rr * YVN + 16] = v0; yw[rr * YVN + 32] = v1;
+          }
+          if constexpr (i == 14 || i == 16) {   // chain 3 complete at position 10: two node quarters per split
+            constexpr int rr = i - 14;
+            float v0 = r[3][rr], v1 = r[3][rr + 1];
+            split2<true>(v0, v1, v0, v1);
+            yw[rr * YVN + 48] = v0; yw[(rr + 1) * YVN + 48] = v1;
+          }
+          FENCE();
+        });
+        r[0] += r0b;
+        {
+          float v0 = r[0][0], v1 = r[0][1], v2 = r[0][2], v3 = r[0][3];
+          split2<true>(v0, v1, v0, v1); split2<true>(v2, v3, v2, v3);
+          yw[0] = v0; yw[YVN] = v1; yw[2 * YVN] = v2; yw[3 * YVN] = v3;
+        }
+      }
+    } else {
     // ---- phase A: contraction of chunk s + 1
 #pragma unroll
     for (int c = 0; c < NCB; ++c) { if constexpr (DEFER) rp[c] = r[c]; r[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -166,6 +230,7 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ g, float* out
         FENCE();
       });
     }
+    }
     __syncthreads();
   };
   for (int s = 0; s < steps; s += 2) { step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); }
@@ -212,5 +277,8 @@ int main() {
   run<4>("bf16: B = duplicated LDS reads, A perms in phase A, scalar split + stores in phase B", g, out, clk, steps);
   run<5>("bf16: same, split + stores deferred into the next phase A", g, out, clk, steps);
   run<6>("bf16: MFMAs + barrier only", g, out, clk, steps);
+  run<9>("bf16: mode 1 with scalar subtracts in the split", g, out, clk, steps);
+  run<7>("bf16: mode 1 (scalar split), waves 4-7 in the complementary phase", g, out, clk, steps);
+  run<8>("bf16: all waves [edge product, contraction + stores]", g, out, clk, steps);
   return 0;
 }
