@@ -79,6 +79,8 @@ class ModelConfig:
     # execution option (ddmi_config.edge_product, not a reference argument): arithmetic of the per-edge product of the
     # interaction layers -- "f32" (exact fp32 chain, default) | "bf16x4" (split-bf16 operands, fp32 accumulation)
     edge_product: str = "f32"
+    # kernel-route selection (ddmi_config.exec = ddmi_exec_options, include/ddmi.h): ((field, value), ...); () = every default
+    exec_options: tuple = ()
 
     # ------------------------------------------------------------------ derived
     @property

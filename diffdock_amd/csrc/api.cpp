@@ -28,24 +28,29 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     h->m.cfg = *cfg;
     h->m.device = device;
     try { build_weight_spec(h->m); } catch (...) { delete h; throw; }
-    if (const char* e = getenv("DDMI_EDGE_PRODUCT")) {
-      h->m.cfg.edge_product = !strcmp(e, "f32") ? 0 : !strcmp(e, "bf16x4") ? 1 : -1;
-      if (h->m.cfg.edge_product < 0) { delete h; throw Error(DDMI_ERR_ARG, std::string("DDMI_EDGE_PRODUCT: unknown route '") + e + "' (f32 | bf16x4)"); }
+    {   // execution options (include/ddmi.h, ddmi_exec_options): 0 = default everywhere; the library reads no environment variable
+      const ddmi_exec_options& x = h->m.cfg.exec;
+      auto in = [&](int v, int hi, const char* name) {
+        if (v < 0 || v > hi) { delete h; throw Error(DDMI_ERR_ARG, std::string("ddmi_config.exec.") + name + ": out of range"); }
+      };
+      if (h->m.cfg.edge_product < 0 || h->m.cfg.edge_product > 1) { delete h; throw Error(DDMI_ERR_ARG, "ddmi_config.edge_product: 0 (f32) or 1 (bf16x4)"); }
+      in(x.streams, 1, "streams"); in(x.dense_rows, 2, "dense_rows"); in(x.shared_tiles, 2, "shared_tiles");
+      in(x.packed_granules, 1, "packed_granules"); in(x.merged_granule, 1, "merged_granule"); in(x.pre_reduce, 1, "pre_reduce");
+      in(x.hidden_mm, 1, "hidden_mm"); in(x.fc1_batch, 1, "fc1_batch"); in(x.tile_split, 8, "tile_split");
+      in(x.tile_split_small, 8, "tile_split_small"); in(x.hidden_grid, 1 << 20, "hidden_grid"); in(x.tp_apply, 3, "tp_apply");
+      h->m.two_streams = x.streams == 0;
+      h->m.fused_dense = x.dense_rows == 0 ? 1 : x.dense_rows == 1 ? 0 : 2;
+      h->m.fused_shared = x.shared_tiles == 0 ? 1 : x.shared_tiles == 1 ? 0 : 2;
+      h->m.fused_pack = x.packed_granules == 0;
+      h->m.fused_tri = x.merged_granule == 0;
+      h->m.fused_prered = x.pre_reduce == 0;
+      h->m.fused_mm = x.hidden_mm == 0;
+      h->m.fc1_batch = x.fc1_batch == 0;
+      h->m.fused_ysplit = x.tile_split;
+      h->m.fused_ysplit_small = x.tile_split_small;
+      h->m.eh_grid = x.hidden_grid > 0 ? x.hidden_grid : 2048;
+      h->m.tp_form = x.tp_apply == 0 ? -1 : x.tp_apply - 1;   // 0 wave, 1 edge, 2 thread
     }
-    if (h->m.cfg.edge_product < 0 || h->m.cfg.edge_product > 1) { delete h; throw Error(DDMI_ERR_ARG, "ddmi_config.edge_product: 0 (f32) or 1 (bf16x4)"); }
-    if (const char* e = getenv("DDMI_STREAMS")) h->m.two_streams = atoi(e) != 1;
-    if (const char* e = getenv("DDMI_FUSED_PACK")) h->m.fused_pack = atoi(e) != 0;
-    if (const char* e = getenv("DDMI_FUSED_TRI")) h->m.fused_tri = atoi(e) != 0;
-    if (const char* e = getenv("DDMI_FUSED_PRERED")) h->m.fused_prered = atoi(e) != 0;
-    if (const char* e = getenv("DDMI_FUSED_SHARED")) h->m.fused_shared = atoi(e);
-    if (const char* e = getenv("DDMI_FUSED_MM")) h->m.fused_mm = atoi(e) != 0;
-    if (const char* e = getenv("DDMI_FC1_BATCH")) h->m.fc1_batch = atoi(e) != 0;
-    if (const char* e = getenv("DDMI_TP_APPLY")) {
-      h->m.tp_form = !strcmp(e, "wave") ? 0 : !strcmp(e, "edge") ? 1 : !strcmp(e, "thread") ? 2 : !strcmp(e, "auto") ? -1 : -2;
-      if (h->m.tp_form == -2) { delete h; throw Error(DDMI_ERR_ARG, std::string("DDMI_TP_APPLY: unknown form '") + e + "' (wave | edge | thread | auto)"); }
-    }
-    if (const char* e = getenv("DDMI_FUSED_DENSE")) h->m.fused_dense = atoi(e);
-    if (const char* e = getenv("DDMI_FUSED_YS")) h->m.fused_ysplit = std::max(0, atoi(e));
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_fork));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_join));
@@ -54,7 +59,13 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
   });
 }
 
-void ddmi_destroy(ddmi_model* h) { delete h; }
+void ddmi_destroy(ddmi_model* h) {
+  if (!h) return;
+  Model& m = h->m;
+  if (m.side_stream) { (void)hipStreamSynchronize(m.side_stream); (void)hipStreamDestroy(m.side_stream); }
+  for (hipEvent_t e : {m.ev_fork, m.ev_join, m.ev_cross}) if (e) (void)hipEventDestroy(e);
+  delete h;
+}
 
 int ddmi_num_weights(ddmi_model* h) { return h ? (int)h->m.spec.size() : DDMI_ERR_ARG; }
 
@@ -238,6 +249,7 @@ int ddmi_set_kernel_timing(ddmi_model* h, int enabled) {
   ddmi::fc_prof_report();   // in-kernel phase clocks since the last call (profiling builds only)
 #endif
   h->m.timing = enabled != 0;
+  h->m.timing_level = enabled;
   if (enabled) h->m.phases.clear();
   return DDMI_OK;
 }

@@ -198,6 +198,10 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     DDMI_CHECK_HIP(hipEventRecord(m.ev_fork, s));
     DDMI_CHECK_HIP(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0));
   }
+  // (Measured and dropped in round 4, profiles/r04_e5_ab.txt: the GEMMs / hidden rows of a stream's SECOND group on extra
+  // "preparation" streams next to the first group's fused launch.  The time with no k_conv_fused dispatch running stayed at
+  // 1.87 ms per forward, the fused launches themselves got 4 % slower -- 27-KB k_edge_hidden_mm workgroups scattered over the
+  // CUs keep 158-KB fused workgroups from being placed: 139.8 -> 135.7 poses/s on the same box.)
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const RunGroup& g = groups[gi];
     const bool side = forked && g.gbase == 0 && g.gcount == c.nL;
@@ -266,6 +270,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb; h.bf = bf ? 1 : 0;
         h.zero_fill = (!L.fgran_generic && dense_rows) ? 1 : 0;
         if (m.cfg.sh_lmax <= 1) { h.vrows = vs.rows; h.vn_ne = vs.ne; }
+        h.grid = m.eh_grid;
         launch_edge_hidden_mm(h, gs);
       } else if (deep) {
         PhaseTimer t(m, "k_edge_hidden", gs);
@@ -302,7 +307,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         // ranges at 40 poses; 5-6 cost the headline 2.5 % (profiles/r03_e27..e37_ab.txt).
         if (small_layer) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
         else ys_req = (int)std::min(6L, std::max(1L, 768 / std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16)));
-        static const int ys_small = getenv("DDMI_FUSED_YS_SMALL") ? atoi(getenv("DDMI_FUSED_YS_SMALL")) : 0;   // tuning: split of a small group next to big ones
+        const int ys_small = m.fused_ysplit_small;   // tuning: split of a small group next to big ones
         if (ys_small > 0 && !small_layer && tiles_of(g) < 256) ys_req = ys_small;
       }
       ys_req = std::max(ys_req, (L.n_fgran + 19) / 20);   // a workgroup keeps at most 24 granule descriptors in LDS
@@ -323,9 +328,8 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         for (int u = 0; u < f.n_units; ++u)
           if (f.ustart[u] >= f.gsplit[y] && f.ustart[u] < f.gsplit[y + 1]) { if (f.ucount[y] == 0) f.ufirst[y] = (short)u; ++f.ucount[y]; }
       }
-      static const bool per_group = getenv("DDMI_TIME_GROUPS") != nullptr;   // profiling: one timing row per edge group
-      if (m.timing && per_group) {
-        static const bool per_layer = atoi(getenv("DDMI_TIME_GROUPS")) >= 2;   // 2: one row per (layer, edge group)
+      if (m.timing && m.timing_level >= 2) {   // ddmi_set_kernel_timing(h, 2 | 3): one timing row per edge group / per (layer, edge group)
+        const bool per_layer = m.timing_level >= 3;
         const std::string tname = "k_conv_fused:" + (per_layer ? "L" + L.name.substr(L.name.size() - 1) : std::string()) + "g" + std::to_string(gi);
         PhaseTimer t(m, tname.c_str(), gs);
         launch_conv_fused(f, gs);
@@ -1275,6 +1279,10 @@ void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) 
     const double s_tr = std::pow((double)cfg.tr_sigma_min, 1 - t_tr) * std::pow((double)cfg.tr_sigma_max, t_tr);
     launch_fill_times(c.s_t, B, (float)t_tr, (float)t_rot, (float)t_tor, s);   // set_time for this step
     m.crop_cutoff = sc.use_crop ? s_tr * 3.0 + sc.crop_beyond : 0.0;   // sampling.py:107
+    // (Measured and dropped in round 4, profiles/r04_e7_ab.txt: the forward captured once as a HIP graph -- every launch argument
+    // of a forward is the same in every step -- and replayed per step.  A dependent-kernel boundary costs the same inside a graph
+    // as between eager launches on this stack, and the replay's fixed cost is not hidden: 146.3 -> 145.4 poses/s at 40 poses,
+    // 102.2 -> 100.5 at 5.)
     forward(m, lig_pos, c.s_t, c.s_t + B, c.s_t + 2 * B, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
     perturb_step(m, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, sc, k, ids_dev, s);
 #ifdef DDMI_PROFILING   // timing-only ablation builds produce garbage scores: DDMI_FREEZE_POSE keeps the graphs fixed (never in the shipped library)

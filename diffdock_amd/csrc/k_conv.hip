@@ -434,8 +434,7 @@ void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {
   const size_t smem = (size_t)(a.ns * (a.H + 1)) * sizeof(float);
   // Many short workgroups (not a persistent grid of 3 per CU, which is 6 % faster alone): with the two streams a long-lived
   // workgroup holds 27 KB of LDS on its CU and keeps the concurrent k_conv_fused workgroups (131 KB) off it.
-  static const int eh_grid = getenv("DDMI_EH_GRID") ? atoi(getenv("DDMI_EH_GRID")) : 2048;   // tuning knob
-  const int grid = std::min(cdiv(a.vcap, 4), eh_grid);
+  const int grid = std::min(cdiv(a.vcap, 4), a.grid > 0 ? a.grid : 2048);
   switch (a.ns / 16) {
     case 1: hipLaunchKernelGGL(k_edge_hidden_mm<1>, dim3(grid), dim3(256), smem, s, a); break;
     case 2: hipLaunchKernelGGL(k_edge_hidden_mm<2>, dim3(grid), dim3(256), smem, s, a); break;

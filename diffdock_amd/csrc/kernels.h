@@ -110,6 +110,7 @@ struct EdgeHiddenArgs {
   const float* vrows; const int* vn_ne;   // l <= 1: per-edge rows of k_vn_rows (words 6, 7 = attribute row, target row) and edge counts; nullptr = index chain
   float* Hb;
   int bf;          // hidden values as packed split-bf16 words (ddmi_common.h: bf_split2) for the bf16 edge product of k_conv_fused
+  int grid;        // workgroups (ddmi_exec_options.hidden_grid); 0 = 2048
 };
 void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s);
 

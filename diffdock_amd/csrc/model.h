@@ -95,14 +95,16 @@ struct Model {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cross = nullptr;
   bool two_streams = true;
   int fused_shared = 1;     // 1: rec<-lig group contracts the distinct gather nodes of a tile on the 4x4x1 MFMA; 0: per virtual node; 2: every dense group (tests)
-  bool fused_tri = true;    // the three light granules of a single-chain 48-channel scalar block as one (DDMI_FUSED_TRI=0: separate)
-  bool fused_pack = true;   // packed granules for output blocks of <= 10 channels (DDMI_FUSED_PACK=0: classic granules only)
-  int tp_form = -1;         // read-out tensor product: -1 by launch size; DDMI_TP_APPLY=wave|edge|thread forces one form (tests)
-  bool fc1_batch = true;    // per-node / per-graph terms of the first Linear of all groups of a layer in one launch (DDMI_FC1_BATCH=0: per group)
-  bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); DDMI_FUSED_MM=0: GEMMs + k_edge_hidden
+  bool fused_tri = true;    // the three light granules of a single-chain 48-channel scalar block as one (exec.merged_granule = 1: separate)
+  bool fused_pack = true;   // packed granules for output blocks of <= 10 channels (exec.packed_granules = 1: classic granules only)
+  int tp_form = -1;         // read-out tensor product: -1 by launch size; exec.tp_apply forces one form (tests)
+  bool fc1_batch = true;    // per-node / per-graph terms of the first Linear of all groups of a layer in one launch (exec.fc1_batch = 1: per group)
+  bool fused_mm = true;     // hidden rows straight from the edge attributes (k_edge_hidden_mm); exec.hidden_mm = 1: GEMMs + k_edge_hidden
   int fused_dense = 1;      // branch-free dense-row main loop: 0 never, 1 groups with >= 20 edges per gather node, 2 always
-  bool fused_prered = true; // in-tile pre-reduction of the lig<-rec messages (DDMI_FUSED_PRERED=0: one message row per edge)
+  bool fused_prered = true; // in-tile pre-reduction of the lig<-rec messages (exec.pre_reduce = 1: one message row per edge)
   int fused_ysplit = 0;     // workgroups per 16-virtual-node tile (granule ranges); 0 = spread launches with few tiles over the CUs
+  int fused_ysplit_small = 0;   // the same for a small group next to chip-filling ones (ddmi_exec_options.tile_split_small); 0 = automatic
+  int eh_grid = 2048;       // workgroups of k_edge_hidden_mm (ddmi_exec_options.hidden_grid)
   double crop_cutoff = 0.0;  // > 0: receptor cropped to this distance from the ligand in ddmi_forward (crop_beyond)
   DevicePool cpool;
   struct Cx;  // defined in complex.cpp
@@ -110,6 +112,7 @@ struct Model {
   std::map<std::string, DebugEntry> debug;
   // ---- kernel timing
   bool timing = false;
+  int timing_level = 0;     // ddmi_set_kernel_timing: 1 = one row per kernel name, 2 = k_conv_fused per edge group, 3 = per (layer, edge group)
   struct TimedPhase { std::string name; double ms = 0; int64_t launches = 0; };
   std::vector<TimedPhase> phases;
   struct EventPair { int phase; hipEvent_t a, b; };

@@ -513,7 +513,7 @@ static void commit_conv(Model& m, ConvW& L) {
     L.n_fgran = (int)fg.size();
     L.max_nb = 4;
     for (auto& G : fg) L.max_nb = std::max(L.max_nb, G.nb);
-    if (getenv("DDMI_DEBUG_GRAN")) {   // granule list of the layer (shape / slots / column blocks), for tests and debugging
+    if (m.cfg.exec.debug & 1) {   // granule list of the layer (shape / slots / column blocks), for tests and debugging
       fprintf(stderr, "ddmi granules %s:", L.name.c_str());
       for (auto& G : fg) fprintf(stderr, " [shape %d slots %d nb %d w %d%s]", G.shape, G.nslot, G.nb, G.n_w, G.accumulate ? " acc" : "");
       fprintf(stderr, "\n");

@@ -11,10 +11,16 @@ utils/torsion.py:15-45 rotatable-bond masks) restated for the parts that are pla
   ligand_graph         get_lig_graph (:279-301): both directions interleaved, one-hot bond type (single, double, triple, aromatic)
   transformation_mask  get_transformation_mask (utils/torsion.py:15-45) with networkx, same component choice
 
-NOT restated (declared external inputs): the 15 RDKit chemistry-perception atom features (chirality, degree incl. implicit
-hydrogens, formal charge, implicit valence, hybridisation, aromaticity, ring membership -- process_mols.py:97-112; only the
-atomic-number column is filled, the rest is 0 unless `atom_features` is passed in), aromaticity perception of bond
-types (a kekulised file keeps its single/double types), and the ESM language-model embeddings (`lm_embeddings`).
+  ligand_atom_features lig_atom_featurizer (:97-120) for the columns that follow from the connection table alone: atomic number,
+                       total degree, formal charge, hydrogen count, aromatic flag, ring count and ring-size flags
+
+NOT restated (declared external inputs): the RDKit chemistry-PERCEPTION columns of the 16 ligand atom features -- chirality
+tag (column 1), implicit valence (4), radical electrons (6, read from the file's charge code / `M  RAD` only) and
+hybridisation (7) stay 0 unless `atom_features` is passed in; aromaticity is taken from the file's bond type 4 (a kekulised
+file keeps its single / double types and its atoms stay non-aromatic -- RDKit would perceive them); rings are a minimum
+cycle basis (networkx), which equals RDKit's SSSR except for the symmetrised extra rings of cage systems; hydrogens are counted
+only when the file writes them (a file without hydrogens gives degree = heavy neighbours, numH = 0 -- RDKit adds implicit
+ones from its valence model).  The ESM language-model embeddings (`lm_embeddings`) are external as well.
 """
 from __future__ import annotations
 
@@ -124,6 +130,77 @@ def read_sdf(path, remove_hs=True):
     return xyz, z, bonds
 
 
+_CHARGE_CODE = {0: 0, 1: 3, 2: 2, 3: 1, 4: 0, 5: -1, 6: -2, 7: -3}     # V2000 atom-block charge field (4 = doublet radical)
+
+
+def ligand_atom_features(path):
+    """[n_heavy, 16] int64: the columns of `lig_atom_featurizer` (datasets/process_mols.py:97-120, feature order of
+    `lig_feature_dims` :65-82) that follow from the V2000 connection table without chemistry perception; the others stay 0
+    (module docstring).  Rows are the heavy atoms in file order, as `read_sdf(remove_hs=True)` returns them.
+
+      0 atomic number          safe_index(range(1, 119) + ['misc'], Z)
+      2 total degree           bonded atoms in the file, hydrogens included (GetTotalDegree; 11 = 'misc' above 10)
+      3 formal charge          atom-block charge code, overridden by `M  CHG` lines; index into [-5 .. 5, 'misc']
+      5 hydrogen count         bonded hydrogen atoms in the file (GetTotalNumHs; 9 = 'misc' above 8)
+      6 radical electrons      `M  RAD` (1 singlet -> 2 electrons as RDKit, 2 doublet -> 1, 3 triplet -> 2) / charge code 4
+      8 aromatic               the atom has a bond of type 4
+      9 ring count             cycles of a minimum cycle basis through the atom (7 = 'misc' above 6)
+      10..15 in a ring of size 3..8"""
+    import networkx as nx
+    with open(path) as f:
+        lines = f.read().splitlines()
+    counts = lines[3]
+    if "V2000" not in counts:
+        raise ValueError("only V2000 connection tables are read")
+    na, nb = int(counts[0:3]), int(counts[3:6])
+    z, charge, rad = [], [], []
+    for l in lines[4:4 + na]:
+        z.append(_Z.get(l[31:34].strip().upper(), 0))
+        code = int(l[36:39]) if len(l) >= 39 and l[36:39].strip() else 0
+        charge.append(_CHARGE_CODE.get(code, 0))
+        rad.append(1 if code == 4 else 0)
+    bonds = [(int(l[0:3]) - 1, int(l[3:6]) - 1, int(l[6:9])) for l in lines[4 + na:4 + na + nb]]
+    chg_lines = [l for l in lines[4 + na + nb:] if l.startswith("M  CHG")]
+    if chg_lines:   # (a CHG property line supersedes every atom-block charge, ctfile specification)
+        charge = [0] * na
+    for l in lines[4 + na + nb:]:
+        if l.startswith("M  END"):
+            break
+        if l.startswith("M  CHG") or l.startswith("M  RAD"):
+            f_ = l.split()
+            for a, v in zip(f_[3::2], f_[4::2]):
+                if l.startswith("M  CHG"):
+                    charge[int(a) - 1] = int(v)
+                else:
+                    rad[int(a) - 1] = {1: 2, 2: 1, 3: 2}.get(int(v), 0)
+    z = np.asarray(z, dtype=np.int64)
+    heavy = np.where(z != 1)[0]
+    deg = np.zeros(na, dtype=np.int64); nh = np.zeros(na, dtype=np.int64); arom = np.zeros(na, dtype=bool)
+    G = nx.Graph()
+    G.add_nodes_from(int(i) for i in heavy)
+    for a, b, o in bonds:
+        deg[a] += 1; deg[b] += 1
+        if z[b] == 1: nh[a] += 1
+        if z[a] == 1: nh[b] += 1
+        if o == 4: arom[a] = arom[b] = True
+        if z[a] != 1 and z[b] != 1:
+            G.add_edge(a, b)
+    rings = [list(c) for c in nx.minimum_cycle_basis(G)]
+    feats = np.zeros((len(heavy), 16), dtype=np.int64)
+    for r, i in enumerate(heavy):
+        mine = [c for c in rings if i in c]
+        feats[r, 0] = z[i] - 1 if 1 <= z[i] <= 118 else 118
+        feats[r, 2] = min(deg[i], 11)
+        feats[r, 3] = charge[i] + 5 if -5 <= charge[i] <= 5 else 11
+        feats[r, 5] = min(nh[i], 9)
+        feats[r, 6] = min(rad[i], 5)
+        feats[r, 8] = int(arom[i])
+        feats[r, 9] = min(len(mine), 7)
+        for size in range(3, 9):
+            feats[r, 7 + size] = int(any(len(c) == size for c in mine))
+    return feats
+
+
 def ligand_bond_arrays(bonds):
     """get_lig_graph: edge_index [2, 2*nb] (both directions interleaved) and one-hot edge_attr [2*nb, 4]."""
     row, col, et = [], [], []
@@ -173,7 +250,7 @@ def complex_graph(pdb_path, sdf_path, receptor_radius=15.0, c_alpha_max_neighbor
     """HeteroData with the schema of the reference's preprocessed complex: receptor C-alpha graph, ligand
     heavy-atom graph with rotatable-bond masks, both centred on the receptor's C-alpha centroid (`original_center`,
     datasets/pdbbind.py get_complex).  `lm_embeddings` [n_res, 1280] and `atom_features` [n_lig, 16] are the external
-    inputs (ESM, RDKit); zeros / atomic number only when absent."""
+    inputs (ESM, RDKit); zeros / the connection-table columns of `ligand_atom_features` when absent."""
     rc, rtype, _ = read_pdb_calpha(pdb_path)
     lc, z, bonds = read_sdf(sdf_path)
     g = HeteroData()
@@ -190,9 +267,9 @@ def complex_graph(pdb_path, sdf_path, receptor_radius=15.0, c_alpha_max_neighbor
     center = torch.mean(rpos, dim=0, keepdim=True)
     g["receptor"].pos = rpos - center
     ei, attr = ligand_bond_arrays(bonds)
-    if atom_features is None:
-        feats = np.zeros((len(z), 16), dtype=np.int64)
-        feats[:, 0] = np.where((z >= 1) & (z <= 118), z - 1, 118)       # safe_index(possible_atomic_num_list, Z)
+    if atom_features is None:       # the connection-table columns; the perception columns stay 0 (module docstring)
+        feats = ligand_atom_features(sdf_path)
+        assert feats.shape[0] == len(z) and np.array_equal(feats[:, 0], np.where((z >= 1) & (z <= 118), z - 1, 118))
     else:
         feats = np.asarray(atom_features, dtype=np.int64)
     mask_edges, mask_rotate = transformation_mask(len(z), ei)

@@ -24,6 +24,42 @@ class DdmiError(RuntimeError):
 EDGE_PRODUCTS = {"f32": 0, "bf16x4": 1}   # ddmi_config.edge_product (include/ddmi.h)
 
 
+class ExecOptions(C.Structure):   # ddmi_exec_options (include/ddmi.h): all 0 = defaults
+    _fields_ = [(n, C.c_int32) for n in ("streams", "dense_rows", "shared_tiles", "packed_granules", "merged_granule", "pre_reduce",
+                                         "hidden_mm", "fc1_batch", "tile_split", "tile_split_small", "hidden_grid", "tp_apply",
+                                         "debug")]
+
+
+# Harness knobs: libddmi.so reads no environment variable; the test / bench harness selects kernel routes through these
+# DDMI_* variables, mapped HERE onto ddmi_config.exec at model creation (INTEGRATION.md has the table).
+def _env_int(name):
+    v = os.environ.get(name)
+    return None if v is None or v == "" else int(v)
+
+
+def exec_options_from_env(base=()) -> ExecOptions:
+    x = ExecOptions()
+    for k, v in dict(base or ()).items():
+        setattr(x, k, int(v))
+    e = _env_int
+    if e("DDMI_STREAMS") is not None: x.streams = 1 if e("DDMI_STREAMS") == 1 else 0
+    if e("DDMI_FUSED_DENSE") is not None: x.dense_rows = {1: 0, 0: 1, 2: 2}[e("DDMI_FUSED_DENSE")]
+    if e("DDMI_FUSED_SHARED") is not None: x.shared_tiles = {1: 0, 0: 1, 2: 2}[e("DDMI_FUSED_SHARED")]
+    for var, field in (("DDMI_FUSED_PACK", "packed_granules"), ("DDMI_FUSED_TRI", "merged_granule"), ("DDMI_FUSED_PRERED", "pre_reduce"),
+                       ("DDMI_FUSED_MM", "hidden_mm"), ("DDMI_FC1_BATCH", "fc1_batch")):
+        if e(var) is not None: setattr(x, field, 0 if e(var) != 0 else 1)     # variable = 0 switches the default route OFF
+    if e("DDMI_FUSED_YS") is not None: x.tile_split = max(0, e("DDMI_FUSED_YS"))
+    if e("DDMI_FUSED_YS_SMALL") is not None: x.tile_split_small = max(0, e("DDMI_FUSED_YS_SMALL"))
+    if e("DDMI_EH_GRID") is not None: x.hidden_grid = max(0, e("DDMI_EH_GRID"))
+    tp = os.environ.get("DDMI_TP_APPLY")
+    if tp is not None:
+        if tp not in ("auto", "wave", "edge", "thread"):
+            raise DdmiError(f"DDMI_TP_APPLY: unknown form '{tp}' (wave | edge | thread | auto)")
+        x.tp_apply = {"auto": 0, "wave": 1, "edge": 2, "thread": 3}[tp]
+    if os.environ.get("DDMI_DEBUG_GRAN"): x.debug = 1
+    return x
+
+
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("ns", "nv", "num_conv_layers", "num_prot_emb_layers", "sh_lmax",
                                          "sigma_embed_dim", "distance_embed_dim", "cross_distance_embed_dim",
@@ -37,7 +73,7 @@ class Config(C.Structure):
                [("all_atoms", C.c_int32), ("confidence_mode", C.c_int32), ("num_confidence_outputs", C.c_int32),
                 ("old_model", C.c_int32), ("atom_confidence", C.c_int32), ("atom_num_confidence_outputs", C.c_int32),
                 ("affinity_prediction", C.c_int32), ("embedding_type", C.c_int32), ("tp_weights_layers", C.c_int32),
-                ("edge_product", C.c_int32)]
+                ("edge_product", C.c_int32), ("exec", ExecOptions)]
 
 
 class Complex(C.Structure):
@@ -67,7 +103,12 @@ def make_config(cfg) -> Config:
         elif name == "embedding_type":
             c.embedding_type = {"sinusoidal": 0, "fourier": 1}[cfg.embedding_type]
         elif name == "edge_product":
-            c.edge_product = EDGE_PRODUCTS[cfg.edge_product]
+            ep = os.environ.get("DDMI_EDGE_PRODUCT") or cfg.edge_product      # (harness override, see exec_options_from_env)
+            if ep not in EDGE_PRODUCTS:
+                raise DdmiError(f"edge_product: unknown route '{ep}' (f32 | bf16x4)")
+            c.edge_product = EDGE_PRODUCTS[ep]
+        elif name == "exec":
+            c.exec = exec_options_from_env(getattr(cfg, "exec_options", None))
         else:
             setattr(c, name, getattr(cfg, name))
     return c

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import weakref
 from typing import Dict, Optional
 
@@ -314,8 +315,13 @@ class MIScoreModel:
         return tr, rot, tor
 
     # ------------------------------------------------------------------ introspection
-    def set_kernel_timing(self, enabled: bool):
-        _lib.check(self.lib, self.lib.ddmi_set_kernel_timing(self._h, int(enabled)))
+    def set_kernel_timing(self, enabled, level: int | None = None):
+        """level 1 = one row per kernel name, 2 = k_conv_fused per edge group, 3 = per (layer, edge group); the harness variable
+        DDMI_TIME_GROUPS=1|2 selects level 2 | 3 (profiling scripts under tools/)."""
+        if level is None:
+            tg = os.environ.get("DDMI_TIME_GROUPS")
+            level = 1 if not tg else (3 if int(tg) >= 2 else 2)
+        _lib.check(self.lib, self.lib.ddmi_set_kernel_timing(self._h, level if enabled else 0))
 
     def kernel_timings(self):
         """{phase: (total_ms, launches)} measured with HIP events on the launch stream."""

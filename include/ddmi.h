@@ -42,6 +42,26 @@ enum ddmi_status {
 /* Hyper-parameters: the keyword arguments get_model passes to CGModel
  * (utils/utils.py:234-276, models/cg_model.py:20-31) and the sigma bounds t_to_sigma reads
  * (utils/diffusion_utils.py:28-32).  Booleans are 0/1. */
+/* Execution options: which of the parity-tested kernel routes a model runs.  Every field 0 = the default a caller should
+ * keep; the other values exist for the route-agreement tests (tests/test_gpu_parity.py::test_selectable_kernel_paths_agree_on_the_gpu)
+ * and for A/B timing.  Read once at ddmi_create; libddmi.so itself reads NO environment variable -- diffdock_amd/lib.py maps
+ * the DDMI_* variables of the test / bench harness onto these fields (INTEGRATION.md has the table). */
+typedef struct ddmi_exec_options {
+  int32_t streams;          /* 0 = two HIP streams (ligand-gather groups next to residue-gather groups), 1 = one stream            */
+  int32_t dense_rows;       /* k_conv_fused dense-row loop: 0 = groups with >= 20 edges per gather node, 1 = never, 2 = always       */
+  int32_t shared_tiles;     /* shared-node tiles (4x4x1 contraction): 0 = the rec<-lig group, 1 = never, 2 = every dense group       */
+  int32_t packed_granules;  /* 0 = packed granules for output blocks of <= 10 channels, 1 = classic 4-slot granules only             */
+  int32_t merged_granule;   /* 0 = the three scalar channel tiles of the first layer as one granule, 1 = separate                    */
+  int32_t pre_reduce;       /* 0 = in-tile pre-reduction of the lig<-rec messages, 1 = one message row per edge                      */
+  int32_t hidden_mm;        /* 0 = hidden rows straight from the edge attributes (k_edge_hidden_mm), 1 = GEMMs + k_edge_hidden       */
+  int32_t fc1_batch;        /* 0 = per-node terms of the first Linear of all groups of a SMALL layer in one launch, 1 = per group    */
+  int32_t tile_split;       /* workgroups per 16-virtual-node tile (granule ranges); 0 = automatic                                   */
+  int32_t tile_split_small; /* the same for a small group that runs next to chip-filling ones; 0 = automatic                         */
+  int32_t hidden_grid;      /* workgroups of k_edge_hidden_mm; 0 = 2048                                                              */
+  int32_t tp_apply;         /* read-out tensor product: 0 = by launch size, 1 = wave per pair, 2 = workgroup per edge, 3 = thread    */
+  int32_t debug;            /* 1 = print the granule list of every interaction layer to stderr at ddmi_commit_weights (tests)         */
+} ddmi_exec_options;
+
 typedef struct ddmi_config {
   int32_t ns, nv, num_conv_layers, num_prot_emb_layers, sh_lmax;
   int32_t sigma_embed_dim, distance_embed_dim, cross_distance_embed_dim, in_lig_edge_features;
@@ -77,8 +97,9 @@ typedef struct ddmi_config {
    *       f32 product on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- a quarter of the matrix-core time of route 0;
    *       applies to the static l <= 1 loops (sh_lmax = 1, ns % 16 == 0), other layers run route 0.  Same 1e-4 parity bar,
    *       reported as its own bench line (dtype "bf16x4-split edge product, f32 accumulate").
-   * The environment variable DDMI_EDGE_PRODUCT (f32 | bf16x4) overrides the field at ddmi_create (test harness). */
+   * (The library reads no environment variable: the Python harness maps DDMI_EDGE_PRODUCT onto this field, diffdock_amd/lib.py.) */
   int32_t edge_product;
+  ddmi_exec_options exec; /* kernel-route selection, all 0 = defaults (see above) */
 } ddmi_config;
 
 /* Static description of one collated batch of complexes = the fields of the PyG Batch the
@@ -201,7 +222,8 @@ int ddmi_wigner_3j(int l1, int l2, int l3, double* host_out);
  * Replaces torch.normal at utils/sampling.py:140-154 when the caller supplies no draws. */
 int ddmi_debug_philox(const uint32_t* counters, const uint32_t* keys, int n, uint32_t* host_out);
 int ddmi_debug_normal(uint64_t seed, int64_t sample0, int n_samples, int step, int n_comp, float* dev_out, ddmi_stream stream);
-/* Name / duration table of the kernels launched by the last ddmi_forward when timing is on. */
+/* Name / duration table of the kernels launched by the last ddmi_forward when timing is on.  enabled: 0 = off, 1 = one row per
+ * kernel name, 2 = k_conv_fused split per edge group, 3 = per (layer, edge group). */
 int ddmi_set_kernel_timing(ddmi_model* m, int enabled);
 int ddmi_kernel_timings(ddmi_model* m, int i, const char** name, double* ms, int64_t* launches);
 

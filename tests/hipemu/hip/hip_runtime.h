@@ -72,11 +72,15 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum { hipStreamNonBlocking = 1 };
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+// (distinct non-null handles: the multi-stream code paths of complex.cpp -- side stream, preparation streams -- run under the
+// emulator too, in issue order)
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static char handles[64]; static int n = 0; *s = (hipStream_t)(handles + (n++ & 63)); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e);
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);

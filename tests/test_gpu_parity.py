@@ -116,14 +116,15 @@ def width48_case():
 
 @pytest.mark.parametrize("env", [{"DDMI_FUSED_PACK": "0"}, {"DDMI_FUSED_DENSE": "0"},
                                  {"DDMI_FUSED_DENSE": "2"}, {"DDMI_FUSED_MM": "0"}, {"DDMI_STREAMS": "1"}, {"DDMI_FUSED_YS": "3"},
-                                 {"DDMI_FUSED_SHARED": "0"}, {"DDMI_FUSED_SHARED": "2", "DDMI_FUSED_DENSE": "2"}, {"DDMI_FC1_BATCH": "0"}, {"DDMI_FUSED_TRI": "0"}],
+                                 {"DDMI_FUSED_SHARED": "0"}, {"DDMI_FUSED_SHARED": "2", "DDMI_FUSED_DENSE": "2"}, {"DDMI_FC1_BATCH": "0"}, {"DDMI_FUSED_TRI": "0"}, {"DDMI_FUSED_PRERED": "0"}],
                          ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
 def test_selectable_kernel_paths_agree_on_the_gpu(env, width48_case, monkeypatch):
     """Every selectable route of an edge group (classic instead of packed granules for the 10-channel vector blocks,
     sparse- / dense-row loop, GEMM first layer, one stream, granule-range splits,
     the rec<-lig group per virtual node instead of per distinct gather node / every group through the shared-node kernel)
-    against the default route and the oracle at the benchmark width: the knobs are read at ddmi_create, so each model handle
-    is built under its own environment."""
+    against the default route and the oracle at the benchmark width.  The routes are fields of ddmi_config.exec (the library
+    reads no environment variable); diffdock_amd/lib.py maps these harness variables onto them when a model handle is created,
+    so each handle is built under its own environment."""
     cfg, sd, batch, ref, base = width48_case
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -212,6 +213,28 @@ def test_all_atom_ddl_width_matches_oracle():
     assert inter["edge_counts"][2] > 100 and int(m.debug_buffer("offs_la_l")[-1]) == inter["edge_counts"][2]
     assert_scores_close((tr2, rot2, tor2), (tr, rot, tor))
     for l in range(cfg.num_conv_layers - 1):   # all node rows: ligand, residues, atoms
+        mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))
+        ref = inter[f"node_attr{l + 1}"]
+        assert rel_err(mine[:, :ref.shape[1]], ref) < REL, l
+
+
+def test_all_atom_bench_size_complex_matches_oracle():
+    """AAModel on the complex of the all-atom bench line (300 residues / ~2250 receptor atoms / 30 ligand atoms, all six interaction
+    layers at the DDL-synth widths), 2 poses instead of 40 so that the oracle -- which materialises the per-edge weights -- stays
+    within seconds: scores and every node table against the oracle.  (The 40-pose run itself is covered by determinism /
+    equivariance / shard invariance below; the per-pose arithmetic does not depend on the batch size up to tile composition.)"""
+    cfg = DDL_SYNTH.replace(all_atoms=True, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0)
+    sd = init_state_dict(cfg, seed=99)
+    g = make_complex(seed=14, n_res=300, n_lig=30, lm_dim=0, all_atoms=True)
+    dl = make_pose_list(g, 2, tr_sigma_max=cfg.tr_sigma_max, seed=15, initial_noise_std_proportion=0.05)
+    batch = HeteroBatch.from_data_list(dl)
+    set_time(batch, 0.5, 0.5, 0.5, 2)
+    tr, rot, tor, _, inter = oracle_model(cfg, sd)(batch, return_intermediates=True)
+    m = gpu_model(cfg, sd)
+    tr2, rot2, tor2, _ = m(to_gpu(batch))
+    assert batch["atom"].pos.shape[0] > 2 * 2000 and inter["edge_counts"][2] > 100
+    assert_scores_close((tr2, rot2, tor2), (tr, rot, tor))
+    for l in range(cfg.num_conv_layers - 1):
         mine = torch.from_numpy(m.debug_buffer(f"x{l + 1}"))
         ref = inter[f"node_attr{l + 1}"]
         assert rel_err(mine[:, :ref.shape[1]], ref) < REL, l
@@ -307,7 +330,12 @@ def test_sharded_sampling_is_sample_invariant():
     for lo in (0, 4):
         parts.append(m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl[lo:lo + 4])), 5, (sched, sched, sched), seed=123,
                                     sample_ids=list(range(lo, lo + 4)), no_final_step_noise=True).cpu().reshape(4, -1, 3))
-    assert (torch.cat(parts) - full).abs().max() < 1e-3
+    dev = float((torch.cat(parts) - full).abs().max())
+    print(f"sharded vs joint sampling, 5 steps: max |dx| = {dev:.3e} A")
+    # not bit-identical: which 16 virtual nodes share a tile depends on the batch, and two things inside a tile depend on its
+    # composition -- whether it takes the shared-node (4x4x1) contraction (<= 4 distinct gather nodes) and the order in which
+    # the pre-reduction adds message rows of one target; both are re-associations of fp32 sums
+    assert dev < 1e-4    # measured 7.6e-6 A after 5 steps (poses travel ~10 A): fp32 rounding level, 100x below the old 1e-3 bound
 
 
 def test_ddl_synth_cropped_forward_matches_oracle():

@@ -75,3 +75,99 @@ def test_configs0_plumbing_on_the_cpu_emulation():
         m.set_tables(*tables())
         return m
     cases.config0_case(make, lambda b: b, TINY.replace(lm_embedding_type=None, num_conv_layers=3), steps=2)   # (4 steps, full width: -m gpu)
+
+
+_PHENOLATE = """phenolate
+  hand-written
+
+ 12 12  0  0  0  0  0  0  0  0999 V2000
+    0.0000    1.4000    0.0000 C   0  0  0  0  0  0
+    1.2124    0.7000    0.0000 C   0  0  0  0  0  0
+    1.2124   -0.7000    0.0000 C   0  0  0  0  0  0
+    0.0000   -1.4000    0.0000 C   0  0  0  0  0  0
+   -1.2124   -0.7000    0.0000 C   0  0  0  0  0  0
+   -1.2124    0.7000    0.0000 C   0  0  0  0  0  0
+    0.0000    2.7600    0.0000 O   0  5  0  0  0  0
+    2.1500    1.2400    0.0000 H   0  0  0  0  0  0
+    2.1500   -1.2400    0.0000 H   0  0  0  0  0  0
+    0.0000   -2.4800    0.0000 H   0  0  0  0  0  0
+   -2.1500   -1.2400    0.0000 H   0  0  0  0  0  0
+   -2.1500    1.2400    0.0000 H   0  0  0  0  0  0
+  1  2  4  0
+  2  3  4  0
+  3  4  4  0
+  4  5  4  0
+  5  6  4  0
+  6  1  4  0
+  1  7  1  0
+  2  8  1  0
+  3  9  1  0
+  4 10  1  0
+  5 11  1  0
+  6 12  1  0
+M  END
+$$$$
+"""
+
+_SPIRO = """spiro[2.3]hexane with an ammonium substituent, charges on M  CHG
+  hand-written
+
+  7  8  0  0  0  0  0  0  0  0999 V2000
+    0.0000    0.0000    0.0000 C   0  0  0  0  0  0
+    1.0000    1.0000    0.0000 C   0  0  0  0  0  0
+    1.0000   -1.0000    0.0000 C   0  0  0  0  0  0
+   -1.0000    1.0000    0.5000 C   0  0  0  0  0  0
+   -2.0000    0.0000    0.0000 C   0  0  0  0  0  0
+   -1.0000   -1.0000   -0.5000 C   0  0  0  0  0  0
+   -3.4000    0.0000    0.0000 N   0  3  0  0  0  0
+  1  2  1  0
+  2  3  1  0
+  3  1  1  0
+  1  4  1  0
+  4  5  1  0
+  5  6  1  0
+  6  1  1  0
+  5  7  1  0
+M  CHG  1   7   1
+M  END
+$$$$
+"""
+
+
+def test_ligand_atom_features_from_the_connection_table(tmp_path):
+    """The columns of lig_atom_featurizer (datasets/process_mols.py:97-120) that need no chemistry perception, on two
+    hand-written molecules whose values follow from the file: phenolate (aromatic bond type 4, explicit hydrogens, charge code)
+    and a spiro ring system (two rings of sizes 3 and 4 through one atom, `M  CHG`).  Chirality / implicit valence /
+    hybridisation (columns 1, 4, 7) stay 0 = declared external."""
+    from diffdock_amd.io import ligand_atom_features
+    p = tmp_path / "phenolate.sdf"
+    p.write_text(_PHENOLATE)
+    f = ligand_atom_features(str(p))
+    assert f.shape == (7, 16)
+    assert f[:, 0].tolist() == [5] * 6 + [7]                    # C, O: atomic number - 1
+    assert f[:, 2].tolist() == [3] * 6 + [1]                    # total degree: ring carbons 3 (2 C + H or O), O 1
+    assert f[:, 3].tolist() == [5] * 6 + [4]                    # formal charge index: 0 -> 5, -1 -> 4
+    assert f[:, 5].tolist() == [0, 1, 1, 1, 1, 1, 0]            # hydrogens written in the file
+    assert f[:, 8].tolist() == [1] * 6 + [0]                    # aromatic: a bond of type 4
+    assert f[:, 9].tolist() == [1] * 6 + [0]                    # one ring through every carbon
+    assert f[:, 13].tolist() == [1] * 6 + [0] and not f[:, [10, 11, 12, 14, 15]].any()     # ring of size 6 only
+    assert not f[:, [1, 4, 6, 7]].any()
+    g = complex_graph_lig_only(str(p))
+    assert np.array_equal(g, f)
+    q = tmp_path / "spiro.sdf"
+    q.write_text(_SPIRO)
+    f = ligand_atom_features(str(q))
+    assert f[:, 9].tolist() == [2, 1, 1, 1, 1, 1, 0]            # the spiro atom is in both rings
+    assert f[:, 10].tolist() == [1, 1, 1, 0, 0, 0, 0] and f[:, 11].tolist() == [1, 0, 0, 1, 1, 1, 0]   # sizes 3 and 4
+    assert f[:, 3].tolist() == [5] * 6 + [6]                    # M  CHG: N +1 (and it supersedes the atom-block code 3 = +1)
+    assert f[:, 2].tolist() == [4, 2, 2, 2, 3, 2, 1]            # no hydrogens in the file: heavy neighbours only (documented)
+
+
+def complex_graph_lig_only(sdf):
+    """ligand rows of complex_graph's default atom features = ligand_atom_features (receptor side from the synthetic PDB-free path
+    is not needed: the function is called directly)."""
+    from diffdock_amd.io import ligand_atom_features, read_sdf
+    _, z, _ = read_sdf(sdf)
+    f = ligand_atom_features(sdf)
+    assert f.shape[0] == len(z)
+    return f
