@@ -846,7 +846,11 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       constexpr int grp = m / (2 * NCB), t8 = m % (2 * NCB), vi = grp >> 1, sub = grp & 1, rt = t8 / NCB, c = t8 % NCB;
       if (DENSE || rt == 0 || two[vi]) {
         const float av = ODD ? (sub == 0 ? hC[vi][rt].z : hC[vi][rt].w) : (sub == 0 ? hC[vi][rt].x : hC[vi][rt].y);
+#ifdef FCV_NOEMMA   // timing-only: no edge-product MFMAs (upper bound of what a cheaper edge product of low-degree groups can buy)
+        acc[vi][rt][c][0] += av * q[grp & 1][c];
+#else
         acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
+#endif
       }
       if constexpr (DO_W) { if constexpr (m % 2 == 0 && m / 2 < NL) loadw(std::integral_constant<int, m / 2>{}); }
       // The hidden rows of the next pair of chunks (HBM / Infinity Cache, slow) are requested AFTER this step's weight
@@ -1190,7 +1194,11 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
       constexpr int grp = m / (2 * NB), t8 = m % (2 * NB), vi = grp >> 1, sub = grp & 1, rt = t8 / NB, c = t8 % NB;
       if (DENSE || rt == 0 || two[vi]) {
         const float av = ODD ? (sub == 0 ? hC[vi][rt].z : hC[vi][rt].w) : (sub == 0 ? hC[vi][rt].x : hC[vi][rt].y);
+#ifdef FCV_NOEMMA
+        acc[vi][rt][c][0] += av * q[grp & 1][c];
+#else
         acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
+#endif
       }
       if constexpr (DO_W) { if constexpr (m % 2 == 0 && m / 2 < NL) loadw(std::integral_constant<int, m / 2>{}); }
       if constexpr (DO_H) {   // (after this step's weight requests: vmcnt retires in order)
