@@ -751,12 +751,22 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       for (int c = 0; c < NCB; ++c) { q[par][c] = yb[16 * c]; q[par][NCB + c] = yb[FC_YROW + 16 * c]; }
     } else {
       const float* __restrict__ yb = yrd + buf * FC_YB + ynoff[grp >> 1] + (grp & 1) * FC_YROW;
+#ifdef FCV_NOQ
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) { q[par][c] = (float)(buf + grp); DDMI_OPAQUE(q[par][c]); }
+      if (true) return;
+#endif
 #pragma unroll
       for (int c = 0; c < NCB; ++c) q[par][c] = yb[16 * c];
     }
   };
   auto store_piece = [&](int buf, int piece) __attribute__((always_inline)) {   // rows of node quarter `rr`, slots 2h and 2h+1
     float* yw = ywr + buf * FC_YB;
+#ifdef FCV_NOYST
+    if constexpr (SH) { float keep = r[piece][0]; DDMI_OPAQUE(keep); }
+    else { float k0 = r[2 * (piece >> 2) < 4 ? 2 * (piece >> 2) : 0][piece & 3]; DDMI_OPAQUE(k0); }
+    if (true) return;
+#endif
     if constexpr (SH) {   // one chain per piece
       const float v = rsc(r[piece]);
       yw[16 * piece] = BF ? bf_split1(v) : v;
@@ -1042,9 +1052,16 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
   // keeping them, for one LDS read per contraction MFMA
   constexpr int XW = 5;          // read-ahead distance of the window, in contraction positions
   float xw[NC];
+#ifdef FCV_NOXW
+  float fcv_x0 = P.xp0[0];
+#endif
   auto xread = [&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     if constexpr (i < NC) {
+#ifdef FCV_NOXW   // timing-only: no x-fragment reads inside the loop (one register, kept opaque)
+      xw[i] = fcv_x0; DDMI_OPAQUE(xw[i]);
+      if (true) return;
+#endif
       if constexpr (O::is_c0(i)) {
         xw[i] = P.xp0[4 * O::step(i)];                                       // scalar input: u = 4 * step + lane / 16
       } else {
@@ -1109,11 +1126,20 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
       for (int c = 0; c < NB; ++c) { q[par][c] = yb[16 * c]; q[par][NB + c] = yb[FC_YROW + 16 * c]; }
     } else {
       const float* __restrict__ yb = yrd + buf * FC_YB + (grp >> 1) * FC_YVN + (grp & 1) * FC_YROW;
+#ifdef FCV_NOQ    // timing-only: no chunk reads for the edge product
+#pragma unroll
+      for (int c = 0; c < NB; ++c) { q[par][c] = (float)(buf + grp); DDMI_OPAQUE(q[par][c]); }
+      if (true) return;
+#endif
 #pragma unroll
       for (int c = 0; c < NB; ++c) q[par][c] = yb[16 * c];
     }
   };
   auto store_slot = [&](int buf, int s_, int rr) __attribute__((always_inline)) {   // node quarter rr of slot s_
+#ifdef FCV_NOYST  // timing-only: contraction results are not stored to the chunk buffer
+    { float keep = r[s_][rr]; DDMI_OPAQUE(keep); }
+    if (true) return;
+#endif
     ywr[buf * FC_YB + rr * FC_YVN + cs * s_] = BF ? bf_split1(r[s_][rr]) : r[s_][rr];
   };
   // late stores: slot 0 (long chain) and the slots behind the early ones

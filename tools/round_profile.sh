@@ -31,3 +31,8 @@ python bench.py --config mix --steps 2 > $out/${tag}_bench_mix.json 2>> $out/${t
 python bench.py --config configs4 --steps 2 --warmup 1 > $out/${tag}_bench_configs4.json 2>> $out/${tag}_bench.err
 python bench.py --samples 5 --no-cpu-baseline > $out/${tag}_bench_b5.json 2>> $out/${tag}_bench.err
 python bench.py --all-atoms > $out/${tag}_bench_all_atoms.json 2>> $out/${tag}_bench.err
+# secondary line: split-bf16 edge product (its own dtype), with the whole GPU suite under that route
+python bench.py --edge-product bf16x4 --no-cpu-baseline > $out/${tag}_bench_bf16x4.json 2>> $out/${tag}_bench.err
+( time DDMI_EDGE_PRODUCT=bf16x4 python -m pytest tests -m gpu -q ) > $out/${tag}_bf16x4_pytest_gpu.log 2>&1
+# where the wall clock of a forward goes (tools/timeline.py)
+python $GRAFT_REPO_ROOT/tools/timeline.py $(find /tmp/prof_kt -name "*.db" | head -1) k_perturb 10 > $out/${tag}_timeline.txt 2>&1
