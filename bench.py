@@ -419,10 +419,12 @@ def main():
                 try:
                     hdr = j["model"].debug_buffer("prered_tile_hdr")
                     nvn = int(j["model"].debug_buffer("vn_off_cross")[-1])
-                    hdr = hdr[:(nvn + 15) // 16]
+                    nt_ = (nvn + 15) // 16
+                    hdr = hdr[:nt_]
                     pre = hdr[:, 0] != 0
-                    if pre.all():
-                        lr_rows = int((hdr[:, 4:] >= 0).sum())
+                    ne_tile = j["model"].debug_buffer("vn_ne_cross")[:nt_ * 16].reshape(nt_, 16).sum(1)
+                    # pre-reducing tiles write one row per target, the others (a tile that spans two poses) one per edge
+                    lr_rows = int((hdr[pre, 4:] >= 0).sum()) + int(ne_tile[~pre].sum())
                     prered_rows.append(lr_rows)
                 except Exception:
                     pass

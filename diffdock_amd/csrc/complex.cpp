@@ -632,7 +632,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
       vs.cnt = dalloc<int>(m, nullptr, {gn_v[i] + 1}); vs.voff = dalloc<int>(m, names[i], {gn_v[i] + 1});
       vs.node = dalloc<int>(m, nullptr, {vs.vcap}); vs.e0 = dalloc<int>(m, nullptr, {vs.vcap});
       const int shd = (cfg.sh_lmax + 1) * (cfg.sh_lmax + 1);
-      vs.ne = dalloc<int>(m, nullptr, {round_up(vs.vcap, 16)});
+      vs.ne = dalloc<int>(m, i == 0 ? "vn_ne_cross" : nullptr, {round_up(vs.vcap, 16)});   // (named: bench.py counts the message rows a pre-reducing launch writes)
       vs.rows = dalloc<float>(m, nullptr, {round_up(vs.vcap, 16), 32, shd == 4 ? 8 : shd + 3});
       if (i == 0) {
         // in-tile pre-reduction of the lig<-rec messages: every interaction layer must run the static l <= 1 kernel variants
