@@ -43,8 +43,11 @@ def exec_options_from_env(base=()) -> ExecOptions:
         setattr(x, k, int(v))
     e = _env_int
     if e("DDMI_STREAMS") is not None: x.streams = 1 if e("DDMI_STREAMS") == 1 else 0
-    if e("DDMI_FUSED_DENSE") is not None: x.dense_rows = {1: 0, 0: 1, 2: 2}[e("DDMI_FUSED_DENSE")]
-    if e("DDMI_FUSED_SHARED") is not None: x.shared_tiles = {1: 0, 0: 1, 2: 2}[e("DDMI_FUSED_SHARED")]
+    for var, field in (("DDMI_FUSED_DENSE", "dense_rows"), ("DDMI_FUSED_SHARED", "shared_tiles")):   # variable: 1 = default rule, 0 = never, 2 = always
+        if e(var) is not None:
+            if e(var) not in (0, 1, 2):
+                raise DdmiError(f"{var}: 0 (never), 1 (default rule) or 2 (always)")
+            setattr(x, field, {1: 0, 0: 1, 2: 2}[e(var)])
     for var, field in (("DDMI_FUSED_PACK", "packed_granules"), ("DDMI_FUSED_TRI", "merged_granule"), ("DDMI_FUSED_PRERED", "pre_reduce"),
                        ("DDMI_FUSED_MM", "hidden_mm"), ("DDMI_FC1_BATCH", "fc1_batch")):
         if e(var) is not None: setattr(x, field, 0 if e(var) != 0 else 1)     # variable = 0 switches the default route OFF
