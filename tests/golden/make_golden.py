@@ -180,6 +180,13 @@ def main():
     # AAModel with receptor embedding layers and embed_also_ligand=False: ligand rows zero-padded (models/aa_model.py:351-357)
     cases["tiny_aa_emb_nolig"] = dict(cfg=TINY.replace(all_atoms=True, num_conv_layers=2, num_prot_emb_layers=2, sh_lmax=2,
                                                         embed_also_ligand=False), n_res=17, n_lig=9, n_samples=2, seed=20, t=0.5)
+    # flags get_model passes through that had no reference-executed evidence until round 4 (third session): odd_parity (one 1o + 1e
+    # read-out pair, ns x 0o torsion features: cg_model.py:223,244,251,377-378), batch_norm off and scale_by_sigma off (:393,421)
+    cases["tiny_oddpar"] = dict(cfg=TINY.replace(odd_parity=True, sh_lmax=2, num_conv_layers=3), n_res=24, n_lig=11, n_samples=2, seed=21, t=0.45)
+    cases["tiny_aa_oddpar"] = dict(cfg=TINY.replace(all_atoms=True, odd_parity=True, num_conv_layers=3, sh_lmax=2, fixed_center_conv=True),
+                                   n_res=14, n_lig=9, n_samples=2, seed=22, t=0.3)
+    cases["tiny_nobn_noscale"] = dict(cfg=TINY.replace(batch_norm=False, scale_by_sigma=False, num_conv_layers=3), n_res=26, n_lig=13,
+                                      n_samples=2, seed=25, t=0.55)
     if len(sys.argv) > 1:
         cases = {k: v for k, v in cases.items() if k in sys.argv[1:]}
     for name, c in cases.items():

@@ -20,7 +20,8 @@ EMU = os.path.join(ROOT, "tests", "hipemu", "libddmi_emu.so")
 CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb",   # tiny_aa_*: AAModel
          "tiny_noaa", "tiny_2nd", "tiny_aa_2nd",   # tiny_*2nd: use_second_order_repr (2e / 2o node blocks)
          "tiny_fourier", "tiny_tpw3",              # embedding_type='fourier'; tp_weights_layers=3
-         "tiny_aa_emb_nolig"]                      # AAModel: embedding layers without embed_also_ligand (zero-padded ligand rows)
+         "tiny_aa_emb_nolig",                      # AAModel: embedding layers without embed_also_ligand (zero-padded ligand rows)
+         "tiny_oddpar", "tiny_aa_oddpar", "tiny_nobn_noscale"]   # odd_parity (CG + all-atom); batch_norm off + scale_by_sigma off
 
 
 @pytest.fixture(scope="session")
@@ -62,7 +63,7 @@ def test_forward_matches_reference_fixture(name, emu_lib):
 
 
 @pytest.mark.parametrize("name", ["tiny_l1", "tiny_l2", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb", "tiny_2nd", "tiny_aa_2nd", "tiny_fourier",
-                                  "tiny_tpw3", "tiny_aa_emb_nolig"])
+                                  "tiny_tpw3", "tiny_aa_emb_nolig", "tiny_oddpar", "tiny_aa_oddpar", "tiny_nobn_noscale"])
 def test_device_loop_matches_reference_trajectory(name, emu_lib):
     fx, cfg, data_list = fixture_case(name)
     m = make_model(cfg, fx["state_dict"], emu_lib)

@@ -16,7 +16,8 @@ from util import fixture_case, load_fixture, oracle_model, rel_err, split_draws,
 CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tiny_l2_crop", "tiny_aa_l1", "tiny_aa_l2", "tiny_aa_l2_emb",
          "tiny_noaa", "tiny_2nd", "tiny_aa_2nd",   # tiny_*2nd: use_second_order_repr (2e / 2o node blocks)
          "tiny_fourier", "tiny_tpw3",              # embedding_type='fourier'; tp_weights_layers=3
-         "tiny_aa_emb_nolig"]                      # AAModel: embedding layers without embed_also_ligand (zero-padded ligand rows)
+         "tiny_aa_emb_nolig",                      # AAModel: embedding layers without embed_also_ligand (zero-padded ligand rows)
+         "tiny_oddpar", "tiny_aa_oddpar", "tiny_nobn_noscale"]   # odd_parity (CG + all-atom); batch_norm off + scale_by_sigma off
 
 
 @pytest.mark.parametrize("name", CASES)
