@@ -46,6 +46,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("DDMI_HARNESS", "1")     # the DDMI_* route variables of tools/*.sh are harness knobs (diffdock_amd/lib.py)
 
 from diffdock_amd.config import DDL_SYNTH  # noqa: E402
 from diffdock_amd.dist import shard_bounds  # noqa: E402
@@ -214,6 +215,21 @@ def main():
     ap.add_argument("--edge-product", default="f32", choices=["f32", "bf16x4"],
                     help="arithmetic of the per-edge product of the interaction layers (ddmi_config.edge_product): f32 = exact fp32 chain "
                          "(the headline), bf16x4 = split-bf16 operands on the bf16 matrix pipe, fp32 accumulation (secondary line, its own dtype)")
+    ap.add_argument("--pose-shards", type=int, default=1,
+                    help="split the poses of a complex on ONE GPU into K independent batches, each with its own model handle and HIP "
+                         "stream, enqueued back to back: the layer-boundary phases of one shard (reduce, per-node terms, hidden rows -- "
+                         "kernels that cannot fill the chip) overlap the convolution kernels of the others.  Poses are independent "
+                         "trajectories (utils/sampling.py:80,91-93); noise is keyed by global sample id, so the poses are the one-batch poses")
+    ap.add_argument("--tile-per-pose", action="store_true",
+                    help="ddmi_exec_options.tile_per_pose: tiles of k_conv_fused never span two poses -> a pose's arithmetic does not depend on "
+                         "its neighbours in the batch (bit-exact shard invariance)")
+    ap.add_argument("--fixed-center-conv", action="store_true",
+                    help="build the model with fixed_center_conv (models/cg_model.py:371-374: the default indexes the ligand table by graph id, "
+                         "so a pose's score depends on its position in the batch -- in the reference too)")
+    ap.add_argument("--verify-shards", action="store_true",
+                    help="multi-rank strong runs: after the timed region sample once more with a fixed seed, gather, and let rank 0 compare the "
+                         "gathered poses with the same poses sampled in ONE batch on its own GPU (readiness check of the sharded path; "
+                         "extra key `shard_check`)")
     ap.add_argument("--all-atoms", action="store_true",
                     help="secondary workload: the all-atom score model (models/aa_model.py), ~7.5 receptor atoms per residue")
     args = ap.parse_args()
@@ -238,6 +254,10 @@ def main():
         cfg = cfg.replace(all_atoms=True)
     if args.edge_product != "f32":
         cfg = cfg.replace(edge_product=args.edge_product)
+    if args.fixed_center_conv:
+        cfg = cfg.replace(fixed_center_conv=True)
+    if args.tile_per_pose:
+        cfg = cfg.replace(exec_options=tuple(cfg.exec_options) + (("tile_per_pose", 1),))
     sd = init_state_dict(cfg, seed=1234)
     so3_t, tor_t = default_tables()
     S = args.samples or wl["samples"]              # poses per complex
@@ -245,29 +265,65 @@ def main():
     lo, hi = shard_bounds(S, rank, world) if strong else (0, S)
     B = hi - lo                                    # poses of each complex on this rank
     sched = t_schedule(INFERENCE_STEPS)
+    K = max(1, min(args.pose_shards, B)) if B > 0 else 1
+
+    def new_model():
+        mdl = MIScoreModel(cfg, device=str(dev), lib_path=args.lib)
+        mdl.load_state_dict(sd)
+        mdl.set_tables(so3_t, tor_t)
+        return mdl
+
+    def make_shards(dl, ids, models=None):
+        """K contiguous blocks of the rank's poses: (model handle, collated batch, sample ids, stream) each"""
+        out = []
+        for k in range(K):
+            a, b = shard_bounds(len(dl), k, K)
+            if b > a:
+                out.append(dict(model=models[k] if models else new_model(), batch=HeteroBatch.from_data_list(dl[a:b]).to(dev), ids=ids[a:b],
+                                stream=torch.cuda.Stream(device=dev) if K > 1 else None, n=b - a))
+        return out
+
     jobs = []
     for (n_res, n_lig, cseed) in wl["complexes"]:
-        model = MIScoreModel(cfg, device=str(dev), lib_path=args.lib)
-        model.load_state_dict(sd)
-        model.set_tables(so3_t, tor_t)
         g = make_complex(seed=cseed, n_res=n_res, n_lig=n_lig, all_atoms=args.all_atoms)
         # strong: all ranks draw the same S initial poses and keep their block; weak: every rank its own S poses
         dl = make_pose_list(g, S, tr_sigma_max=cfg.tr_sigma_max, seed=1000 + (0 if strong else rank), initial_noise_std_proportion=0.3)
         dl = dl[lo:hi]
-        batch = HeteroBatch.from_data_list(dl).to(dev) if B > 0 else None
         ids = list(range(lo, hi)) if strong else list(range(rank * S, (rank + 1) * S))
+        shards = make_shards(dl, ids) if B > 0 else []
+        if not shards:
+            shards = [dict(model=new_model(), batch=None, ids=[], stream=None, n=0)]
         cap = max(shard_bounds(S, r, world)[1] - shard_bounds(S, r, world)[0] for r in range(world)) if strong else S
         gathered = [torch.empty(cap * n_lig, 3, device=dev) for _ in range(world)] if world > 1 else None
-        jobs.append(dict(model=model, g=g, batch=batch, ids=ids, n_res=n_res, n_lig=n_lig, gathered=gathered, cap=cap))
+        jobs.append(dict(model=shards[0]["model"], shards=shards, g=g, batch=shards[0]["batch"], ids=ids, n_res=n_res, n_lig=n_lig,
+                         gathered=gathered, cap=cap))
+
+    def sample_job(j, seed):
+        """the 20-step loop of every pose shard of one complex; shards on their own streams, enqueued back to back"""
+        live = [sh for sh in j["shards"] if sh["batch"] is not None]
+        if not live:
+            return torch.zeros(0, 3, device=dev)
+        if len(live) == 1 and live[0]["stream"] is None:
+            sh = live[0]
+            return sh["model"].sample_batch(sh["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=seed, sample_ids=sh["ids"],
+                                            no_final_step_noise=True, **TEMP)
+        cur = torch.cuda.current_stream(dev)
+        outs = []
+        for sh in live:
+            sh["stream"].wait_stream(cur)
+            with torch.cuda.stream(sh["stream"]):
+                outs.append(sh["model"].sample_batch(sh["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=seed, sample_ids=sh["ids"],
+                                                     no_final_step_noise=True, **TEMP))
+        for sh, o in zip(live, outs):
+            cur.wait_stream(sh["stream"])
+            o.record_stream(cur)
+        return torch.cat(outs)
 
     def one_step(seed, jobs_=None):
         last = None
         for j in (jobs if jobs_ is None else jobs_):
-            if j["batch"] is not None:
-                pos = j["model"].sample_batch(j["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=seed, sample_ids=j["ids"],
-                                              no_final_step_noise=True, **TEMP)
-            else:
-                pos = torch.zeros(0, 3, device=dev)
+            if True:
+                pos = sample_job(j, seed)
             if world > 1:     # one all_gather per complex: the final coordinates of every pose on every rank
                 buf = pos
                 if pos.shape[0] != j["cap"] * j["n_lig"]:
@@ -305,24 +361,61 @@ def main():
         wjobs = []
         for j in jobs:
             dlw = make_pose_list(j["g"], S, tr_sigma_max=cfg.tr_sigma_max, seed=1000 + rank, initial_noise_std_proportion=0.3)
-            wjobs.append(dict(j, batch=HeteroBatch.from_data_list(dlw).to(dev), ids=list(range(rank * S, (rank + 1) * S)), cap=S,
+            widx = list(range(rank * S, (rank + 1) * S))
+            wsh = [dict(model=j["model"], batch=HeteroBatch.from_data_list(dlw).to(dev), ids=widx, stream=None, n=S)]
+            wjobs.append(dict(j, shards=wsh, batch=wsh[0]["batch"], ids=widx, cap=S,
                               gathered=[torch.empty(S * j["n_lig"], 3, device=dev) for _ in range(world)]))
         one_step(7, wjobs)
         dtw, _ = timed(1, wjobs)
         weak_extra = {"value": world * S * len(jobs) / dtw, "unit": "poses/s", "poses_per_gpu": S * len(jobs), "steps": 1,
                       "note": "weak scaling: every rank samples its own poses (not the BASELINE configs[3] partition)"}
         del wjobs
+    shard_check = None
+    if strong and args.verify_shards:
+        # readiness check of the sharded path (utils/sampling.py:80,91-93: poses are independent trajectories, noise keyed by global
+        # sample id): every rank's gathered block against the SAME block sampled by rank 0 as its own batch.  (Block by block, not
+        # against one batch of all S poses: with the reference's default centre convolution -- fixed_center_conv off,
+        # models/cg_model.py:371-374 indexes the ligand table by GRAPH id -- a pose's score depends on its position in the batch, in
+        # the reference too, so a batch of 40 and eight batches of 5 are different functions.  --fixed-center-conv removes that
+        # dependency; the one-batch comparison is then reported as well.)
+        one_step(4242)
+        torch.cuda.synchronize()
+        if rank == 0:
+            worst, worst_one, blocks = 0.0, None, []
+            mdl = jobs[0]["model"]
+            for j in jobs:
+                dlf = make_pose_list(j["g"], S, tr_sigma_max=cfg.tr_sigma_max, seed=1000, initial_noise_std_proportion=0.3)
+                for r in range(world):
+                    b0, b1 = shard_bounds(S, r, world)
+                    if b1 <= b0:
+                        continue
+                    got = j["gathered"][r][:(b1 - b0) * j["n_lig"]].reshape(b1 - b0, j["n_lig"], 3)
+                    mine = mdl.sample_batch(HeteroBatch.from_data_list(dlf[b0:b1]).to(dev), INFERENCE_STEPS, (sched, sched, sched), seed=4242,
+                                            sample_ids=list(range(b0, b1)), no_final_step_noise=True, **TEMP).reshape(b1 - b0, j["n_lig"], 3)
+                    worst = max(worst, float((got - mine).abs().max()))
+                    blocks.append([b0, b1])
+                if cfg.fixed_center_conv:
+                    full = mdl.sample_batch(HeteroBatch.from_data_list(dlf).to(dev), INFERENCE_STEPS, (sched, sched, sched), seed=4242,
+                                            sample_ids=list(range(S)), no_final_step_noise=True, **TEMP).reshape(S, j["n_lig"], 3)
+                    allg = torch.cat([j["gathered"][r][:(shard_bounds(S, r, world)[1] - shard_bounds(S, r, world)[0]) * j["n_lig"]] for r in range(world)])
+                    worst_one = max(worst_one or 0.0, float((allg.reshape(S, j["n_lig"], 3) - full).abs().max()))
+                mdl.invalidate_complex()
+            shard_check = {"max_abs_diff_vs_same_block_on_rank0_angstrom": worst, "max_abs_diff_vs_one_batch_angstrom": worst_one,
+                           "blocks": blocks[:world], "tolerance_angstrom": 1e-3, "ok": bool(worst <= 1e-3 and (worst_one is None or worst_one <= 1e-3)),
+                           "note": "20-step final ligand coordinates gathered from the ranks vs the same blocks sampled on rank 0 (and, with "
+                                   "--fixed-center-conv, vs all poses in one batch); per-sample Philox streams keyed by global sample id"}
     # one more, untimed step with the per-kernel HIP-event timers on: phase table and kernel-level roofline figures
-    for j in jobs:
-        j["model"].set_kernel_timing(True)
+    all_models = [sh["model"] for j in jobs for sh in j["shards"]]
+    for mdl in all_models:
+        mdl.set_kernel_timing(True)
     one_step(999)
     torch.cuda.synchronize()
     timings = {}
-    for j in jobs:
-        for k, (ms, n) in j["model"].kernel_timings().items():
+    for mdl in all_models:
+        for k, (ms, n) in mdl.kernel_timings().items():
             a = timings.get(k, (0.0, 0))
             timings[k] = (a[0] + ms, a[1] + n)
-        j["model"].set_kernel_timing(False)
+        mdl.set_kernel_timing(False)
     timed_steps = 1                       # steps behind `timings`
     assert os.environ.get("DDMI_BENCH_NOCHECK") or torch.isfinite(pos).all()   # NOCHECK: timing-only ablation builds
 
@@ -330,14 +423,19 @@ def main():
         # edges actually processed by the last forward of the run, per complex
         edges, work = [], []
         for j in jobs:
-            m = j["model"]
-            e_ll, e_lr, e_rr = int(m.debug_buffer("goff_ll")[-1]), int(m.debug_buffer("offs_l")[-1]), int(m.debug_buffer("rr_goff")[-1])
-            edges.append(dict(n_res=j["n_res"], n_lig=j["n_lig"], lig_lig=e_ll, cross_each_direction=e_lr, rec_rec=e_rr,
-                              **({"lig_atom_each_direction": int(m.debug_buffer("offs_la_l")[-1]),
-                                  "atom_atom": int(m.debug_buffer("aa_goff")[-1]),
-                                  "atom_rec_each_direction": int(m.debug_buffer("ar_goff")[-1]),
-                                  "atoms": int(j["batch"]["atom"].pos.shape[0])} if args.all_atoms else {})))
-            work += conv_work(cfg, B * j["n_lig"], B * j["n_res"], e_ll, e_lr, e_rr)
+            tot = dict(lig_lig=0, cross_each_direction=0, rec_rec=0)
+            extra = dict(lig_atom_each_direction=0, atom_atom=0, atom_rec_each_direction=0, atoms=0)
+            for sh in j["shards"]:
+                if sh["batch"] is None:
+                    continue
+                m = sh["model"]
+                e_ll, e_lr, e_rr = int(m.debug_buffer("goff_ll")[-1]), int(m.debug_buffer("offs_l")[-1]), int(m.debug_buffer("rr_goff")[-1])
+                tot["lig_lig"] += e_ll; tot["cross_each_direction"] += e_lr; tot["rec_rec"] += e_rr
+                if args.all_atoms:
+                    extra["lig_atom_each_direction"] += int(m.debug_buffer("offs_la_l")[-1]); extra["atom_atom"] += int(m.debug_buffer("aa_goff")[-1])
+                    extra["atom_rec_each_direction"] += int(m.debug_buffer("ar_goff")[-1]); extra["atoms"] += int(sh["batch"]["atom"].pos.shape[0])
+                work += conv_work(cfg, sh["n"] * j["n_lig"], sh["n"] * j["n_res"], e_ll, e_lr, e_rr)     # one entry per launch
+            edges.append(dict(n_res=j["n_res"], n_lig=j["n_lig"], **tot, **(extra if args.all_atoms else {})))
         n_forwards = timed_steps * INFERENCE_STEPS * len(jobs)                  # forwards behind `timings`
         n_forwards_timed = args.steps * INFERENCE_STEPS * len(jobs)             # forwards inside the timed region
         # ---- roofline of the dominant kernel.  Headline `frac` = the kernel's algorithmic flops of all forwards of the TIMED
@@ -418,7 +516,10 @@ def main():
                 lr_rows = e["cross_each_direction"]
                 try:
                     hdr = j["model"].debug_buffer("prered_tile_hdr")
-                    nvn = int(j["model"].debug_buffer("vn_off_cross")[-1])
+                    try:
+                        nvn = int(j["model"].debug_buffer("vn_count_cross")[0])     # (tile_per_pose: the padded list)
+                    except Exception:
+                        nvn = int(j["model"].debug_buffer("vn_off_cross")[-1])
                     nt_ = (nvn + 15) // 16
                     hdr = hdr[:nt_]
                     pre = hdr[:, 0] != 0
@@ -476,7 +577,7 @@ def main():
                        "parallelism": ("single GPU" if world == 1 else
                                        f"strong: the {S} poses of a complex sharded in blocks over {world} GPUs, 1 all_gather per complex" if strong else
                                        f"weak: {S} poses per GPU x {world} GPUs (pose-sharded, 1 all_gather per complex)")},
-            "roofline": roof, "roofline_scatter": roof_scatter, "cpu_baseline": cpu, "weak_scaling": weak_extra,
+            "roofline": roof, "roofline_scatter": roof_scatter, "cpu_baseline": cpu, "weak_scaling": weak_extra, "shard_check": shard_check,
             "phase_ms_per_forward": {k: v[0] / max(n_forwards, 1) for k, v in timings.items()},
         }
         print(json.dumps(out))

@@ -46,6 +46,7 @@ struct Model::Cx {
   struct VnSet { int vcap = 0; int *cnt = nullptr, *voff = nullptr, *node = nullptr, *e0 = nullptr, *ne = nullptr;
                  float* rows = nullptr;   // per-edge rows of k_conv_fused (k_vn_rows)
                  int* tile_hdr = nullptr; unsigned char* live = nullptr;   // in-tile pre-reduction (launch_vn_tiles): tile headers, rows that get written
+                 int* nvn_pad = nullptr;   // tile_per_pose: length of the list with every graph padded to whole tiles (else voff[gcount])
                  // what the lists and per-edge rows were built from (k_vn_rows bakes target slots, attribute rows, harmonics with
                  // their sign and edge weights in): a group that reuses a list id with any other input rebuilds it
                  const int *built_goff = nullptr, *built_tgt = nullptr, *built_tslot = nullptr, *built_arow = nullptr;
@@ -252,12 +253,20 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
         vr.arow = g.arow; vr.nvec = g.nvec; vr.ew = g.ew; vr.tslot = g.tslot; vr.sgn = g.sgn; vr.sh_lmax = m.cfg.sh_lmax;
         vr.tgt = g.tgt; vr.tbase = g.tbase;
         vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
-        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs);
-        if (g.vn == 0 && c.prered) launch_vn_tiles(vs.voff + g.gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
+        VnPoseTiles pp{};
+        if (vs.nvn_pad) {   // graph of every gather node: ligand / receptor / atom rows of the node table
+          static const char vn_type[9] = {'R', 'R', 'L', 'L', 'A', 'A', 'A', 'L', 'R'};   // gather-node type of every virtual-node list (set_complex)
+          const bool lig = vn_type[g.vn] == 'L', atom = vn_type[g.vn] == 'A';
+          pp.node_batch = lig ? c.lig_batch : atom ? c.atom_batch : c.rec_batch;
+          pp.graph_ptr = lig ? c.lig_ptr : atom ? c.atom_ptr : c.rec_ptr;
+          pp.n_graphs = c.B; pp.nvn_pad = vs.nvn_pad;
+        }
+        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs, vs.nvn_pad ? &pp : nullptr);
+        if (g.vn == 0 && c.prered) launch_vn_tiles(vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
         vs.built_goff = g.goff; vs.epoch = c.epoch; vs.built_tgt = g.tgt; vs.built_tslot = g.tslot; vs.built_arow = g.arow;
         vs.built_nvec = g.nvec; vs.built_ew = g.ew; vs.built_sgn = g.sgn; vs.built_tbase = g.tbase;
       }
-      const int* nvn = vs.voff + g.gcount;
+      const int* nvn = vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount;
       // dense-row loop: groups with >= 20 edges per gather node (both row tiles of every virtual node are multiplied)
       // split-bf16 edge product (ddmi_config.edge_product = 1): the static l <= 1 loops only; other layers keep the f32 route
       const bool bf = m.cfg.edge_product == 1 && !L.fgran_generic && L.maxd <= 3 && m.cfg.sh_lmax <= 1;
@@ -629,6 +638,10 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     for (int i = 0; i < (cfg.all_atoms ? 9 : 4); ++i) {
       Cx::VnSet& vs = c.vn[i];
       vs.vcap = gn_v[i] + ecap_v[i] / 32 + 2;   // a gather node with deg edges: ceil(deg / 32) <= deg / 32 + 1 virtual nodes
+      if (m.tile_per_pose) {                    // every graph padded to whole 16-node tiles
+        vs.vcap += 16 * B;
+        vs.nvn_pad = dalloc<int>(m, i == 0 ? "vn_count_cross" : nullptr, {1}, true);
+      }
       vs.cnt = dalloc<int>(m, nullptr, {gn_v[i] + 1}); vs.voff = dalloc<int>(m, names[i], {gn_v[i] + 1});
       vs.node = dalloc<int>(m, nullptr, {vs.vcap}); vs.e0 = dalloc<int>(m, nullptr, {vs.vcap});
       const int shd = (cfg.sh_lmax + 1) * (cfg.sh_lmax + 1);

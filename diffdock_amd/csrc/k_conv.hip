@@ -142,6 +142,28 @@ __global__ void k_vn_fill(const int* __restrict__ goff, const int* __restrict__ 
   const int v0 = voff[d], n = voff[d + 1] - v0, e0 = goff[d], e1 = goff[d + 1];
   for (int b = 0; b < n; ++b) { vn_node[v0 + b] = d; vn_e0[v0 + b] = min(e0 + 32 * b, e1); }
 }
+// tile_per_pose (ddmi_exec_options): the same lists with every graph of the batch padded to whole 16-node tiles by DEAD virtual
+// nodes (node = the graph's last gather node, no edges), so that no tile of k_conv_fused spans two graphs: which virtual nodes
+// share a tile -- and with it the summation trees inside the tile -- then depends on the graph alone, not on its neighbours in
+// the batch.  graph_ptr: first gather node of every graph (local index), node_batch: graph of every gather node; *nvn_pad = the
+// padded list length.
+__global__ void k_vn_fill_pp(const int* __restrict__ goff, const int* __restrict__ voff, int gcount, const int* __restrict__ node_batch,
+                             const int* __restrict__ graph_ptr, int n_graphs, int* __restrict__ vn_node, int* __restrict__ vn_e0,
+                             int* __restrict__ nvn_pad) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= gcount) return;
+  const int b = node_batch[d];
+  int pad = 0;
+  for (int q = 0; q < b; ++q) { const int n = voff[graph_ptr[q + 1]] - voff[graph_ptr[q]]; pad += ((n + 15) & ~15) - n; }
+  const int v0 = voff[d] + pad, n = voff[d + 1] - voff[d], e0 = goff[d], e1 = goff[d + 1];
+  for (int j = 0; j < n; ++j) { vn_node[v0 + j] = d; vn_e0[v0 + j] = min(e0 + 32 * j, e1); }
+  if (d == graph_ptr[b + 1] - 1) {   // last gather node of its graph: dead virtual nodes up to the tile boundary
+    const int nb = voff[graph_ptr[b + 1]] - voff[graph_ptr[b]];
+    const int padb = ((nb + 15) & ~15) - nb;
+    for (int j = 0; j < padb; ++j) { vn_node[v0 + n + j] = d; vn_e0[v0 + n + j] = e1; }
+    if (b == n_graphs - 1) *nvn_pad = voff[gcount] + pad + padb;
+  }
+}
 // Per-edge rows of the fused kernel, once per forward and edge group (the six layers share the graph): virtual node v, edge
 // row r -> [spherical harmonics (SHD) | edge weight | message row | pad] at stride ES, zero rows behind the node's last edge
 // and for the dead virtual nodes of the last 16-node tile; vn_ne[v] = edges of the virtual node.  The tile prologue of
@@ -182,14 +204,16 @@ __global__ __launch_bounds__(256) void k_vn_rows(VnRowsArgs a) {
   if (r == 0) a.vn_ne[v] = ne;
 }
 void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, const VnRowsArgs& rows_in,
-                     hipStream_t s) {
+                     hipStream_t s, const VnPoseTiles* pp) {
   if (gcount <= 0) return;
   hipLaunchKernelGGL(k_vn_count, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, gcount, cnt_tmp);
   launch_exclusive_scan(cnt_tmp, voff, gcount, s);
-  hipLaunchKernelGGL(k_vn_fill, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, voff, gcount, vn_node, vn_e0);
+  if (pp) hipLaunchKernelGGL(k_vn_fill_pp, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, voff, gcount, pp->node_batch, pp->graph_ptr,
+                             pp->n_graphs, vn_node, vn_e0, pp->nvn_pad);
+  else hipLaunchKernelGGL(k_vn_fill, dim3(cdiv(gcount, 256)), dim3(256), 0, s, goff, voff, gcount, vn_node, vn_e0);
   if (rows_in.rows) {
     VnRowsArgs r = rows_in;
-    r.nvn = voff + gcount; r.vn_node = vn_node; r.vn_e0 = vn_e0; r.goff = goff;
+    r.nvn = pp ? pp->nvn_pad : voff + gcount; r.vn_node = vn_node; r.vn_e0 = vn_e0; r.goff = goff;
     const dim3 grid((unsigned)cdiv(round_up(r.vcap, 16), 8));
     if (r.sh_lmax <= 1) hipLaunchKernelGGL((k_vn_rows<4, 8>), grid, dim3(256), 0, s, r);
     else hipLaunchKernelGGL((k_vn_rows<9, 12>), grid, dim3(256), 0, s, r);
@@ -1830,9 +1854,9 @@ static void launch_conv_fused_k(const FusedConvArgs& a, hipStream_t s) {
   constexpr int GS2 = PACK ? 8 * MAXD + 12 : 4 * MAXD + 8, ES = SHD == 4 ? 8 : SHD + 3, CGN = FC_MAXSLOT * MAXD * SHD;
   int max_local = 0;
   for (int y = 0; y < a.ysplit; ++y) max_local = std::max(max_local, a.gsplit[y + 1] - a.gsplit[y]);
-  if (max_local > FC_MAXG) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: more granules per workgroup than descriptor slots (raise DDMI_FUSED_YS)");
+  if (max_local > FC_MAXG) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: more granules per workgroup than descriptor slots (raise ddmi_config.exec.tile_split)");
   const size_t smem = (size_t)(FC_VN * NC_XS + 2 * FcDim<NBK>::YB + FC_WAVES * 16 * GS2 + FC_WAVES * 2 * 32 * ES + FC_MAXG * FC_GWORDS + FC_MAXG + FC_TILE_NT + max_local * CGN) * sizeof(float);
-  if (smem > 160 * 1024) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: LDS budget exceeded (raise DDMI_FUSED_YS)");
+  if (smem > 160 * 1024) throw Error(DDMI_ERR_CAPACITY, "k_conv_fused: LDS budget exceeded (raise ddmi_config.exec.tile_split)");
   static bool lds_opt_in = false;   // > 64 KB of dynamic LDS per workgroup needs the attribute (once per instantiation)
   if (!lds_opt_in) {
     DDMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused<MAXD, SHD, MODE, NBK, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

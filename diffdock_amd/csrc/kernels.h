@@ -79,8 +79,10 @@ struct VnRowsArgs {
   const int* tgt; int tbase;           // target node of every edge (first node id of the target range)
   int vcap; float* rows; int* vn_ne;   // rows == nullptr: lists only
 };
+// tile_per_pose: pad every graph of the batch to whole 16-node tiles (k_vn_fill_pp); nullptr = dense lists
+struct VnPoseTiles { const int* node_batch; const int* graph_ptr; int n_graphs; int* nvn_pad; };
 void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, const VnRowsArgs& rows,
-                     hipStream_t s);
+                     hipStream_t s, const VnPoseTiles* pp = nullptr);
 // In-tile pre-reduction of the messages (groups whose 16 virtual nodes of a tile send to the same few targets: lig<-rec, where
 // 16 residues address the <= 32 atoms of one ligand).  Per tile a header of FC_TILE_HDR ints: [0] = 1 when the tile's targets
 // span <= 32 consecutive target rows (else the tile stores one message row per edge as before), [1] = first target row,

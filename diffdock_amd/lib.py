@@ -27,20 +27,33 @@ EDGE_PRODUCTS = {"f32": 0, "bf16x4": 1}   # ddmi_config.edge_product (include/dd
 class ExecOptions(C.Structure):   # ddmi_exec_options (include/ddmi.h): all 0 = defaults
     _fields_ = [(n, C.c_int32) for n in ("streams", "dense_rows", "shared_tiles", "packed_granules", "merged_granule", "pre_reduce",
                                          "hidden_mm", "fc1_batch", "tile_split", "tile_split_small", "hidden_grid", "tp_apply",
-                                         "debug")]
+                                         "debug", "tile_per_pose")]
 
 
 # Harness knobs: libddmi.so reads no environment variable; the test / bench harness selects kernel routes through these
-# DDMI_* variables, mapped HERE onto ddmi_config.exec at model creation (INTEGRATION.md has the table).
+# DDMI_* variables, mapped HERE onto ddmi_config.exec at model creation (INTEGRATION.md has the table) -- and ONLY when the
+# harness switch DDMI_HARNESS=1 is set (tests/conftest.py, bench.py and tools/*.sh set it): a stray DDMI_* variable in a
+# production environment changes nothing.
+def harness_enabled() -> bool:
+    return os.environ.get("DDMI_HARNESS") == "1"
+
+
 def _env_int(name):
     v = os.environ.get(name)
-    return None if v is None or v == "" else int(v)
+    if v is None or v == "":
+        return None
+    try:
+        return int(v)
+    except ValueError:
+        raise DdmiError(f"{name}: integer expected, got '{v}'") from None
 
 
 def exec_options_from_env(base=()) -> ExecOptions:
     x = ExecOptions()
     for k, v in dict(base or ()).items():
         setattr(x, k, int(v))
+    if not harness_enabled():
+        return x
     e = _env_int
     if e("DDMI_STREAMS") is not None: x.streams = 1 if e("DDMI_STREAMS") == 1 else 0
     for var, field in (("DDMI_FUSED_DENSE", "dense_rows"), ("DDMI_FUSED_SHARED", "shared_tiles")):   # variable: 1 = default rule, 0 = never, 2 = always
@@ -60,11 +73,13 @@ def exec_options_from_env(base=()) -> ExecOptions:
             raise DdmiError(f"DDMI_TP_APPLY: unknown form '{tp}' (wave | edge | thread | auto)")
         x.tp_apply = {"auto": 0, "wave": 1, "edge": 2, "thread": 3}[tp]
     if os.environ.get("DDMI_DEBUG_GRAN"): x.debug = 1
+    if e("DDMI_TILE_PER_POSE") is not None: x.tile_per_pose = 1 if e("DDMI_TILE_PER_POSE") else 0
     return x
 
 
 class Config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("ns", "nv", "num_conv_layers", "num_prot_emb_layers", "sh_lmax",
+    _fields_ = [("struct_size", C.c_uint32)] + \
+               [(n, C.c_int32) for n in ("ns", "nv", "num_conv_layers", "num_prot_emb_layers", "sh_lmax",
                                          "sigma_embed_dim", "distance_embed_dim", "cross_distance_embed_dim",
                                          "in_lig_edge_features", "lm_embedding_dim")] + \
                [(n, C.c_float) for n in ("lig_max_radius", "rec_max_radius", "cross_max_distance", "center_max_distance")] + \
@@ -99,14 +114,18 @@ class SampleCfg(C.Structure):
 def make_config(cfg) -> Config:
     c = Config()
     for name, _ in Config._fields_:
-        if name == "lm_embedding_dim":
+        if name == "struct_size":
+            c.struct_size = C.sizeof(Config)
+        elif name == "lm_embedding_dim":
             c.lm_embedding_dim = cfg.lm_embedding_dim
         elif name == "old_model":
             c.old_model = int(cfg.old)
         elif name == "embedding_type":
             c.embedding_type = {"sinusoidal": 0, "fourier": 1}[cfg.embedding_type]
         elif name == "edge_product":
-            ep = os.environ.get("DDMI_EDGE_PRODUCT") or cfg.edge_product      # (harness override, see exec_options_from_env)
+            ep = cfg.edge_product      # an explicit cfg.edge_product wins; the harness variable only replaces the default
+            if ep == "f32" and harness_enabled() and os.environ.get("DDMI_EDGE_PRODUCT"):
+                ep = os.environ["DDMI_EDGE_PRODUCT"]
             if ep not in EDGE_PRODUCTS:
                 raise DdmiError(f"edge_product: unknown route '{ep}' (f32 | bf16x4)")
             c.edge_product = EDGE_PRODUCTS[ep]

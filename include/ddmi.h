@@ -39,9 +39,6 @@ enum ddmi_status {
   DDMI_ERR_CAPACITY = -5 /* workspace or neighbour capacity exceeded      */
 };
 
-/* Hyper-parameters: the keyword arguments get_model passes to CGModel
- * (utils/utils.py:234-276, models/cg_model.py:20-31) and the sigma bounds t_to_sigma reads
- * (utils/diffusion_utils.py:28-32).  Booleans are 0/1. */
 /* Execution options: which of the parity-tested kernel routes a model runs.  Every field 0 = the default a caller should
  * keep; the other values exist for the route-agreement tests (tests/test_gpu_parity.py::test_selectable_kernel_paths_agree_on_the_gpu)
  * and for A/B timing.  Read once at ddmi_create; libddmi.so itself reads NO environment variable -- diffdock_amd/lib.py maps
@@ -60,9 +57,18 @@ typedef struct ddmi_exec_options {
   int32_t hidden_grid;      /* workgroups of k_edge_hidden_mm; 0 = 2048                                                              */
   int32_t tp_apply;         /* read-out tensor product: 0 = by launch size, 1 = wave per pair, 2 = workgroup per edge, 3 = thread    */
   int32_t debug;            /* 1 = print the granule list of every interaction layer to stderr at ddmi_commit_weights (tests)         */
+  int32_t tile_per_pose;    /* 1 = the 16-virtual-node tiles of k_conv_fused never span two graphs of the batch (dead virtual nodes
+                             * pad every graph to whole tiles): the arithmetic of a pose then does not depend on the poses batched
+                             * with it -- a sharded run is BIT-identical to the one-batch run.  0 = dense tiles.     */
 } ddmi_exec_options;
 
+/* Hyper-parameters: the keyword arguments get_model passes to CGModel
+ * (utils/utils.py:234-276, models/cg_model.py:20-31) and the sigma bounds t_to_sigma reads
+ * (utils/diffusion_utils.py:28-32).  Booleans are 0/1.
+ * struct_size MUST be sizeof(ddmi_config) of the header the caller was compiled against: the struct is passed by pointer and
+ * grows with the library, so ddmi_create rejects a caller built against another layout instead of reading past its struct. */
 typedef struct ddmi_config {
+  uint32_t struct_size;
   int32_t ns, nv, num_conv_layers, num_prot_emb_layers, sh_lmax;
   int32_t sigma_embed_dim, distance_embed_dim, cross_distance_embed_dim, in_lig_edge_features;
   int32_t lm_embedding_dim; /* 1280 for 'precomputed' ESM2 features, else 0 */

@@ -569,3 +569,46 @@ def test_all_atom_ragged_batch_and_empty_ligand_atom_group(emu_lib):
         assert int(m.debug_buffer("offs_la_l")[-1]) == ref[4]["edge_counts"][2]
         for o, r in zip(out[:3], ref[:3]):
             assert rel_err(o, r) < 1e-4
+
+
+def test_tile_per_pose_makes_shards_bit_identical(emu_lib):
+    """ddmi_exec_options.tile_per_pose: every graph of the batch padded to whole 16-virtual-node tiles, so that which virtual
+    nodes share a tile of k_conv_fused -- hence whether the tile takes the shared-node (4x4x1) contraction and in which order
+    the pre-reduction adds the rows of a target -- depends on the pose alone.  A pose evaluated alone, in a batch of 2 and in
+    a batch of 3 gives BIT-identical scores; with dense tiles (the default) the same comparison is only
+    rounding-level close.  DDL-synth widths; 21 residues x 12 atoms: 21 virtual nodes per pose in the residue-gather groups, so
+    without the option tiles straddle poses.  Also the 2-step device loop, position for position."""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = replace(DDL_SYNTH, num_conv_layers=3, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_max=5.0,
+                  fixed_center_conv=True)     # (the default centre convolution indexes the ligand table by graph id, cg_model.py:371-374)
+    sd = init_state_dict(cfg, seed=3)
+    g = make_complex(seed=2, n_res=21, n_lig=12, lm_dim=0)
+    dl = make_pose_list(g, 3, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.3)
+    assert int(dl[0]["ligand"].edge_mask.sum()) > 0
+
+    def scores(model, lst):
+        b = HeteroBatch.from_data_list(lst)
+        set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+        return [o.clone() for o in model(b)[:3]]
+    pp = make_model(cfg.replace(exec_options=(("tile_per_pose", 1),)), sd, emu_lib)
+    full = scores(pp, dl)
+    R = full[2].numel() // 3
+    for lo, hi in ((0, 1), (1, 3), (2, 3), (0, 2)):
+        part = scores(pp, dl[lo:hi])
+        assert torch.equal(part[0], full[0][lo:hi]) and torch.equal(part[1], full[1][lo:hi]) and torch.equal(part[2], full[2][lo * R:hi * R])
+    # same function as the default route (dense tiles), at rounding distance
+    dense = scores(make_model(cfg, sd, emu_lib), dl)
+    for a_, b_ in zip(full, dense):
+        assert rel_err(a_, b_) < 1e-5
+    b3 = HeteroBatch.from_data_list(dl)
+    set_time(b3, 0.6, 0.6, 0.6, 3)
+    for o, r in zip(full, CGModelOracle(cfg, sd, *tables())(b3)[:3]):
+        assert rel_err(o, r) < 1e-4
+    # device loop: counter-based noise keyed by sample id + per-pose tiles -> identical trajectories
+    sched = get_t_schedule(2)
+    pos = pp.sample_batch(HeteroBatch.from_data_list(dl), 2, (sched, sched, sched), seed=11, sample_ids=[0, 1, 2], no_final_step_noise=True).reshape(3, -1, 3)
+    one = pp.sample_batch(HeteroBatch.from_data_list(dl[1:2]), 2, (sched, sched, sched), seed=11, sample_ids=[1], no_final_step_noise=True).reshape(1, -1, 3)
+    assert torch.equal(one[0], pos[1])

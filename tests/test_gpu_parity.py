@@ -413,3 +413,39 @@ def test_sampling_crops_confidence_graphs_like_the_reference():
     pos = torch.stack([d["ligand"].pos.cpu() for d in out])
     assert (pos - fx["final_pos"]).abs().max() < 2e-3
     assert conf.shape == fx["confidence"].shape and rel_err(conf.cpu(), fx["confidence"]) < 1e-4
+
+
+def test_tile_per_pose_shards_are_bit_identical_at_full_size():
+    """ddmi_exec_options.tile_per_pose: BASELINE configs[2] / configs[3] shapes -- the 40-pose batch against its
+    20 + 20 and 8 x 5 shards, torch.equal on every score, and the 5-step device loop against its shards position for position
+    (noise keyed by global sample id).  fixed_center_conv: with the reference's default a pose's score depends on its graph id."""
+    cfg = DDL_SYNTH.replace(fixed_center_conv=True, exec_options=(("tile_per_pose", 1),))
+    sd = init_state_dict(cfg, seed=1234)
+    m = gpu_model(cfg, sd)
+    B = 40
+    g = make_complex(seed=4, n_res=300, n_lig=30)
+    dl = make_pose_list(g, B, tr_sigma_max=cfg.tr_sigma_max, seed=5, initial_noise_std_proportion=0.6)
+
+    def run(lst):
+        b = HeteroBatch.from_data_list(lst)
+        set_time(b, 0.5, 0.5, 0.5, len(lst))
+        return [o.clone() for o in m(to_gpu(b))[:3]]
+    tr, rot, tor = run(dl)
+    R = tor.numel() // B
+    for n in (20, 5):
+        for lo in range(0, B, n):
+            tr_s, rot_s, tor_s = run(dl[lo:lo + n])
+            assert torch.equal(tr_s, tr[lo:lo + n]) and torch.equal(rot_s, rot[lo:lo + n]) and torch.equal(tor_s, tor[lo * R:(lo + n) * R]), (n, lo)
+    # same function as the dense-tile default, at rounding distance
+    d = gpu_model(cfg.replace(exec_options=()), sd)
+    b = HeteroBatch.from_data_list(dl)
+    set_time(b, 0.5, 0.5, 0.5, B)
+    for x, y in zip(d(to_gpu(b))[:3], (tr, rot, tor)):
+        assert rel_err(x.cpu(), y.cpu()) < 1e-5
+    sched = get_t_schedule(5)
+    full = m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl[:10])), 5, (sched, sched, sched), seed=123, sample_ids=list(range(10)),
+                          no_final_step_noise=True).reshape(10, -1, 3)
+    for lo in (0, 5):
+        part = m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl[lo:lo + 5])), 5, (sched, sched, sched), seed=123,
+                              sample_ids=list(range(lo, lo + 5)), no_final_step_noise=True).reshape(5, -1, 3)
+        assert torch.equal(part, full[lo:lo + 5]), lo

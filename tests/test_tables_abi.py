@@ -108,6 +108,7 @@ def test_harness_variables_map_onto_exec_options(monkeypatch):
             monkeypatch.delenv(k)
     c = L.make_config(TINY)
     assert all(getattr(c.exec, n) == 0 for n, _ in L.ExecOptions._fields_) and c.edge_product == 0
+    monkeypatch.setenv("DDMI_HARNESS", "1")
     monkeypatch.setenv("DDMI_STREAMS", "1"); monkeypatch.setenv("DDMI_FUSED_DENSE", "0"); monkeypatch.setenv("DDMI_FUSED_SHARED", "2")
     monkeypatch.setenv("DDMI_FUSED_PACK", "0"); monkeypatch.setenv("DDMI_FUSED_YS", "3"); monkeypatch.setenv("DDMI_TP_APPLY", "edge")
     monkeypatch.setenv("DDMI_EDGE_PRODUCT", "bf16x4")
@@ -120,3 +121,24 @@ def test_harness_variables_map_onto_exec_options(monkeypatch):
             monkeypatch.delenv(k)
     c = L.make_config(TINY.replace(exec_options=(("streams", 1), ("hidden_grid", 512))))
     assert c.exec.streams == 1 and c.exec.hidden_grid == 512
+
+
+def test_route_variables_need_the_harness_switch(monkeypatch):
+    """A stray DDMI_* variable must not change what a production caller gets: diffdock_amd/lib.py maps the route variables onto
+    ddmi_config only under DDMI_HARNESS=1 (set by tests/conftest.py, bench.py); an explicit cfg.edge_product always wins; a
+    non-integer value is a DdmiError, not a bare ValueError."""
+    from diffdock_amd.config import TINY
+    monkeypatch.setenv("DDMI_EDGE_PRODUCT", "bf16x4")
+    monkeypatch.setenv("DDMI_STREAMS", "1")
+    monkeypatch.setenv("DDMI_FUSED_YS", "3")
+    monkeypatch.delenv("DDMI_HARNESS", raising=False)
+    c = L.make_config(TINY)
+    assert c.edge_product == 0 and c.exec.streams == 0 and c.exec.tile_split == 0
+    monkeypatch.setenv("DDMI_HARNESS", "1")
+    c = L.make_config(TINY)
+    assert c.edge_product == 1 and c.exec.streams == 1 and c.exec.tile_split == 3
+    monkeypatch.setenv("DDMI_EDGE_PRODUCT", "f32")
+    assert L.make_config(TINY.replace(edge_product="bf16x4")).edge_product == 1      # explicit configuration wins
+    monkeypatch.setenv("DDMI_FUSED_YS", "three")
+    with pytest.raises(L.DdmiError):
+        L.make_config(TINY)
