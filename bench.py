@@ -86,6 +86,11 @@ def traffic_from_record(rec, kernel_source=KERNEL_SOURCE):
     return rec["bytes_per_launch"], rec["source"], rec.get("l2_hit_rate")
 
 
+def scatter_traffic_from_record(rec):
+    sc = rec.get("scatter") if traffic_from_record(rec)[0] is not None else None
+    return sc["bytes_per_launch"] if sc else None
+
+
 def bench_cfg():
     return DDL_SYNTH.replace(dynamic_max_cross=False, cross_max_distance=80.0)
 
@@ -116,11 +121,11 @@ def conv_work(cfg, nL, nR, e_ll, e_lr, e_rr):
         d_in, d_out = sum(x.dim for x in parse_irreps(a)), sum(x.dim for x in parse_irreps(b))
         # (gather nodes, target nodes, edges, gather side is receptor)
         groups = [(nL, nL, e_ll, False), (nR, nL, e_lr, True), (nR, nR, e_rr, True), (nL, nR, e_lr, False)]
-        for gcount, tcount, E, rec_gather in (groups if l < L - 1 else groups[:2]):
+        for gi, (gcount, tcount, E, rec_gather) in enumerate(groups if l < L - 1 else groups[:2]):
             H = 3 * cfg.ns
             node_flops, edge_flops = 2.0 * gcount * HK * mac_node, 2.0 * E * HK * NT
             ref_flops = E * (2.0 * (H * H + H * W) + 6.0 * W)
-            out.append({"k_conv_fused": {"flops": node_flops + edge_flops, "ref_flops": ref_flops,
+            out.append({"k_conv_fused": {"flops": node_flops + edge_flops, "ref_flops": ref_flops, "group": gi,
                                          "bytes": gcount * d_in * 4.0 + E * (H * 4.0 + d_out * 4.0)}})
     return out
 
@@ -220,9 +225,11 @@ def main():
                          "stream, enqueued back to back: the layer-boundary phases of one shard (reduce, per-node terms, hidden rows -- "
                          "kernels that cannot fill the chip) overlap the convolution kernels of the others.  Poses are independent "
                          "trajectories (utils/sampling.py:80,91-93); noise is keyed by global sample id, so the poses are the one-batch poses")
-    ap.add_argument("--tile-per-pose", action="store_true",
+    ap.add_argument("--tile-per-pose", dest="tile_per_pose", action="store_true", default=None,
                     help="ddmi_exec_options.tile_per_pose: tiles of k_conv_fused never span two poses -> a pose's arithmetic does not depend on "
-                         "its neighbours in the batch (bit-exact shard invariance)")
+                         "its neighbours in the batch (bit-exact shard invariance).  Default: ON for --gpus N > 1 (measured cost 1.9 %: 148.2 vs "
+                         "151.1 poses/s at 40 poses, profiles/r05_v1_bench_tile_per_pose.json), off at N = 1")
+    ap.add_argument("--no-tile-per-pose", dest="tile_per_pose", action="store_false")
     ap.add_argument("--fixed-center-conv", action="store_true",
                     help="build the model with fixed_center_conv (models/cg_model.py:371-374: the default indexes the ligand table by graph id, "
                          "so a pose's score depends on its position in the batch -- in the reference too)")
@@ -256,6 +263,8 @@ def main():
         cfg = cfg.replace(edge_product=args.edge_product)
     if args.fixed_center_conv:
         cfg = cfg.replace(fixed_center_conv=True)
+    if args.tile_per_pose is None:
+        args.tile_per_pose = world > 1          # sharded runs: every rank's poses as the one-batch run would compute them
     if args.tile_per_pose:
         cfg = cfg.replace(exec_options=tuple(cfg.exec_options) + (("tile_per_pose", 1),))
     sd = init_state_dict(cfg, seed=1234)
@@ -490,16 +499,27 @@ def main():
                 del os.environ["DDMI_STREAMS"]
                 m1.load_state_dict(sd)
                 m1.set_tables(so3_t, tor_t)
-                m1.sample_batch(j["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=7, sample_ids=j["ids"], no_final_step_noise=True, **TEMP)
-                m1.set_kernel_timing(True)
-                m1.sample_batch(j["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=8, sample_ids=j["ids"], no_final_step_noise=True, **TEMP)
+                sh0 = j["shards"][0]      # (with --pose-shards: the first shard's batch -- the launches the roofline's per-launch work describes)
+                m1.sample_batch(sh0["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=7, sample_ids=sh0["ids"], no_final_step_noise=True, **TEMP)
+                m1.set_kernel_timing(True, level=2)       # one row per edge group: k_conv_fused:g0 .. g3
+                m1.sample_batch(sh0["batch"], INFERENCE_STEPS, (sched, sched, sched), seed=8, sample_ids=sh0["ids"], no_final_step_noise=True, **TEMP)
                 torch.cuda.synchronize()
                 t1 = m1.kernel_timings()
-                ms1, n1 = t1[dom]
+                rows = {k: v for k, v in t1.items() if k.startswith(dom)}
+                ms1, n1 = sum(v[0] for v in rows.values()), sum(v[1] for v in rows.values())
                 ach1 = flops / (ms1 / max(n1, 1) * 1e-3) / 1e12
+                names = ["lig-lig", "lig<-rec", "rec-rec", "rec<-lig"]
+                per_group = {}
+                for gi in range(4):
+                    r = rows.get(f"{dom}:g{gi}")
+                    fl = sum(w["flops"] for w in w_dom if w.get("group") == gi) / max(K, 1) / len(jobs)   # per forward of the first shard
+                    if r and r[0] > 0:
+                        per_group[names[gi]] = {"ms_per_forward": r[0] / INFERENCE_STEPS, "launches_per_forward": r[1] // INFERENCE_STEPS,
+                                                "frac": fl * INFERENCE_STEPS / (r[0] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
                 roof["serialised"] = {"avg_launch_ms": ms1 / max(n1, 1), "launches": n1, "achieved": ach1,
                                       "frac": ach1 / MFMA_F32_PEAK_TFLOPS,
-                                      "forward_ms": t1["forward_total"][0] / max(t1["forward_total"][1], 1)}
+                                      "forward_ms": t1["forward_total"][0] / max(t1["forward_total"][1], 1),
+                                      "per_group": per_group}
                 if "k_reduce_bn" in t1:
                     timings.setdefault("k_reduce_bn_serialised", t1["k_reduce_bn"])
                 del m1
@@ -540,8 +560,12 @@ def main():
             ms_s, n_s = timings.get("k_reduce_bn_serialised", timings["k_reduce_bn"])
             per_launch_s = ms_s / max(n_s, 1) * 1e-3
             per_launch_b = sc_bytes / (L_ * len(jobs))
+            sc_traffic = None
+            if os.path.exists(TRAFFIC_RECORD) and args.config == "configs2" and args.samples is None and world == 1 and K == 1:
+                sc_traffic = scatter_traffic_from_record(json.load(open(TRAFFIC_RECORD)))
             roof_scatter = {"kernel": "k_reduce_bn", "bound": "hbm", "achieved": per_launch_b / per_launch_s / 1e9, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": per_launch_b / per_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "unit": "GB/s", "frac": per_launch_b / per_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": sc_traffic,
+                            "traffic_unit": "bytes per launch from the same PMC passes as roofline.traffic (FETCH_SIZE x 2 + WRITE_SIZE)",
                             "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_launch": per_launch_b,
                             "lig_rec_message_rows": prered_rows or None,
                             "alg_definition": "per interaction layer: 4 B x (D_out per message row read -- one per edge, for the pre-reduced "
@@ -572,7 +596,7 @@ def main():
                                    f"{INFERENCE_STEPS} steps x {S} poses per complex, {shape}, cross graph pinned at its upper bound "
                                    f"(static 80 A cutoff), low-temperature SDE, random-init weights",
                        "name": args.config, "poses_per_complex": S, "poses_per_gpu": B * len(jobs), "inference_steps": INFERENCE_STEPS,
-                       "complexes": len(jobs), "edges": edges[0] if len(edges) == 1 else edges,
+                       "complexes": len(jobs), "edges": edges[0] if len(edges) == 1 else edges, "tile_per_pose": bool(args.tile_per_pose),
                        "edges_per_layer": sum(e["lig_lig"] + 2 * e["cross_each_direction"] + e["rec_rec"] for e in edges),
                        "parallelism": ("single GPU" if world == 1 else
                                        f"strong: the {S} poses of a complex sharded in blocks over {world} GPUs, 1 all_gather per complex" if strong else

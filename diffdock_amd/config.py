@@ -76,6 +76,13 @@ class ModelConfig:
     # confidence checkpoint is (`old_confidence_model: true`).  Score and confidence mode; always sh_lmax = 2, one confidence output.
     old: bool = False
     use_old_atom_encoder: bool = True
+    # CGModel.sidechain_predictor (models/cg_model.py:173-178,397-402): o3.Linear on the receptor rows of the last node table ->
+    # 4x0e + 2x1e + 4x0o + 2x1o, even and odd halves summed: the 4th element of the forward tuple, [n_rec, 10]
+    # (get_model: sidechain_loss_weight > 0 or backbone_loss_weight > 0, utils/utils.py:274-275)
+    sidechain_pred: bool = False
+    # TensorProductConvLayer(depthwise=True) in the embedding and interaction layers (models/tensor_layers.py:248-290,324-325;
+    # cg_model.py:124,147,168): an e3nn 'uvu' TensorProduct (one weight per path and input channel) followed by o3.Linear
+    depthwise_convolution: bool = False
     # execution option (ddmi_config.edge_product, not a reference argument): arithmetic of the per-edge product of the
     # interaction layers -- "f32" (exact fp32 chain, default) | "bf16x4" (split-bf16 operands, fp32 accumulation)
     edge_product: str = "f32"
@@ -126,10 +133,11 @@ class ModelConfig:
         d.update(max_radius=self.lig_max_radius, no_batch_norm=not self.batch_norm,
                  no_differentiate_convolutions=not self.differentiate_convolutions,
                  dropout=0.0,
-                 esm_embeddings_path="precomputed" if self.lm_embedding_type else None)
+                 esm_embeddings_path="precomputed" if self.lm_embedding_type else None,
+                 sidechain_loss_weight=1.0 if self.sidechain_pred else 0.0)
         for k in ('fixed_center_conv', 'lm_embedding_type', 'batch_norm', 'differentiate_convolutions',
                   'lig_max_radius', 'rec_max_radius', 'center_max_distance', 'in_lig_edge_features', 'confidence_mode',
-                  'num_confidence_outputs', 'old', 'atom_confidence', 'atom_num_confidence_outputs'):
+                  'num_confidence_outputs', 'old', 'atom_confidence', 'atom_num_confidence_outputs', 'sidechain_pred'):
             d.pop(k)
         if self.num_confidence_outputs > 1:
             d["rmsd_classification_cutoff"] = [2.0 + i for i in range(self.num_confidence_outputs - 1)]
@@ -166,10 +174,12 @@ def config_from_args(args) -> ModelConfig:
         unsupported.append("esm_embeddings_model (on-the-fly language-model embeddings)")
     if get("parallel", 1) not in (1, None):
         unsupported.append("parallel > 1")
-    if get("depthwise_convolution", False):
-        unsupported.append("depthwise_convolution")
-    if get("sidechain_loss_weight", 0) or get("backbone_loss_weight", 0):
-        unsupported.append("sidechain_pred (sidechain_loss_weight / backbone_loss_weight > 0)")
+    if get("depthwise_convolution", False) and get("all_atoms", False):
+        unsupported.append("depthwise_convolution with all_atoms (AAModel asserts it away, models/aa_model.py:39)")
+    sidechain = bool(get("sidechain_loss_weight", 0) and args.sidechain_loss_weight > 0) or \
+        bool(get("backbone_loss_weight", 0) and args.backbone_loss_weight > 0)
+    if sidechain and get("all_atoms", False):
+        unsupported.append("sidechain_pred with all_atoms (AAModel asserts it away, models/aa_model.py:38)")
     if get("include_miscellaneous_atoms", False):
         unsupported.append("include_miscellaneous_atoms")
     if get("tp_weights_layers", 2) < 2:
@@ -184,6 +194,7 @@ def config_from_args(args) -> ModelConfig:
     cut = get("rmsd_classification_cutoff", None)
     acut = get("atom_rmsd_classification_cutoff", None)
     return ModelConfig(
+        sidechain_pred=sidechain, depthwise_convolution=bool(get("depthwise_convolution", False)),
         all_atoms=bool(get("all_atoms", False)),
         num_confidence_outputs=len(cut) + 1 if isinstance(cut, list) else 1,
         atom_confidence=get("atom_confidence_loss_weight", 0.0) > 0.0,

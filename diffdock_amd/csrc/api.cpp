@@ -145,6 +145,15 @@ int ddmi_forward(ddmi_model* h, const float* lig_pos, const float* t_tr, const f
   });
 }
 
+int ddmi_sidechain_pred(ddmi_model* h, float* out, ddmi_stream s) {
+  return guard([&] {
+    DDMI_REQUIRE(h && out, DDMI_ERR_ARG, "null argument");
+    DDMI_REQUIRE(h->m.cfg.sidechain_pred, DDMI_ERR_STATE, "ddmi_sidechain_pred needs a model created with sidechain_pred");
+    DDMI_CHECK_HIP(hipSetDevice(h->m.device));
+    sidechain_pred(h->m, out, (hipStream_t)s);
+  });
+}
+
 int ddmi_confidence(ddmi_model* h, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor,
                     float* conf_out, float* atom_conf_out, ddmi_stream s) {
   return guard([&] {

@@ -39,6 +39,7 @@ struct Model::Cx {
   int *pairrank, *cnt_l, *cnt_r, *offs_l, *offs_r, *g1_tgt, *g1_tslot, *g3_tgt, *g3_tslot, *pbatch;
   float *pdist, *pnvec, *pew, *cross_ea;
   float *HE, *P, *Q; float* msg[4];
+  const float* x_last = nullptr;   // node table behind the last interaction layer of the last forward (sidechain_pred)
   float *HE_b, *P_b, *Q_b, *rowbias_b;   // second scratch set: ligand-gather groups on the side stream
   float *Pg[9] = {}, *Qg[9] = {}, *rbg[9] = {};   // per-group first-layer terms when a layer's GEMMs go out in one launch (run_conv)
   // fused form (k_conv_fused): virtual-node lists of the two receptor-gather topologies (0 = lig<-rec cross, 1 = rec-rec),
@@ -1153,10 +1154,13 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     for (int l = 0; l < Lc; ++l, ++xi) {
       if (l < Lc - 1)
         run_conv(m, m.conv_layers[l], {g_ll, g_lr, g_rr, g_rl}, crop ? c.rg_all_crop : c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s);
-      else run_conv(m, m.conv_layers[l], {g_ll, g_lr}, c.rg_lig, 2, c.X[xi], c.X[xi + 1], 0, nL, s);
+      else run_conv(m, m.conv_layers[l], {g_ll, g_lr}, c.rg_lig, 2, c.X[xi], c.X[xi + 1], 0, cfg.sidechain_pred ? c.N : nL, s);
+      // (sidechain_pred reads the RECEPTOR rows of the last table: in the reference the last layer writes them too -- no message
+      // reaches them, so they are BatchNorm(0) + the padded input row, cg_model.py:345-349 -- the score read-outs only need the ligand rows)
     }
   }
   const float* XL = c.X[xi];
+  c.x_last = XL;
   PhaseTimer t_read(m, "readouts", s);
   if (conf) {   // cg_model.py:353-366: graph-mean of the even (and, from 3 layers on, the odd) scalars -> confidence_predictor
     const int total = cfg.num_conv_layers + cfg.num_prot_emb_layers;
@@ -1183,6 +1187,13 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     return;
   }
   score_readouts(m, XL, lig_pos, t_tr, t_rot, t_tor, tr_out, rot_out, tor_out, s);
+}
+
+// models/cg_model.py:397-402: sidechain_predictor (o3.Linear, folded into one [10][K] matrix at commit) on the receptor rows
+void sidechain_pred(Model& m, float* out, hipStream_t s) {
+  DDMI_REQUIRE(m.has_complex && m.cx->x_last && m.side_Mt, DDMI_ERR_STATE, "ddmi_forward must precede ddmi_sidechain_pred");
+  Cx& c = *m.cx;
+  gemm(c.x_last + (size_t)c.nL * XS, XS, m.side_Mt, m.side_K, nullptr, out, 10, c.nR, 10, m.side_K, 0, s);
 }
 
 // ========================================================================= conformer / sampling

@@ -1411,84 +1411,146 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 #endif
   const int nv_live = min(FC_VN, nvn - v0);
   constexpr bool SHM = MODE == 4;
+  // ---- tile prologue.  Every global request of the tile is in flight before the first dependent use: the one dependent chain is
+  // [virtual node -> gather node -> x row]; granule descriptors, coupling rows, tile header and per-edge rows ride along with it.
+  // (Round 5: the loop form -- descriptor / coupling / x-row copies as load -> LDS-store iterations with runtime trip counts -- was
+  // ~10 dependent round trips, 25-30 k cycles per workgroup = 0.6 ms per forward, profiles/r05_p1_phase_clocks.txt.)
   int dsl[2] = {2 * wave, 2 * wave + 1};   // x-tile / chunk-buffer row of this wave's two virtual nodes
   int xr = lr;                             // the lane's x-tile row in the 16-row forms
   bool sh_tile = false;                    // SHM: at most four distinct gather nodes -> 4-row x tile, 4x4x1 contraction
+  const int xnl = tid >> 5, xj = tid & 31; // x tile: thread = (row, 16-B piece); a row is 40 pieces (XS = 160)
+  int xnd = -1;                            // gather node of x-tile row xnl (-1: zero row)
+  int ndist = 0;
   if constexpr (SHM) {
     // Distinct gather nodes of the tile (virtual nodes of a node are consecutive): slot of virtual node j = number of node
-    // changes up to j.  Every wave derives the same map; the node of every slot goes through wave-private scratch.
+    // changes up to j.  Every wave derives the same map from one request (lane lr <-> virtual node lr).
     const int vv = v0 + lr;
     const int nd_ = vv < nvn ? a.vn_node[vv] : -1;
     const int prev = __shfl(nd_, (lane & 48) + ((lr + 15) & 15));
     const bool first = lr == 0 || (nd_ >= 0 && nd_ != prev);
     const unsigned bal = (unsigned)(__ballot(first) & 0xffffull);
     auto slot_of = [&](int j) { return __popcll((unsigned long long)(bal & ((2u << j) - 1u))) - 1; };
-    xr = slot_of(lr);
-    dsl[0] = DDMI_UNIFORM(slot_of(2 * wave));
-    dsl[1] = DDMI_UNIFORM(slot_of(2 * wave + 1));
-    const int ndist = __popcll((unsigned long long)bal);
+    ndist = __popcll((unsigned long long)bal);
     sh_tile = DDMI_UNIFORM(ndist) <= 4;
     if (sh_tile) {
-      int* wsn = reinterpret_cast<int*>(gscr + wave * 16 * GS2);
-      if (lane < 16 && first) wsn[xr] = nd_;
-      DDMI_WAVE_SYNC();
-      for (int idx = tid; idx < 4 * XS; idx += 64 * FC_WAVES) {
-        const int nl = idx / XS, c = idx - nl * XS;
-        xbuf[nl * NC_XS + c] = nl < ndist ? a.X[(size_t)(a.gbase + wsn[nl]) * XS + c] : 0.f;
-      }
+      xr = slot_of(lr);
+      dsl[0] = DDMI_UNIFORM(slot_of(2 * wave));
+      dsl[1] = DDMI_UNIFORM(slot_of(2 * wave + 1));
+      // node of slot xnl = the virtual node at the xnl-th set bit of the map
+      unsigned bb = bal;
+      int p = 0;
+      for (int q = 0; q <= (xnl & 3); ++q) { p = bb ? __builtin_ctz(bb) : 0; bb &= bb - 1u; }
+      const int nds = __shfl(nd_, (lane & 48) + p);
+      xnd = (xnl < 4 && xnl < ndist) ? nds : -1;
     } else {   // more than four distinct nodes: the tile runs in the 16-row form of mode 3
-      xr = lr; dsl[0] = 2 * wave; dsl[1] = 2 * wave + 1;
+      const int nds = __shfl(nd_, (lane & 48) + (xnl & 15));
+      xnd = xnl < nv_live ? nds : -1;
     }
-  }
-  if (!sh_tile) {
-    for (int idx = tid; idx < FC_VN * XS; idx += 64 * FC_WAVES) {
-      const int nl = idx / XS, c = idx - nl * XS;
-      xbuf[nl * NC_XS + c] = nl < nv_live ? a.X[(size_t)(a.gbase + a.vn_node[v0 + nl]) * XS + c] : 0.f;
-    }
+  } else {
+    if (xnl < nv_live) xnd = a.vn_node[v0 + xnl];
   }
   const int g_begin = a.gsplit[blockIdx.y], g_end = a.gsplit[blockIdx.y + 1];
+  const int n_loc = g_end - g_begin;
   // The granule descriptors are copied to LDS before the first message store: on gfx9-family parts loads and stores share
   // the in-order vmcnt counter, so a descriptor field fetched from global memory AFTER a burst of message stores would wait
   // for every one of them to be acknowledged (the compiler cannot keep the fields in registers across stores that may alias).
-  for (int idx = tid; idx < (g_end - g_begin) * FC_GWORDS; idx += 64 * FC_WAVES)
-    gdesc[idx] = reinterpret_cast<const int*>(a.gran + g_begin)[idx];
-  const FGran* __restrict__ gran_l = reinterpret_cast<const FGran*>(gdesc) - g_begin;   // gran_l[gi], gi in [g_begin, g_end)
-  // Visiting order of the granules, rotated by whole units per workgroup: tiles start together and take equal time, so with
-  // one common order all 256 CUs would issue their message stores (98 KB per tile and granule) in the same microseconds and
-  // then wait for that burst to drain; rotated, the stores of the chip spread over the whole granule period.
-  if (tid < g_end - g_begin) {   // (unit starts and the units of this granule range come with the kernel arguments: no global loads)
-    const int n = g_end - g_begin, nu = a.ucount[blockIdx.y];
-    const int want = DDMI_ABL(a.dbg, 2048) || nu == 0 ? 0 : (int)(blockIdx.x % (unsigned)nu);
-    const int start = nu == 0 ? 0 : a.ustart[a.ufirst[blockIdx.y] + want] - g_begin;
-    gorder[tid] = g_begin + (start + tid) % n;
+  constexpr int GD_IT = (FC_MAXG * FC_GWORDS + 64 * FC_WAVES - 1) / (64 * FC_WAVES);
+  int gd_r[GD_IT];
+  {
+    const int* __restrict__ gsrc = reinterpret_cast<const int*>(a.gran + g_begin);
+#pragma unroll
+    for (int it = 0; it < GD_IT; ++it) {
+      const int idx = tid + 64 * FC_WAVES * it;
+      gd_r[it] = idx < n_loc * FC_GWORDS ? gsrc[idx] : 0;
+    }
   }
   // dense coupling rows of this workgroup's granules (host-built, weights.cpp): cgt[g][s][k'][j]
-  for (int idx = tid; idx < (g_end - g_begin) * CGN; idx += 64 * FC_WAVES) cgt[idx] = a.cgt[(size_t)g_begin * CGN + idx];
+  constexpr bool CG_REG = CGN <= 96;       // l <= 1 kernels: through registers with the other requests; wider tables: plain loop below
+  constexpr int CG_IT = CG_REG ? (FC_MAXG * CGN + 64 * FC_WAVES - 1) / (64 * FC_WAVES) : 1;
+  float cg_r[CG_IT];
+  if constexpr (CG_REG) {
+#pragma unroll
+    for (int it = 0; it < CG_IT; ++it) {
+      const int idx = tid + 64 * FC_WAVES * it;
+      cg_r[it] = idx < n_loc * CGN ? a.cgt[(size_t)g_begin * CGN + idx] : 0.f;
+    }
+  }
   // In-tile pre-reduction (launch_vn_tiles): this tile's targets span <= 32 rows -> every wave sums its message rows per target
   // in LDS, the eight partial sums meet in a fixed order and ONE row per target leaves the tile.
   constexpr bool PRE_OK = (MODE == 0 || MODE == 3) && SHD == 4;
   bool pre = false;
   int pre_t0 = 0, pre_nt = 0;
-  const int* pre_rep = nullptr;
+  int pre_rep_r = -1;
   if constexpr (PRE_OK) {
     if (a.tile_hdr) {
       const int* __restrict__ th = a.tile_hdr + (size_t)blockIdx.x * FC_TILE_HDR;
       pre = DDMI_UNIFORM(th[0]) != 0;
       pre_t0 = DDMI_UNIFORM(th[1]); pre_nt = DDMI_UNIFORM(th[2]);
-      pre_rep = th + 4;
-      if (pre && tid < FC_TILE_NT) prep[tid] = pre_rep[tid];   // (to LDS before the first message store, like the granule descriptors)
+      if (tid < FC_TILE_NT) pre_rep_r = th[4 + tid];
     }
   }
-  (void)pre_t0; (void)pre_nt; (void)pre_rep; (void)prep;
+  (void)pre_t0; (void)pre_nt;
   int vne[2];
   float* gw = gscr + wave * 16 * GS2;
   float* ew_ = escr + wave * 2 * 32 * ES;
-  {   // per-edge rows (harmonics, weight, message row) of the wave's two virtual nodes: prepared by k_vn_rows, one coalesced copy
+  // per-edge rows (harmonics, weight, message row) of the wave's two virtual nodes: prepared by k_vn_rows, one coalesced copy
+  constexpr int ER_IT = 2 * 32 * ES / 4 / 64;
+  static_assert(2 * 32 * ES % 256 == 0, "per-edge rows of a wave are whole 16-B pieces per lane");
+  float4 er_r[ER_IT];
+  {
     const float4* __restrict__ rsrc = reinterpret_cast<const float4*>(a.vrows + (size_t)(v0 + 2 * wave) * 32 * ES);
 #pragma unroll
-    for (int idx = lane; idx < 2 * 32 * ES / 4; idx += 64) reinterpret_cast<float4*>(ew_)[idx] = rsrc[idx];
+    for (int it = 0; it < ER_IT; ++it) er_r[it] = rsrc[lane + 64 * it];
     vne[0] = a.vn_ne[v0 + 2 * wave];
     vne[1] = a.vn_ne[v0 + 2 * wave + 1];
+  }
+  // x rows (behind the node ids)
+  float4 xv0 = make_float4(0.f, 0.f, 0.f, 0.f), xv1 = xv0;
+  if (xnd >= 0) {
+    const float4* __restrict__ xrow = reinterpret_cast<const float4*>(a.X + (size_t)(a.gbase + xnd) * XS);
+    xv0 = xrow[xj];
+    if (xj < XS / 4 - 32) xv1 = xrow[32 + xj];
+  }
+  static_assert(XS % 4 == 0 && XS / 4 > 32 && XS / 4 <= 64 && (NC_XS % 2) == 0, "x tile copy: 40 pieces per row, 8-B aligned LDS rows");
+  // ---- everything to LDS
+#pragma unroll
+  for (int it = 0; it < GD_IT; ++it) {
+    const int idx = tid + 64 * FC_WAVES * it;
+    if (idx < n_loc * FC_GWORDS) gdesc[idx] = gd_r[it];
+  }
+  const FGran* __restrict__ gran_l = reinterpret_cast<const FGran*>(gdesc) - g_begin;   // gran_l[gi], gi in [g_begin, g_end)
+  // Visiting order of the granules, rotated by whole units per workgroup: tiles start together and take equal time, so with
+  // one common order all 256 CUs would issue their message stores (98 KB per tile and granule) in the same microseconds and
+  // then wait for that burst to drain; rotated, the stores of the chip spread over the whole granule period.
+  if (tid < n_loc) {   // (unit starts and the units of this granule range come with the kernel arguments: no global loads)
+    const int n = n_loc, nu = a.ucount[blockIdx.y];
+    const int want = DDMI_ABL(a.dbg, 2048) || nu == 0 ? 0 : (int)(blockIdx.x % (unsigned)nu);
+    const int start = nu == 0 ? 0 : a.ustart[a.ufirst[blockIdx.y] + want] - g_begin;
+    gorder[tid] = g_begin + (start + tid) % n;
+  }
+  if constexpr (CG_REG) {
+#pragma unroll
+    for (int it = 0; it < CG_IT; ++it) {
+      const int idx = tid + 64 * FC_WAVES * it;
+      if (idx < n_loc * CGN) cgt[idx] = cg_r[it];
+    }
+  } else {
+    for (int idx = tid; idx < n_loc * CGN; idx += 64 * FC_WAVES) cgt[idx] = a.cgt[(size_t)g_begin * CGN + idx];
+  }
+  if constexpr (PRE_OK) {
+    if (pre && tid < FC_TILE_NT) prep[tid] = pre_rep_r;   // (to LDS before the first message store, like the granule descriptors)
+  }
+  (void)prep;
+#pragma unroll
+  for (int it = 0; it < ER_IT; ++it) reinterpret_cast<float4*>(ew_)[lane + 64 * it] = er_r[it];
+  if (!(SHM && sh_tile) || xnl < 4) {   // (shared-node tiles keep their distinct nodes in rows 0..3)
+    float* xd = xbuf + xnl * NC_XS + 4 * xj;
+    *reinterpret_cast<float2*>(xd) = make_float2(xv0.x, xv0.y);
+    *reinterpret_cast<float2*>(xd + 2) = make_float2(xv0.z, xv0.w);
+    if (xj < XS / 4 - 32) {
+      *reinterpret_cast<float2*>(xd + 128) = make_float2(xv1.x, xv1.y);
+      *reinterpret_cast<float2*>(xd + 130) = make_float2(xv1.z, xv1.w);
+    }
   }
   __syncthreads();
   const int H = a.HK - 1;
@@ -1663,76 +1725,140 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     const int lr_e = lane_e & 15, lq_e = lane_e >> 4;
     const float* __restrict__ cg = cgt + (gi - g_begin) * CGN;
     float* stg = ybuf + wave * ((2 * FC_YB) / FC_WAVES);   // the chunk buffers are idle during the coupling phase: [16][RS] message rows
-    float* tT = stg + (pre ? FC_TILE_NT * 48 : 16 * 16 * MAXD);   // packed: [16 rows][2 channels][8 slots] accumulators of the tail block
     float* const pw = stg;                                 // pre-reduction: this wave's partial sums [targets of the tile][RS] (instead of the staged rows)
     const bool tri = Gd.shape == 7;                        // merged granule: slot c = output channels 16c .. 16c+15 (dout = 1)
-    const int RS = tri ? 48 : 16 * Gd.dout, L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
+    // (row stride of the staged rows / partial sums: the widest row of the kernel's granules for EVERY granule -- a compile-time
+    // stride keeps the row addressing out of the integer multiplier; scalar blocks then use 16 of the 48 columns)
+    constexpr int RS = 16 * MAXD;
+    const int L = Gd.n_w * Gd.dout, c0 = Gd.o_off + Gd.w0 * Gd.dout;
     const int V = ((c0 | L) & 3) == 0 ? 4 : ((c0 | L) & 1) == 0 ? 2 : 1;
-    if (PRE_OK && pre) {   // partial sums start from zero (RS = 16 or 48 here: whole 16-B pieces)
+    // Round 5: BOTH 16-row tiles of a virtual node go through every phase together (coupling rows -> coupling -> tail block ->
+    // row stores): the phases are wave-local LDS hand-offs whose latency is exposed (all eight waves of the CU are in the same
+    // phase), so two row tiles per hand-off halve the exposures.  Wave-private scratch in the idle chunk buffers, WST floats:
+    //   [0, 1536)    staged rows of row tile 0 | 1 ([16][RS <= 48] each), or the partial sums of the pre-reduction ([<= 32 targets][RS])
+    //   [1536, 2048) tail-block transposes of row tile 0 | 1 (packed granules)
+    //   [2048, ...)  coupling rows of row tile 1 (row tile 0: the wave's gscr rows)
+    // Launches whose chunk buffers are too small for that (4-column-block kernels with a packed granule, l = 2 kernels) keep
+    // the one-row-tile sequence.
+    constexpr int WST = (2 * FC_YB) / FC_WAVES;
+    constexpr bool BATCH_FITS = PACK && WST >= 2048 + 16 * GS2;          // tail blocks included
+    constexpr bool BATCH_FITS_NOTAIL = PACK && WST >= 1536 + 16 * GS2;   // granules without a tail block (classic, merged)
+    float* const gw2 = stg + ((BATCH_FITS || !BATCH_FITS_NOTAIL) ? 2048 : 1536);
+    static_assert(!PACK || FC_TILE_NT * 48 <= 1536, "partial sums of the pre-reduction fit the staged-row area");
+    static_assert(WST - 68 >= (PACK ? (BATCH_FITS ? 2048 + 16 * GS2 : BATCH_FITS_NOTAIL ? 1536 + 16 * GS2 : 1792) : 16 * 16 * MAXD + 256),
+                  "the per-lane dump words of the masked stores lie behind everything else in the wave's scratch");
+    const bool packed_rt = PACK && packed, tri_rt = tri, pre_rt = PRE_OK && pre;
+    // One instance of the coupling phase per granule kind and pre-reduction state (round 5): the wave-uniform tests on them --
+    // per value, per row, per phase in the run-time form -- fold at compile time inside an instance (the epilogue is bound by
+    // its instruction count).  KIND: 0 packed, 1 merged (three scalar channel tiles), 2 scalar block,
+    // 3 vector block, 4 any other output width.  The locals below SHADOW the run-time values of the same name.
+    auto epi_body = [&](auto kindc, auto prec) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kindc)::value;
+    constexpr bool pre = decltype(prec)::value;
+    constexpr bool packed = KIND == 0;
+    const int dout = KIND == 1 || KIND == 2 ? 1 : KIND == 3 ? 3 : Gd.dout;
+    const bool batch2 = !DDMI_ABL(a.dbg, 16384) && (BATCH_FITS || (BATCH_FITS_NOTAIL && !(PACK && packed)));
+    if (PRE_OK && pre) {   // partial sums start from zero
       for (int idx = lane_e; idx < pre_nt * RS / 4; idx += 64) reinterpret_cast<float4*>(pw)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // one message value: staged in the row's place, or added to the partial sum of the row's target
-    auto put = [&](float* __restrict__ p, float v) __attribute__((always_inline)) { if (PRE_OK && pre) *p += v; else *p = v; };
+    // A lane's message values of one row tile: staged in the row's place, or (pre-reduction) ADDED to the partial sum of the
+    // row's target.  The adds of a row tile go out as [all loads][all stores]: within a virtual node every edge has its own
+    // target (a gather node has at most ONE edge to a target in every graph the builders produce: radius graphs, kNN lists and
+    // all-pairs cross graphs hold a pair once), so the addresses of one tile are distinct -- value by value (load, add, store; the compiler must keep possibly
+    // aliasing LDS accesses in order) each of the 12 values paid an LDS round trip.
+    constexpr int NPUT = 4 * MAXD;
+    struct Puts { float* p[NPUT]; float v[NPUT]; bool ok[NPUT]; };
+    // Masked-out values go to a per-lane dump word instead of being branched around: a predicated LDS access costs an exec-mask
+    // save / branch / restore sequence (four scalar instructions) per value, the select costs one v_cndmask.
+    // (One select per ROW on a base pointer, the values at base + k, was tried next: the compiler then keeps the pointer array
+    // in scratch memory and addresses LDS through flat instructions -- 62 instead of 147 poses/s, profiles/r05_e5_ab.txt.)
+    float* const dump = stg + WST - 68 + lane_e;   // (+ 2 floats behind the lane's word for a row's values k = 1, 2: all of it scratch)
+    // entries [row r][k]: rows r < NR, values k < KN of a row (compile time: a scalar block stores ONE value per row, not MAXD
+    // slots of which MAXD - 1 go to the dump word).  SEL: the per-entry select on P.ok; without it the caller has already
+    // pointed the masked ROWS at the dump word (one select per row: P.p[r][k] = (ok_r ? row address : dump) + k).
+    auto flush = [&](Puts& P, auto nrc, auto knc, auto selc) __attribute__((always_inline)) {
+      constexpr int NR = decltype(nrc)::value, KN = decltype(knc)::value;
+      constexpr bool SEL = decltype(selc)::value;
+#define FC_LIVE(i) ((i) / MAXD < NR && (i) % MAXD < KN)
+#pragma unroll
+      for (int i = 0; i < NPUT; ++i) if (SEL && FC_LIVE(i)) P.p[i] = P.ok[i] ? P.p[i] : dump;
+      if (PRE_OK && pre) {
+        float old[NPUT];
+#pragma unroll
+        for (int i = 0; i < NPUT; ++i) if (FC_LIVE(i)) old[i] = *P.p[i];
+#pragma unroll
+        for (int i = 0; i < NPUT; ++i) if (FC_LIVE(i)) *P.p[i] = old[i] + P.v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < NPUT; ++i) if (FC_LIVE(i)) *P.p[i] = P.v[i];
+      }
+#undef FC_LIVE
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using IM = std::integral_constant<int, MAXD>;
+    using SelY = std::true_type;
+    using SelN = std::false_type;
 #pragma unroll
     for (int vi = 0; vi < 2; ++vi) {
       const int ne = vne[vi];
       if (ne == 0 || DDMI_ABL(a.dbg, 32)) continue;
       const float* __restrict__ erow = ew_ + vi * 32 * ES;
+      // ---- phase A: G[row][s][k'] = we_row * sum_j cg[s][k'][j] * sh_row[j] : lane = (edge row, quarter of the slots); the edge weight rides along
+      auto phase_g = [&](int rt, float* __restrict__ gwx) __attribute__((always_inline)) {
+        const int row = lane_e & 15, part = lane_e >> 4, el = 16 * rt + row;
+        float sh[SHD];
+        if constexpr (SHD == 4) {
+          const float4 s4 = *reinterpret_cast<const float4*>(erow + el * ES);
+          sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
+        } else {
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        if (ne <= 16 * rt) break;
-        DDMI_WAVE_SYNC();
-        {   // G[row][s][k'] = we_row * sum_j cg[s][k'][j] * sh_row[j] : lane = (edge row, quarter of the slots); the edge weight rides along
-          const int row = lane_e & 15, part = lane_e >> 4, el = 16 * rt + row;
-          float sh[SHD];
-          if constexpr (SHD == 4) {
-            const float4 s4 = *reinterpret_cast<const float4*>(erow + el * ES);
-            sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < SHD; ++j) sh[j] = erow[el * ES + j];
-          }
-          const float we = erow[el * ES + SHD];
-          auto gval = [&](int s_, int k) __attribute__((always_inline)) {
-            float v = 0.f;
-#pragma unroll
-            for (int j = 0; j < SHD; ++j) v = fmaf(cg[(s_ * MAXD + k) * SHD + j], sh[j], v);
-            return v * we;
-          };
-          if (PACK && packed) {   // slots 2*part (even half, position part) and 2*part + 1 (odd half, position part)
-#pragma unroll
-            for (int k = 0; k < MAXD; ++k) {
-              gw[row * GS2 + 8 * k + part] = gval(2 * part, k);
-              gw[row * GS2 + 8 * k + 4 + part] = gval(2 * part + 1, k);
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < MAXD; ++k)
-              if (k < Gd.dout) gw[row * GS2 + 4 * k + part] = gval(part, k);   // the four slots of (row, k') side by side (scalar blocks: k' = 0 only)
-          }
+          for (int j = 0; j < SHD; ++j) sh[j] = erow[el * ES + j];
         }
-        DDMI_WAVE_SYNC();
-        FC_STAMP(pf, 6);
-        // destination of the lane's four rows 4 lq + r: the staged row, or (pre-reduction) the partial-sum row of its target
+        const float we = erow[el * ES + SHD];
+        auto gval = [&](int s_, int k) __attribute__((always_inline)) {
+          float v = 0.f;
+#pragma unroll
+          for (int j = 0; j < SHD; ++j) v = fmaf(cg[(s_ * MAXD + k) * SHD + j], sh[j], v);
+          return v * we;
+        };
+        if (PACK && packed) {   // slots 2*part (even half, position part) and 2*part + 1 (odd half, position part)
+#pragma unroll
+          for (int k = 0; k < MAXD; ++k) {
+            gwx[row * GS2 + 8 * k + part] = gval(2 * part, k);
+            gwx[row * GS2 + 8 * k + 4 + part] = gval(2 * part + 1, k);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < MAXD; ++k)
+            if (k < dout) gwx[row * GS2 + 4 * k + part] = gval(part, k);   // the four slots of (row, k') side by side (scalar blocks: k' = 0 only)
+        }
+      };
+      // ---- phase B: coupling of the lane's four rows 4 lq + r with their accumulators; destination = the staged row, or
+      // (pre-reduction) the partial-sum row of the row's target
+      auto phase_c = [&](auto rtc, const float* __restrict__ gwx, float* __restrict__ stgx, float* __restrict__ tTx) __attribute__((always_inline)) {
+        constexpr int rt = decltype(rtc)::value;
         float* orow[4]; bool rok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 4 * lq_e + r, el = 16 * rt + row;
-          rok[r] = true; orow[r] = stg + row * RS;
+          rok[r] = true; orow[r] = stgx + row * RS;
           if (PRE_OK && pre) {
             rok[r] = el < ne;
             orow[r] = pw + (rok[r] ? reinterpret_cast<const int*>(erow)[el * ES + 7] - pre_t0 : 0) * RS;
           }
         }
+        Puts P;
         if (PACK && packed) {
           if constexpr (PACK) {
             const int hi = lr_e >> 3, NS = Gd.nslot;
             // pair blocks: lanes lr_e and lr_e + 8 hold the even / odd slots of channel lr_e & 7; their partial sums meet by a row rotate
+            // (one body per packed shape with the block / slot counts at compile time measured 1 % SLOWER: profiles/r05_e7_ab.txt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int row = 4 * lq_e + r;
-              const float* __restrict__ G = gw + row * GS2 + 4 * hi;
-              float m[MAXD];
+              const float* __restrict__ G = gwx + row * GS2 + 4 * hi;
 #pragma unroll
               for (int k = 0; k < MAXD; ++k) {
                 const float4 g4 = *reinterpret_cast<const float4*>(G + 8 * k);
@@ -1741,36 +1867,18 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)   // pair block c: slot 2c + hi (a slot past the last one is a padding column: not read)
                   if (c < NB - 1) v = fmaf(gq[c], 2 * c + hi < NS ? acc[vi][rt][c][r] : 0.f, v);
-                m[k] = v + DDMI_ROW_XOR8(v);
+                P.v[r * MAXD + k] = v + DDMI_ROW_XOR8(v);
               }
-              if (lr_e < 8 && rok[r]) {
+              float* const pr = (lr_e < 8 && rok[r]) ? orow[r] + lr_e * MAXD : dump;   // (packed granules: dout = MAXD = 3)
 #pragma unroll
-                for (int k = 0; k < MAXD; ++k) put(orow[r] + lr_e * MAXD + k, m[k]);   // (packed granules: dout = MAXD = 3)
-              }
+              for (int k = 0; k < MAXD; ++k) P.p[r * MAXD + k] = pr + k;
               // tail block: lane_e lr_e = 2*slot + (channel - 8) -> transposed through LDS
               float tv = 0.f;
 #pragma unroll
               for (int c = 2; c < NBK; ++c) if (c == NB - 1) tv = acc[vi][rt][c][r];
-              tT[row * 16 + (lr_e & 1) * 8 + (lr_e >> 1)] = (lr_e >> 1) < NS ? tv : 0.f;
+              tTx[row * 16 + (lr_e & 1) * 8 + (lr_e >> 1)] = (lr_e >> 1) < NS ? tv : 0.f;
             }
-            DDMI_WAVE_SYNC();
-            if (lane_e < 32) {   // lane_e = (row, channel 8 + wb): all slots of one output channel
-              const int row = lane_e >> 1, wb = lane_e & 1;
-              float* o2 = stg + row * RS; bool ok2 = true;
-              if (PRE_OK && pre) {
-                ok2 = 16 * rt + row < ne;
-                o2 = pw + (ok2 ? reinterpret_cast<const int*>(erow)[(16 * rt + row) * ES + 7] - pre_t0 : 0) * RS;
-              }
-              const float4 ta = *reinterpret_cast<const float4*>(tT + row * 16 + wb * 8), tb = *reinterpret_cast<const float4*>(tT + row * 16 + wb * 8 + 4);
-#pragma unroll
-              for (int k = 0; k < MAXD; ++k) {
-                const float4 ge = *reinterpret_cast<const float4*>(gw + row * GS2 + 8 * k), go_ = *reinterpret_cast<const float4*>(gw + row * GS2 + 8 * k + 4);
-                float v = ge.x * ta.x;           // slots 0, 2, 4, 6 = ge.xyzw; 1, 3, 5, 7 = go_.xyzw; tT holds slot order 0..7
-                v = fmaf(go_.x, ta.y, v); v = fmaf(ge.y, ta.z, v); v = fmaf(go_.y, ta.w, v);
-                v = fmaf(ge.z, tb.x, v); v = fmaf(go_.z, tb.y, v); v = fmaf(ge.w, tb.z, v); v = fmaf(go_.w, tb.w, v);
-                if (8 + wb < Gd.n_w && ok2) put(o2 + (8 + wb) * MAXD + k, v);
-              }
-            }
+            flush(P, I4{}, IM{}, SelN{});
           }
         } else {
           // message value of (row, k') from the lane_e's four slot accumulators
@@ -1781,41 +1889,149 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
             v = fmaf(g4.z, t2, v);
             return fmaf(g4.w, t3, v);
           };
+          // one body per output width: DO = 0 the merged granule (three scalar channel tiles: every slot is
+          // its own output, columns lr, 16 + lr, 32 + lr), 1 scalar blocks, 3 vector blocks (the components of (row, w) side by
+          // side), -1 any other width (l = 2 kernels)
+          auto body = [&](auto doc) __attribute__((always_inline)) {
+            constexpr int DO = decltype(doc)::value;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 4 * lq_e + r;
-            const float* __restrict__ G = gw + row * GS2;
-            const float t0 = acc[vi][rt][0][r], t1 = acc[vi][rt][1][r], t2 = acc[vi][rt][2][r], t3 = acc[vi][rt][3][r];
-            if (!rok[r]) continue;
-            if (tri) {                   // three scalar channel tiles: every slot is its own output
-              const float4 g4 = *reinterpret_cast<const float4*>(G);
-              float* __restrict__ o = orow[r] + lr_e;
-              put(o, g4.x * t0); put(o + 16, g4.y * t1); put(o + 32, g4.z * t2);
-            } else if (Gd.dout == 1) {   // scalar output blocks
-              put(orow[r] + lr_e, couple(G, 0, t0, t1, t2, t3));
-            } else if (Gd.dout == 3) {   // vector output blocks: the three components of (row, w) side by side
-              float* __restrict__ o = orow[r] + lr_e * 3;
-              put(o, couple(G, 0, t0, t1, t2, t3)); put(o + 1, couple(G, 1, t0, t1, t2, t3)); put(o + 2, couple(G, 2, t0, t1, t2, t3));
-            } else {
+            for (int r = 0; r < 4; ++r) {
+              const int row = 4 * lq_e + r;
+              const float* __restrict__ G = gwx + row * GS2;
+              const float t0 = acc[vi][rt][0][r], t1 = acc[vi][rt][1][r], t2 = acc[vi][rt][2][r], t3 = acc[vi][rt][3][r];
+              if constexpr (DO == 0) {
+                const float4 g4 = *reinterpret_cast<const float4*>(G);
+                const float gv[3] = {g4.x * t0, g4.y * t1, g4.z * t2};
 #pragma unroll
-              for (int k = 0; k < MAXD; ++k)
-                if (k < Gd.dout) put(orow[r] + lr_e * Gd.dout + k, couple(G, k, t0, t1, t2, t3));
+                for (int k = 0; k < MAXD; ++k) {
+                  P.ok[r * MAXD + k] = rok[r];
+                  P.p[r * MAXD + k] = orow[r] + lr_e + 16 * k;
+                  P.v[r * MAXD + k] = k < 3 ? gv[k < 3 ? k : 0] : 0.f;
+                }
+              } else if constexpr (DO > 0) {   // one select per row: masked rows point at the dump word
+                float* const pr = rok[r] ? orow[r] + lr_e * DO : dump;
+#pragma unroll
+                for (int k = 0; k < MAXD; ++k) {
+                  P.p[r * MAXD + k] = pr + k;
+                  P.v[r * MAXD + k] = k < DO ? couple(G, k, t0, t1, t2, t3) : 0.f;
+                }
+              } else {
+#pragma unroll
+                for (int k = 0; k < MAXD; ++k) {
+                  const bool live = k < dout;
+                  P.ok[r * MAXD + k] = rok[r] && live;
+                  P.p[r * MAXD + k] = orow[r] + lr_e * dout + k;
+                  P.v[r * MAXD + k] = live ? couple(G, k, t0, t1, t2, t3) : 0.f;
+                }
+              }
             }
+            if constexpr (DO == 0) flush(P, I4{}, I3{}, SelY{});
+            else if constexpr (DO == 3) flush(P, I4{}, I3{}, SelN{});
+            else if constexpr (DO == 1) flush(P, I4{}, I1{}, SelN{});
+            else flush(P, I4{}, IM{}, SelY{});
+          };
+          body(std::integral_constant<int, KIND == 1 ? 0 : KIND == 2 ? 1 : KIND == 3 ? 3 : -1>{});
+        }
+      };
+      // ---- phase B': tail block of a packed granule: lane = (row, channel 8 + wb), all slots of one output channel
+      auto phase_t = [&](int rt, const float* __restrict__ gwx, float* __restrict__ stgx, const float* __restrict__ tTx) __attribute__((always_inline)) {
+        if constexpr (PACK) {
+          if (lane_e < 32) {
+            const int row = lane_e >> 1, wb = lane_e & 1;
+            float* o2 = stgx + row * RS; bool ok2 = true;
+            if (PRE_OK && pre) {
+              ok2 = 16 * rt + row < ne;
+              o2 = pw + (ok2 ? reinterpret_cast<const int*>(erow)[(16 * rt + row) * ES + 7] - pre_t0 : 0) * RS;
+            }
+            ok2 = ok2 && 8 + wb < Gd.n_w;
+            const float4 ta = *reinterpret_cast<const float4*>(tTx + row * 16 + wb * 8), tb = *reinterpret_cast<const float4*>(tTx + row * 16 + wb * 8 + 4);
+            Puts P;
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k) {
+              const float4 ge = *reinterpret_cast<const float4*>(gwx + row * GS2 + 8 * k), go_ = *reinterpret_cast<const float4*>(gwx + row * GS2 + 8 * k + 4);
+              float v = ge.x * ta.x;           // slots 0, 2, 4, 6 = ge.xyzw; 1, 3, 5, 7 = go_.xyzw; tT holds slot order 0..7
+              v = fmaf(go_.x, ta.y, v); v = fmaf(ge.y, ta.z, v); v = fmaf(go_.y, ta.w, v);
+              v = fmaf(ge.z, tb.x, v); v = fmaf(go_.z, tb.y, v); v = fmaf(ge.w, tb.z, v); v = fmaf(go_.w, tb.w, v);
+              P.v[k] = v;
+            }
+            float* const pr = ok2 ? o2 + (8 + wb) * MAXD : dump;
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k) P.p[k] = pr + k;
+            flush(P, I1{}, IM{}, SelN{});
           }
         }
-        DDMI_WAVE_SYNC();
-        FC_STAMP(pf, 7);
+      };
+      // ---- phase C: staged rows -> message rows
+      auto phase_s = [&](int rt, const float* __restrict__ stgx) __attribute__((always_inline)) {
         if (!DDMI_ABL(a.dbg, 256) && !(PRE_OK && pre)) {
           const int nrows = min(16, ne - 16 * rt);
           const float* __restrict__ er = erow + rt * 16 * ES;
           const int accum = DDMI_ABL(a.dbg, 8192) ? 0 : Gd.accumulate;   // (timing-only: later granules of a unit overwrite instead of adding)
-          if (V == 4) fc_store_rows<4>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
-          else if (V == 2) fc_store_rows<2>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
-          else fc_store_rows<1>(stg, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
+          if (V == 4) fc_store_rows<4>(stgx, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
+          else if (V == 2) fc_store_rows<2>(stgx, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
+          else fc_store_rows<1>(stgx, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
+        }
+      };
+      using RT0 = std::integral_constant<int, 0>;
+      using RT1 = std::integral_constant<int, 1>;
+      float* const tT0 = stg + 1536;        // (one-row-tile sequence: both row tiles use the first slots in turn)
+      if (batch2 && ne > 16) {
+        DDMI_WAVE_SYNC();
+        phase_g(0, gw); phase_g(1, gw2);
+        DDMI_WAVE_SYNC();
+        FC_STAMP(pf, 6);
+        phase_c(RT0{}, gw, stg, tT0); phase_c(RT1{}, gw2, stg + 768, tT0 + 256);
+        if (PACK && packed) {
+          DDMI_WAVE_SYNC();
+          phase_t(0, gw, stg, tT0); phase_t(1, gw2, stg + 768, tT0 + 256);
         }
         DDMI_WAVE_SYNC();
+        FC_STAMP(pf, 7);
+        phase_s(0, stg); phase_s(1, stg + 768);
+        DDMI_WAVE_SYNC();
         FC_STAMP(pf, 8);
+      } else {
+        float* const tT1 = (PRE_OK && pre) ? tT0 : stg + 16 * 16 * MAXD;   // (as before round 5: behind the staged rows / the partial sums)
+        DDMI_WAVE_SYNC();
+        phase_g(0, gw);
+        DDMI_WAVE_SYNC();
+        FC_STAMP(pf, 6);
+        phase_c(RT0{}, gw, stg, tT1);
+        if (PACK && packed) { DDMI_WAVE_SYNC(); phase_t(0, gw, stg, tT1); }
+        DDMI_WAVE_SYNC();
+        FC_STAMP(pf, 7);
+        phase_s(0, stg);
+        DDMI_WAVE_SYNC();
+        FC_STAMP(pf, 8);
+        if (ne > 16) {
+          phase_g(1, gw);
+          DDMI_WAVE_SYNC();
+          FC_STAMP(pf, 6);
+          phase_c(RT1{}, gw, stg, tT1);
+          if (PACK && packed) { DDMI_WAVE_SYNC(); phase_t(1, gw, stg, tT1); }
+          DDMI_WAVE_SYNC();
+          FC_STAMP(pf, 7);
+          phase_s(1, stg);
+          DDMI_WAVE_SYNC();
+          FC_STAMP(pf, 8);
+        }
       }
+    }
+    };   // epi_body
+    {
+      using P0 = std::false_type;
+      using P1 = std::true_type;
+      auto run_kind = [&](auto prec) __attribute__((always_inline)) {
+        if constexpr (PACK) {
+          if (packed_rt) { epi_body(std::integral_constant<int, 0>{}, prec); return; }
+          if (tri_rt) { epi_body(std::integral_constant<int, 1>{}, prec); return; }
+        }
+        if (Gd.dout == 1) epi_body(std::integral_constant<int, 2>{}, prec);
+        else if (Gd.dout == 3) epi_body(std::integral_constant<int, 3>{}, prec);
+        else epi_body(std::integral_constant<int, 4>{}, prec);
+      };
+      if constexpr (PRE_OK) { if (pre_rt) run_kind(P1{}); else run_kind(P0{}); }
+      else run_kind(P0{});
     }
     FC_STAMP(pf, 7);
     if (PRE_OK && pre) {   // the eight partial sums of every (target, column), in wave order; one message row per target leaves the tile
@@ -1875,6 +2091,11 @@ void launch_conv_fused(const FusedConvArgs& a_in, hipStream_t s) {
   launch_conv_fused_k<3, 4, 3, 4, true>(a, s);
   return;
 #endif
+  // In-tile pre-reduction contract: k_reduce_bn trusts ReduceGroup.live (it reads only the flagged rows of the group), and only
+  // the MODE 0 / 3 instantiations with l <= 1 rows (PRE_OK in the kernel) honour tile_hdr -- any other route would write one row
+  // per edge while the reducer skips most of them.  set_complex keeps the two in step; a launch that breaks it fails here.
+  if (a.tile_hdr && (a.generic || a.shared || a.maxd > 3 || a.sh_lmax > 1))
+    throw Error(DDMI_ERR_STATE, "k_conv_fused: pre-reduced group routed to a kernel variant without the pre-reducing epilogue");
   // the predicated variant (MODE 1) walks classic 4-slot granules only: a packed / merged granule there would be mis-read
   if (a.generic && a.max_nb > 4) throw Error(DDMI_ERR_ARG, "k_conv_fused: packed granule in a generic layer (weights.cpp builds those layers unpacked)");
   if (a.maxd <= 3 && a.sh_lmax <= 1) {   // the l <= 1 tensor product (FasterTensorProduct structure): static chain shapes, packed granules

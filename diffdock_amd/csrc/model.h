@@ -43,6 +43,7 @@ struct ConvW {  // one TensorProductConvLayer
   Irreps in_irr, sh_irr, out_irr;
   TPTable table;
   int n_edge = 0, H = 0, HK = 0, D_in = 0, D_out = 0, NT = 0, sh_dim = 0, Wn = 0;
+  bool depthwise = false; int Wn_dw = 0, n_lin2 = 0;   // depthwise layer: state-dict sizes of the 'uvu' weights and of linear_2 (folded at commit)
   std::vector<float*> W1, b1, W2, b2, wpack;
   int TL = 2;                                                // Linear layers of the per-edge weight MLP (tp_weights_layers)
   std::vector<std::vector<float*>> Wmid, bmid;               // [group][TL - 2] hidden Linear layers H -> H (TL > 2)
@@ -85,6 +86,7 @@ struct Model {
   Mlp2W old_lig_lin, old_rec_lin;                          // OldAtomEncoder.linear (W0/b0 only)
   float *old_lm_W = nullptr, *old_lm_b = nullptr;          // OldAtomEncoder.lm_embedding_layer [ns][1280 + ns]
   float *tor_W0 = nullptr, *tor_W3 = nullptr;
+  float* side_Mt = nullptr; int side_K = 0;   // sidechain_predictor as one dense [10][side_K] matrix over a node row (weights.cpp)
   float* tor_T = nullptr; int tor_ds = 0, tor_dts = 0;  // FullTensorProduct(sh, 2e) dense table
   float* time_freq = nullptr;
   std::vector<float> time_freq_host;
@@ -138,6 +140,7 @@ void set_complex(Model& m, const ddmi_complex& c, hipStream_t s);
 void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor, float* tr_out,
              float* rot_out, float* tor_out, hipStream_t s, float* conf_out = nullptr, float* atom_conf_out = nullptr);
 void modify_conformer(Model& m, float* lig_pos, const float* tr, const float* rot, const float* tor, hipStream_t s);
+void sidechain_pred(Model& m, float* out, hipStream_t s);   // model(batch)[3] of the last forward (models/cg_model.py:397-402)
 void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s);
 // NaN guard + score / noise combination of step k (utils/sampling.py:117-186) on score arrays, in place
 void perturb(Model& m, float* tr, float* rot, float* tor, const ddmi_sample_cfg& sc, int k, hipStream_t s);

@@ -51,8 +51,46 @@ static int conv_groups(const ddmi_config& c, int l) {
   return l == c.num_conv_layers - 1 ? 2 : 4;
 }
 
+// A depthwise TensorProductConvLayer (models/tensor_layers.py:248-290): instructions (i_in, i_sh, ir_out in ir_in * ir_sh if it
+// occurs in the output irreps), in e3nn's creation order, each with mul_in 'uvu' weights; linear_2 = o3.Linear(irreps_mid.sort()
+// .simplify(), out): per reached output irrep one [rows, mul_out] slot, rows = the instructions' multiplicities stacked in
+// creation order (Irreps.sort is stable), slots in the sorted order of the irreps ((l, p) tuples: odd parity first).
+struct DwIns { int i1, i2, io, mul, w_off, row_base, lin_off; };
+static std::vector<DwIns> depthwise_instructions(const Irreps& in, const Irreps& sh, const Irreps& out, int* n_tp, int* n_lin) {
+  std::vector<DwIns> ins;
+  int off = 0;
+  std::map<std::pair<int, int>, int> rows;   // (l, p) -> rows so far
+  for (int i1 = 0; i1 < (int)in.size(); ++i1)
+    for (int i2 = 0; i2 < (int)sh.size(); ++i2)
+      for (int l = std::abs(in[i1].l - sh[i2].l); l <= in[i1].l + sh[i2].l; ++l) {
+        const int p = in[i1].p * sh[i2].p;
+        int io = -1, hits = 0;
+        for (int o = 0; o < (int)out.size(); ++o) if (out[o].l == l && out[o].p == p) { io = o; ++hits; }
+        if (io < 0) continue;
+        if (hits != 1 || sh[i2].mul != 1) throw Error(DDMI_ERR_ARG, "depthwise layer: repeated output irrep / spherical harmonics with multiplicity");
+        ins.push_back({i1, i2, io, in[i1].mul, off, rows[{l, p}], 0});
+        rows[{l, p}] += in[i1].mul;
+        off += in[i1].mul;
+      }
+  int lin = 0;
+  std::map<int, int> lin_off_of;   // output block -> offset of its linear_2 slot
+  for (auto& kv : rows) {          // std::map iterates (l, p) in tuple order
+    for (int o = 0; o < (int)out.size(); ++o)
+      if (out[o].l == kv.first.first && out[o].p == kv.first.second) { lin_off_of[o] = lin; lin += kv.second * out[o].mul; }
+  }
+  for (auto& q : ins) q.lin_off = lin_off_of[q.io];
+  if (n_tp) *n_tp = off;
+  if (n_lin) *n_lin = lin;
+  return ins;
+}
+
 static void init_conv_meta(const ddmi_config& c, ConvW& L, const std::string& name, const Irreps& in, const Irreps& sh,
                            const Irreps& out, int n_edge, int G, bool faster, bool residual, bool yform) {
+  L.depthwise = c.depthwise_convolution != 0 && yform;   // embedding / interaction layers; the read-out convolutions stay fully connected
+  if (L.depthwise) {   // e3nn semantics (the depthwise branch replaces FasterTensorProduct): the equivalent fully connected table
+    faster = false;
+    depthwise_instructions(in, sh, out, &L.Wn_dw, &L.n_lin2);
+  }
   L.name = name; L.G = G; L.faster = faster; L.residual = residual; L.has_bn = c.batch_norm != 0; L.yform = yform;
   L.in_irr = in; L.sh_irr = sh; L.out_irr = out;
   L.table = faster ? faster_table(in, out) : fctp_table(in, sh, out);
@@ -109,8 +147,9 @@ void build_weight_spec(Model& m) {
       const std::string pre = L.G == 1 ? L.name + ".fc" : L.name + ".fc." + std::to_string(g);
       lin(pre + ".0", L.n_edge, L.H);
       for (int j = 1; j + 1 < L.TL; ++j) lin(pre + "." + std::to_string(3 * j), L.H, L.H);   // FCBlock hidden layers (models/layers.py:14-15)
-      lin(pre + "." + std::to_string(3 * (L.TL - 1)), L.H, L.Wn);
+      lin(pre + "." + std::to_string(3 * (L.TL - 1)), L.H, L.depthwise ? L.Wn_dw : L.Wn);
     }
+    if (L.depthwise) S.push_back({L.name + ".linear_2.weight", {L.n_lin2}});
     if (L.has_bn) bn(L.name + ".batch_norm", L.out_irr);
   };
   const int TL = c.tp_weights_layers <= 0 ? 2 : c.tp_weights_layers;
@@ -244,6 +283,14 @@ void build_weight_spec(Model& m) {
     predictor("confidence_predictor", n_in, c.num_confidence_outputs + (c.affinity_prediction ? 1 : 0));
     return;
   }
+  DDMI_REQUIRE(!(c.depthwise_convolution && (c.all_atoms || c.old_model)), DDMI_ERR_ARG,
+               "depthwise_convolution: CG models of the new class only (AAModel asserts it away, models/aa_model.py:39; get_model(old=True) never passes it)");
+  if (c.sidechain_pred) {   // models/cg_model.py:173-178: o3.Linear(last_out -> 4x0e + 2x1e + 4x0o + 2x1o), one flat weight vector
+    DDMI_REQUIRE(!c.all_atoms, DDMI_ERR_ARG, "sidechain_pred: CG models only (AAModel asserts it away, models/aa_model.py:38)");
+    int n = 0;
+    for (auto& b : last_out) n += b.mul * ((b.l == 0) ? 4 : (b.l == 1) ? 2 : 0);
+    S.push_back({"sidechain_predictor.weight", {n}});
+  }
   readout_spec(last_out);
 }
 
@@ -346,7 +393,32 @@ static void commit_conv(Model& m, ConvW& L) {
       L.Wmid.back().push_back(up(m, pre + "." + std::to_string(3 * j) + ".weight"));
       L.bmid.back().push_back(up(m, pre + "." + std::to_string(3 * j) + ".bias"));
     }
-    const HostTensor &w2 = W(m, last + ".weight"), &b2 = W(m, last + ".bias");
+    const HostTensor &w2s = W(m, last + ".weight"), &b2s = W(m, last + ".bias");
+    HostTensor w2x, b2x;
+    if (L.depthwise) {
+      // fold 'uvu' TensorProduct + linear_2 into the last Linear of the edge MLP of the equivalent fully connected layer:
+      //   W2'[(path, u, w)][k] = W2[(instruction, u)][k] * linear_2[(row_base + u), w]      (likewise the bias)
+      // The e3nn normalisations agree: sqrt(dim_out) (uvu, one instruction per mid block) * rows^-1/2 (linear_2, path_normalization
+      // 'element') = sqrt(dim_out / fan_in) of the fully connected product over the same paths (fan_in = rows).
+      const HostTensor& l2 = W(m, L.name + ".linear_2.weight");
+      const std::vector<DwIns> ins = depthwise_instructions(L.in_irr, L.sh_irr, L.out_irr, nullptr, nullptr);
+      w2x.shape = {L.Wn, H}; w2x.data.assign((size_t)L.Wn * H, 0.f);
+      b2x.shape = {L.Wn}; b2x.data.assign((size_t)L.Wn, 0.f);
+      for (auto& p : L.table.paths) {
+        const DwIns* q = nullptr;
+        for (auto& c_ : ins)
+          if (L.in_irr[c_.i1].off == p.i_off && L.sh_irr[c_.i2].off == p.s_off && c_.io == p.out_block) q = &c_;
+        DDMI_REQUIRE(q && q->mul == p.mul_in, DDMI_ERR_ARG, "depthwise layer: path without an instruction");
+        for (int u = 0; u < p.mul_in; ++u)
+          for (int w = 0; w < p.mul_out; ++w) {
+            const float f = l2.data[(size_t)q->lin_off + (size_t)(q->row_base + u) * p.mul_out + w];
+            const size_t slot = (size_t)p.w_off + (size_t)u * p.mul_out + w, src = (size_t)q->w_off + u;
+            for (int k = 0; k < H; ++k) w2x.data[slot * H + k] = w2s.data[src * H + k] * f;
+            b2x.data[slot] = b2s.data[src] * f;
+          }
+      }
+    }
+    const HostTensor &w2 = L.depthwise ? w2x : w2s, &b2 = L.depthwise ? b2x : b2s;
     if (!L.yform) {
       L.W2.push_back(m.wpool.upload(w2.data));
       L.b2.push_back(m.wpool.upload(b2.data));
@@ -725,6 +797,37 @@ void commit_weights(Model& m) {
   for (auto& L : m.lig_emb_layers) commit_conv(m, L);
   for (auto& L : m.conv_layers) commit_conv(m, L);
   if (!c.confidence_mode) commit_readouts(m);
+  if (c.sidechain_pred && !c.confidence_mode) {
+    // e3nn o3.Linear (e3nn/o3/_linear.py): weight slots [mul_in, mul_out] row-major in the order (i_in, i_out) of the matching
+    // irreps; every slot into an output block is scaled by (sum of mul_in over the slots into that block) ** -0.5.  The read-out
+    // sums the even half (4x0e + 2x1e, 10 columns) and the odd half (4x0o + 2x1o) of the 20 outputs (cg_model.py:402), so the whole
+    // predictor is ONE dense matrix Mt[10][row width] over a node row: column of (w, m) in a half = (l == 0 ? w : 4 + 3 w + m).
+    const Irreps in = layer_irreps(c, c.num_prot_emb_layers + c.num_conv_layers);
+    const int K = irreps_dim(in);
+    const HostTensor& w = W(m, "sidechain_predictor.weight");
+    struct OB { int mul, l, p; };
+    const OB outs[4] = {{4, 0, 1}, {2, 1, 1}, {4, 0, -1}, {2, 1, -1}};
+    std::vector<float> Mt((size_t)10 * K, 0.f);
+    int fan[4] = {0, 0, 0, 0};
+    for (auto& b : in)
+      for (int o = 0; o < 4; ++o) if (b.l == outs[o].l && b.p == outs[o].p) fan[o] += b.mul;
+    size_t off = 0;
+    for (auto& b : in)
+      for (int o = 0; o < 4; ++o) {
+        if (b.l != outs[o].l || b.p != outs[o].p) continue;
+        const float sc = 1.f / std::sqrt((float)fan[o]);
+        const int d = b.d();
+        for (int u = 0; u < b.mul; ++u)
+          for (int ww = 0; ww < outs[o].mul; ++ww) {
+            const float v = w.data[off + (size_t)u * outs[o].mul + ww] * sc;
+            for (int mm = 0; mm < d; ++mm) Mt[(size_t)(b.l == 0 ? ww : 4 + 3 * ww + mm) * K + b.off + u * d + mm] += v;
+          }
+        off += (size_t)b.mul * outs[o].mul;
+      }
+    DDMI_REQUIRE(off == w.data.size(), DDMI_ERR_KEY, "sidechain_predictor.weight: unexpected size");
+    m.side_Mt = m.wpool.upload(Mt);
+    m.side_K = K;
+  }
   // sinusoidal embedding frequencies (utils/diffusion_utils.py:101-103) unless supplied by the caller; 'fourier': the frozen W
   const int half = m.sd / 2;
   if (c.embedding_type == 1) {

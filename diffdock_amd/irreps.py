@@ -134,3 +134,21 @@ def tp_weight_numel(in_irreps, sh, out_irreps, faster) -> int:
     if faster:
         return faster_weight_shapes(in_irreps, out_irreps)[1]
     return fctp_paths(in_irreps, sh, out_irreps)[1]
+
+
+def depthwise_numels(in_irreps: str, sh: str, out_irreps: str) -> Tuple[int, int]:
+    """(weight_numel of the 'uvu' TensorProduct, weight_numel of linear_2) of a depthwise TensorProductConvLayer
+    (models/tensor_layers.py:248-290): one weight per (instruction, u); linear_2 = o3.Linear(irreps_mid.sort().simplify(), out)
+    = one [sum of mul over the instructions into an irrep, mul_out] slot per output irrep that is reached."""
+    A, B, C = parse_irreps(in_irreps), parse_irreps(sh), parse_irreps(out_irreps)
+    rows = {}
+    n_tp = 0
+    for a in A:
+        for b in B:
+            for l in range(abs(a.l - b.l), a.l + b.l + 1):
+                key = (l, a.p * b.p)
+                if any((c.l, c.p) == key for c in C):
+                    rows[key] = rows.get(key, 0) + a.mul
+                    n_tp += a.mul * b.mul
+    n_lin = sum(r * c.mul for key, r in rows.items() for c in C if (c.l, c.p) == key)
+    return n_tp, n_lin

@@ -91,7 +91,7 @@ class Config(C.Structure):
                [("all_atoms", C.c_int32), ("confidence_mode", C.c_int32), ("num_confidence_outputs", C.c_int32),
                 ("old_model", C.c_int32), ("atom_confidence", C.c_int32), ("atom_num_confidence_outputs", C.c_int32),
                 ("affinity_prediction", C.c_int32), ("embedding_type", C.c_int32), ("tp_weights_layers", C.c_int32),
-                ("edge_product", C.c_int32), ("exec", ExecOptions)]
+                ("sidechain_pred", C.c_int32), ("depthwise_convolution", C.c_int32), ("edge_product", C.c_int32), ("exec", ExecOptions)]
 
 
 class Complex(C.Structure):
@@ -149,6 +149,7 @@ _DECLS = {
     "ddmi_set_complex": (C.c_int, [C.c_void_p, C.POINTER(Complex), C.c_void_p]),
     "ddmi_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
     "ddmi_confidence": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p]),
+    "ddmi_sidechain_pred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddmi_set_crop_cutoff": (C.c_int, [C.c_void_p, C.c_float]),
     "ddmi_modify_conformer": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "ddmi_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SampleCfg), C.c_void_p]),

@@ -37,13 +37,20 @@ def time_frequencies(sigma_embed_dim: int) -> torch.Tensor:
 
 
 def _mask_fingerprint(mr):
+    """Key of the rotatable-bond masks (numpy arrays / tensors, possibly a list per graph).  Host arrays are keyed by CONTENT (an
+    id() can be recycled after the old list is collected, and in-place edits leave it unchanged; hashing them is a host-side
+    memcpy).  DEVICE tensors are keyed by (storage address, in-place version counter, shape): hashing their content would put a
+    blocking device-to-host copy in front of every forward of the step-wise loop."""
     import hashlib
     import numpy as np
     if mr is None:
         return None
     h = hashlib.sha1()
     for a in (mr if isinstance(mr, (list, tuple)) else [mr]):
-        a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+        if torch.is_tensor(a) and a.device.type != "cpu":
+            h.update(repr((a.data_ptr(), 0 if a.is_inference() else a._version, tuple(a.shape), str(a.dtype))).encode())
+            continue
+        a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
         h.update(str(a.shape).encode())
         h.update(np.ascontiguousarray(a).view(np.uint8).tobytes() if a.size else b"")
     return h.hexdigest()
@@ -91,8 +98,12 @@ class MIScoreModel:
         expected = self.expected_keys()
         # e3nn keeps constant buffers under *.tp.* / final_tp_tor.* in real checkpoints, and nn.BatchNorm1d (confidence
         # predictors, cg_model.py:184-207) its `num_batches_tracked` step counter: neither is a weight
+        # ... e3nn's o3.Linear registers an `output_mask` buffer (and an empty `bias`) next to `weight`; a confidence-mode module
+        # built with sidechain_pred owns a sidechain_predictor its forward never calls (cg_model.py:173-178 vs 353-366)
         given = {k: v for k, v in sd.items() if ".tp." not in k and not k.startswith("final_tp_tor.")
-                 and not k.endswith("num_batches_tracked")}
+                 and not k.endswith("num_batches_tracked") and not k.endswith(".output_mask")
+                 and not (k.endswith((".linear_2.bias", "sidechain_predictor.bias")) and v.numel() == 0)
+                 and not (self.cfg.confidence_mode and k.startswith("sidechain_predictor."))}
         missing = [k for k in expected if k not in given]
         unexpected = [k for k in given if k not in expected]
         if strict and (missing or unexpected):
@@ -234,7 +245,11 @@ class MIScoreModel:
                                                    _ptr(rot), None if no_tor else _ptr(tor), self._stream()))
         if self.cfg.old:   # the legacy class returns a 3-tuple (old_cg_model.py:329,352)
             return tr, rot, tor
-        return tr, rot, tor, None
+        side = None
+        if self.cfg.sidechain_pred:   # models/cg_model.py:397-402: [n_rec, 10]
+            side = torch.empty(int(data["receptor"].pos.shape[0]), 10, device=dev)
+            _lib.check(self.lib, self.lib.ddmi_sidechain_pred(self._h, _ptr(side), self._stream()))
+        return tr, rot, tor, side
 
     forward = __call__
 
@@ -351,6 +366,7 @@ def get_model(args, device, t_to_sigma=None, no_parallel=True, confidence_mode=F
         if cfg.all_atoms:
             raise NotImplementedError("the legacy classes are built on CG graphs only (models/old_cg_model.py)")
         cfg = cfg.replace(old=True, confidence_mode=bool(confidence_mode), sh_lmax=2, num_prot_emb_layers=0,
+                          depthwise_convolution=False, sidechain_pred=False,   # (not among the arguments get_model(old=True) passes, utils/utils.py:180-219)
                           reduce_pseudoscalars=False, num_confidence_outputs=1,
                           use_old_atom_encoder=getattr(args, "use_old_atom_encoder", True) if not isinstance(args, ModelConfig)
                           else cfg.use_old_atom_encoder)

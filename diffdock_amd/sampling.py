@@ -47,6 +47,9 @@ def crop_beyond(graph, cutoff, all_atoms=False):
     model runs on the device instead (ddmi_set_crop_cutoff)."""
     lig, rec = graph["ligand"].pos, graph["receptor"].pos
     keep = torch.any(torch.sum((lig.unsqueeze(0) - rec.unsqueeze(1)) ** 2, -1) < cutoff ** 2, dim=1)
+    if not bool(keep.any()):
+        raise ValueError(f"crop_beyond({cutoff}) removes every residue of '{getattr(graph, 'name', '?')}': the ligand is farther than "
+                         f"the cutoff from the whole receptor (an empty receptor graph cannot be scored)")
 
     def sub_graph(mask, edge_index):
         ok = mask[edge_index[0]] & mask[edge_index[1]]

@@ -13,7 +13,7 @@ from typing import Dict, Tuple
 import torch
 
 from .config import ModelConfig, LIG_FEATURE_DIMS, LM_EMBEDDING_DIM, REC_RESIDUE_FEATURE_DIMS, REC_ATOM_FEATURE_DIMS
-from .irreps import parse_irreps, irreps_num, sh_irreps, full_tp_irreps, tp_weight_numel
+from .irreps import parse_irreps, irreps_num, sh_irreps, full_tp_irreps, tp_weight_numel, depthwise_numels
 
 
 def tor_sh_irreps(cfg: ModelConfig) -> str:
@@ -60,6 +60,10 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
 
     def conv(name, in_irr, sh, out_irr, n_edge, hidden, groups, faster, deep=False):
         W = tp_weight_numel(in_irr, sh, out_irr, faster)
+        dw = deep and cfg.depthwise_convolution      # embedding / interaction layers (cg_model.py:124,147,168), not the read-out convolutions
+        if dw:   # 'uvu' TensorProduct weights per edge + the shared linear_2 (models/tensor_layers.py:248-290)
+            W, n_lin = depthwise_numels(in_irr, sh, out_irr)
+            spec[f"{name}.linear_2.weight"] = ((n_lin,), "o3lin")
         for g in range(groups):
             pre = f"{name}.fc" if groups == 1 else f"{name}.fc.{g}"
             tl = cfg.tp_weights_layers if deep else 2   # FCBlock(..., tp_weights_layers, ...) (models/layers.py:10-17): keys 0, 3, .. 3(tl-1)
@@ -124,6 +128,9 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...]
             n_in = ns
         predictor("confidence_predictor", n_in, cfg.num_confidence_outputs + (1 if cfg.affinity_prediction else 0))
         return spec
+    if cfg.sidechain_pred:   # o3.Linear(last_out -> 4x0e + 2x1e + 4x0o + 2x1o): one flat `weight` (models/cg_model.py:173-178)
+        tgt = {(0, 1): 4, (1, 1): 2, (0, -1): 4, (1, -1): 2}
+        spec["sidechain_predictor.weight"] = ((sum(x.mul * tgt.get((x.l, x.p), 0) for x in parse_irreps(last_out)),), "o3lin")
     _readout_spec(cfg, spec, lin, mlp, conv, last_out, sh)
     return spec
 
@@ -222,6 +229,8 @@ def init_state_dict(cfg: ModelConfig, seed: int = 1234, dtype=torch.float32) -> 
             sd[key] = (U(shape, 0.5) + 1.0)
         elif kind == "bn_b":
             sd[key] = U(shape, 0.2)
+        elif kind == "o3lin":         # e3nn o3.Linear internal weights: torch.randn(weight_numel)
+            sd[key] = torch.randn(shape, generator=g, dtype=torch.float64).to(dtype)
         elif kind == "fourier_w":     # torch.randn(embedding_size // 2) * scale
             sd[key] = (torch.randn(shape, generator=g, dtype=torch.float64) * cfg.embedding_scale).to(dtype)
         else:

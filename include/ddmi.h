@@ -96,6 +96,17 @@ typedef struct ddmi_config {
   /* FCBlock depth of the per-edge weight MLP of the embedding / interaction layers (models/layers.py:10-17,
    * tensor_layers.py:302-304): 2 (or 0) = Linear, ReLU, Linear; n > 2 adds n - 2 hidden Linear + ReLU (keys fc.3 .. fc.3(n-1)) */
   int32_t tp_weights_layers;
+  /* CGModel.sidechain_predictor (models/cg_model.py:173-178,397-402; get_model: sidechain_loss_weight > 0 or backbone_loss_weight > 0,
+   * utils/utils.py:274-275): an e3nn o3.Linear on the receptor rows of the last node table -> 4x0e + 2x1e + 4x0o + 2x1o, even and
+   * odd halves summed -- the 4th element of the forward tuple.  State-dict key `sidechain_predictor.weight`; read with
+   * ddmi_sidechain_pred after ddmi_forward.  CG models only (AAModel asserts it away, models/aa_model.py:38). */
+  int32_t sidechain_pred;
+  /* TensorProductConvLayer(depthwise=True) in the embedding and interaction layers (models/tensor_layers.py:248-290,324-325;
+   * cg_model.py:124,147,168): an e3nn 'uvu' TensorProduct (one per-edge weight per path and input channel) followed by the shared
+   * o3.Linear `linear_2`.  Both stages are linear in the weights, so at ddmi_commit_weights the pair is folded into the second
+   * layer of the per-edge MLP of an equivalent fully connected tensor product (W2'[(path, u, w)] = W2[(path, u)] * linear_2[u, w];
+   * the two e3nn normalisations multiply to the fully connected one) and the layer runs the same kernels.  CG models only. */
+  int32_t depthwise_convolution;
   /* ---- execution options (not arguments of the reference's get_model; 0 = default).
    * edge_product: arithmetic of the per-edge product T_e = h_e . Y_d in the interaction layers (k_conv_fused):
    *   0 = v_mfma_f32_16x16x4_f32, an exact fp32 fma chain (the headline route);
@@ -184,6 +195,10 @@ int ddmi_set_complex(ddmi_model* m, const ddmi_complex* c, ddmi_stream stream);
  * lig_pos [n_lig,3]; t_* [B] = batch.complex_t[...]; outputs tr [B,3], rot [B,3], tor [n_tor]. */
 int ddmi_forward(ddmi_model* m, const float* lig_pos, const float* t_tr, const float* t_rot, const float* t_tor,
                  float* tr_out, float* rot_out, float* tor_out, ddmi_stream stream);
+
+/* sidechain_pred = model(batch)[3] -- models/cg_model.py:397-402 -- of the LAST ddmi_forward call on this handle:
+ * out [n_rec, 10].  Requires ddmi_config.sidechain_pred. */
+int ddmi_sidechain_pred(ddmi_model* m, float* out, ddmi_stream stream);
 
 /* confidence, atom_confidence = confidence_model(batch) -- utils/sampling.py:221, models/cg_model.py:353-366 /
  * models/aa_model.py:431-452.  Requires ddmi_config.confidence_mode.  t_* are used raw (sampling() passes 0).

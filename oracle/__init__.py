@@ -9,7 +9,9 @@ What it is: a pure-torch (CPU, fp32 or fp64) restatement of the reference path
 
   oracle/e3nn_lite.py   e3nn==0.5.x pieces the path uses (NOT vendored in the
                         reference): Irreps, wigner_3j, spherical_harmonics,
-                        FullyConnectedTensorProduct, FullTensorProduct, BatchNorm
+                        FullyConnectedTensorProduct, FullTensorProduct, BatchNorm,
+                        o3.Linear and the 'uvu' o3.TensorProduct (round 5: sidechain_pred,
+                        depthwise convolutions)
   oracle/graph_ops.py   torch-cluster 1.6 radius / radius_graph, torch-scatter scatter
   oracle/layers.py      models/layers.py + models/tensor_layers.py
   oracle/cg_model.py    models/cg_model.py (CGModel forward)

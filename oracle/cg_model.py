@@ -49,7 +49,8 @@ class CGModelOracle:
         self.sh_irreps = Irreps.spherical_harmonics(c.sh_lmax)
         K, L = c.num_prot_emb_layers, c.num_conv_layers
         mk = lambda name, i, groups: TPConv(sd, name, *self._io(i), residual=True, batch_norm=c.batch_norm,
-                                            faster=c.faster, edge_groups=groups, tp_weights_layers=c.tp_weights_layers)
+                                            faster=c.faster, edge_groups=groups, tp_weights_layers=c.tp_weights_layers,
+                                            depthwise=c.depthwise_convolution)
         self.rec_emb_layers = [mk(f"rec_emb_layers.{i}", i, 1) for i in range(K)]
         self.lig_emb_layers = [mk(f"lig_emb_layers.{i}", i, 1) for i in range(K)] if c.embed_also_ligand else []
         self.conv_layers = [mk(f"conv_layers.{l}", K + l, c.conv_groups(l)) for l in range(L)]
@@ -255,9 +256,17 @@ class CGModelOracle:
         if c.confidence_mode:
             out = self._confidence(data, lig_node_attr)
             return out + (inter,) if return_intermediates else out
-        return self._readouts(data, lig_node_attr, tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates)
+        sidechain = None
+        if c.sidechain_pred:   # cg_model.py:397-402: o3.Linear on the receptor rows, even and odd halves summed
+            from .e3nn_lite import Linear
+            lin = Linear(c.layer_irreps(c.num_prot_emb_layers + c.num_conv_layers - 1)[1], "4x0e + 2x1e + 4x0o + 2x1o")
+            lin.weight.data = sd["sidechain_predictor.weight"].to(self.dtype)
+            with torch.no_grad():
+                sp = lin(node_attr[n_lig:])
+            sidechain = sp[:, :10] + sp[:, 10:]
+        return self._readouts(data, lig_node_attr, tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates, sidechain)
 
-    def _readouts(self, data, lig_node_attr, tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates):
+    def _readouts(self, data, lig_node_attr, tr_sigma, rot_sigma, tor_sigma, inter, return_intermediates, sidechain=None):
         """Centre convolution, score heads, torsion convolution (cg_model.py:368-424 == aa_model.py:438-484)."""
         c, sd, ns = self.cfg, self.sd, self.cfg.ns
         lig = data["ligand"]
@@ -279,7 +288,7 @@ class CGModelOracle:
             inter["global_pred"] = global_pred
 
         if c.no_torsion or int(lig.edge_mask.sum()) == 0:
-            out = (tr_pred, rot_pred, torch.empty(0, dtype=self.dtype), None)
+            out = (tr_pred, rot_pred, torch.empty(0, dtype=self.dtype), sidechain)
             return out + (inter,) if return_intermediates else out
 
         pos = lig.pos.to(self.dtype)
@@ -298,5 +307,5 @@ class CGModelOracle:
         edge_sigma = tor_sigma[lig.batch][data["ligand", "ligand"].edge_index[0]][lig.edge_mask]
         if c.scale_by_sigma:
             tor_pred = tor_pred * torch.sqrt(torch.tensor(torus_score_norm(self.torus_table, edge_sigma)).float()).to(self.dtype)
-        out = (tr_pred, rot_pred, tor_pred, None)
+        out = (tr_pred, rot_pred, tor_pred, sidechain)
         return out + (inter,) if return_intermediates else out

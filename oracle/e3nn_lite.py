@@ -359,3 +359,93 @@ def batch_norm_eval(irreps, x, running_mean, running_var, weight, bias, eps=1e-5
         iv += mi.mul
         out.append(f.reshape(N, mi.mul * d))
     return torch.cat(out, -1)
+
+
+# ------------------------------------------------------------------ o3.Linear / o3.TensorProduct('uvu')
+def simplify(irreps):
+    """Irreps.simplify(): adjacent entries of the same irrep merged (no sort)."""
+    out = []
+    for mi in Irreps(irreps):
+        if out and out[-1][1] == mi.ir:
+            out[-1] = (out[-1][0] + mi.mul, mi.ir)
+        elif mi.mul > 0:
+            out.append((mi.mul, mi.ir))
+    return Irreps(out)
+
+
+Irreps.simplify = lambda self: simplify(self)
+
+
+class Linear(torch.nn.Module):
+    """o3.Linear(irreps_in, irreps_out, internal_weights=True, shared_weights=True), no biases (e3nn/o3/_linear.py).
+
+    Reference call sites: CGModel.sidechain_predictor (models/cg_model.py:173-178,401) and the second stage of a depthwise
+    TensorProductConvLayer (models/tensor_layers.py:281-290,324-325).
+    Instructions (weight slots, [mul_in, mul_out] row-major, in this order): for i_in in irreps_in, for i_out in irreps_out if the
+    irreps agree.  path_normalization='element': every slot into output block i_out is scaled by
+    (sum of mul_in over the slots into i_out) ** -0.5.  out[i_out][w, m] += scale * sum_u W[u, w] x[i_in][u, m]."""
+
+    def __init__(self, irreps_in, irreps_out, internal_weights=True, shared_weights=True, **kw):
+        super().__init__()
+        assert internal_weights and shared_weights and not kw.get("biases", False)
+        self.irreps_in, self.irreps_out = Irreps(irreps_in), Irreps(irreps_out)
+        self.instructions = [(i, o) for i, a in enumerate(self.irreps_in) for o, b in enumerate(self.irreps_out) if a.ir == b.ir]
+        fan = {}
+        for i, o in self.instructions:
+            fan[o] = fan.get(o, 0) + self.irreps_in[i].mul
+        self.scales = [fan[o] ** -0.5 for _, o in self.instructions]
+        self.weight_numel = sum(self.irreps_in[i].mul * self.irreps_out[o].mul for i, o in self.instructions)
+        self.weight = torch.nn.Parameter(torch.randn(self.weight_numel))
+
+    def forward(self, x):
+        N = x.shape[0]
+        si = self.irreps_in.slices()
+        outs = [x.new_zeros(N, mi.mul, mi.ir.dim) for mi in self.irreps_out]
+        off = 0
+        for (i, o), sc in zip(self.instructions, self.scales):
+            a, b = self.irreps_in[i], self.irreps_out[o]
+            W = self.weight[off:off + a.mul * b.mul].reshape(a.mul, b.mul).to(x.dtype)
+            off += a.mul * b.mul
+            outs[o] = outs[o] + sc * torch.einsum("uw,num->nwm", W, x[:, si[i]].reshape(N, a.mul, a.ir.dim))
+        return torch.cat([t.reshape(N, mi.dim) for t, mi in zip(outs, self.irreps_out)], -1)
+
+
+class TensorProduct(torch.nn.Module):
+    """o3.TensorProduct(in1, in2, out, instructions, shared_weights=False, internal_weights=False) for the 'uvu' connection mode
+    with trainable paths -- what a depthwise TensorProductConvLayer builds (models/tensor_layers.py:248-279): one weight per
+    (path, u) [mul_in2 is 1 for spherical harmonics], weight slots in instruction order, [mul1, mul2] row-major.
+    irrep_normalization='component', path_normalization='element' (e3nn/o3/_tensor_product/_tensor_product.py):
+        coeff = sqrt((2 l_out + 1) / sum over the instructions into the same output block of mul2)
+    out[i_out][u, k] += coeff * sum_{v, i, j} W[u, v] x1[u, i] x2[v, j] w3j(l1, l2, l_out)[i, j, k]"""
+
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, instructions, shared_weights=False, internal_weights=False):
+        super().__init__()
+        assert not shared_weights and not internal_weights
+        self.irreps_in1, self.irreps_in2, self.irreps_out = Irreps(irreps_in1), Irreps(irreps_in2), Irreps(irreps_out)
+        self.instructions = []
+        for ins in instructions:
+            i1, i2, io, mode, train = ins[:5]
+            assert mode == "uvu" and train
+            assert self.irreps_in1[i1].mul == self.irreps_out[io].mul
+            self.instructions.append((i1, i2, io))
+        fan = {}
+        for i1, i2, io in self.instructions:
+            fan[io] = fan.get(io, 0) + self.irreps_in2[i2].mul
+        self.coeffs = [math.sqrt(self.irreps_out[io].ir.dim / fan[io]) for _, _, io in self.instructions]
+        self.slot_shapes = [(self.irreps_in1[i1].mul, self.irreps_in2[i2].mul) for i1, i2, _ in self.instructions]
+        self.weight_numel = sum(a * b for a, b in self.slot_shapes)
+
+    def forward(self, x1, x2, weight):
+        E = x1.shape[0]
+        s1, s2 = self.irreps_in1.slices(), self.irreps_in2.slices()
+        outs = [x1.new_zeros(E, mi.mul, mi.ir.dim) for mi in self.irreps_out]
+        off = 0
+        for (i1, i2, io), c, (m1, m2) in zip(self.instructions, self.coeffs, self.slot_shapes):
+            a, b, o = self.irreps_in1[i1], self.irreps_in2[i2], self.irreps_out[io]
+            W = weight[:, off:off + m1 * m2].reshape(E, m1, m2)
+            off += m1 * m2
+            X1 = x1[:, s1[i1]].reshape(E, m1, a.ir.dim)
+            X2 = x2[:, s2[i2]].reshape(E, m2, b.ir.dim)
+            C = wigner_3j(a.ir.l, b.ir.l, o.ir.l, dtype=x1.dtype)
+            outs[io] = outs[io] + c * torch.einsum("euv,eui,evj,ijk->euk", W, X1, X2, C)
+        return torch.cat([t.reshape(E, mi.dim) for t, mi in zip(outs, self.irreps_out)], -1)

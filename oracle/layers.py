@@ -117,12 +117,30 @@ class TPConv:
     """One TensorProductConvLayer (eval mode) bound to a state_dict prefix."""
 
     def __init__(self, sd, name, in_irreps, sh_irreps, out_irreps, residual=True, batch_norm=True,
-                 faster=False, edge_groups=1, tp_weights_layers=2):
+                 faster=False, edge_groups=1, tp_weights_layers=2, depthwise=False):
         self.tp_weights_layers = tp_weights_layers
         self.sd, self.name = sd, name
         self.in_irreps, self.sh_irreps, self.out_irreps = Irreps(in_irreps), Irreps(sh_irreps), Irreps(out_irreps)
         self.residual, self.batch_norm, self.faster, self.edge_groups = residual, batch_norm, faster, edge_groups
-        if faster:
+        self.depthwise = depthwise
+        if depthwise:   # models/tensor_layers.py:248-290: 'uvu' TensorProduct into the sorted mid irreps, then linear_2 (replaces FasterTP)
+            from .e3nn_lite import Linear, TensorProduct
+            mid, instr = [], []
+            for i, a in enumerate(self.in_irreps):
+                for j, b in enumerate(self.sh_irreps):
+                    for ir_out in a.ir * b.ir:
+                        if ir_out in self.out_irreps:
+                            instr.append((i, j, len(mid), "uvu", True))
+                            mid.append((a.mul, ir_out))
+            mid, p, _ = Irreps(mid).sort()
+            instr = [(i1, i2, p[io], mode, train) for i1, i2, io, mode, train in instr]
+            self.faster = False
+            self.tp = TensorProduct(self.in_irreps, self.sh_irreps, mid, instr)
+            self.weight_numel = self.tp.weight_numel
+            self.linear_2 = Linear(mid.simplify(), self.out_irreps)
+            self.linear_2.weight.data = sd[f"{name}.linear_2.weight"]
+            self.mid_irreps = mid
+        elif faster:
             self.weight_numel = faster_weight_numel(in_irreps, out_irreps)
         else:
             self.tp = FullyConnectedTensorProduct(in_irreps, sh_irreps, out_irreps)
@@ -141,6 +159,7 @@ class TPConv:
         if edge_index.shape[1] == 0 and node_attr.shape[0] == 0:
             raise ValueError("No edges and no nodes")
         n_out = out_nodes or node_attr.shape[0]
+        tp_dim = self.mid_irreps.dim if self.depthwise else self.out_irreps.dim
         if edge_index.shape[1] == 0:
             out = node_attr.new_zeros(node_attr.shape[0], self.out_irreps.dim)
         else:
@@ -150,7 +169,7 @@ class TPConv:
                 out = scatter(self._tp(node_attr[dst], edge_sh, w), src, 0, n_out, reduce)
             else:
                 assert isinstance(edge_attr, list) and len(edge_attr) == self.edge_groups
-                out = node_attr.new_zeros(n_out, self.out_irreps.dim)
+                out = node_attr.new_zeros(n_out, tp_dim)
                 div = node_attr.new_zeros(n_out)
                 start = 0
                 for g, ea in enumerate(edge_attr):
@@ -163,6 +182,9 @@ class TPConv:
                 assert start == edge_index.shape[1]
                 if reduce == "mean":
                     out = out / div.clamp(min=torch.finfo(div.dtype).eps)[:, None]
+            if self.depthwise:   # tensor_layers.py:324-325
+                with torch.no_grad():
+                    out = self.linear_2(out)
             if self.batch_norm:
                 n = f"{self.name}.batch_norm"
                 out = batch_norm_eval(self.out_irreps, out, self.sd[n + ".running_mean"], self.sd[n + ".running_var"],

@@ -53,7 +53,7 @@ def install_stubs():
              spherical_harmonics=e3nn_lite.spherical_harmonics,
              FullyConnectedTensorProduct=e3nn_lite.FullyConnectedTensorProduct,
              FullTensorProduct=e3nn_lite.FullTensorProduct,
-             TensorProduct=MagicMock(), Linear=MagicMock(), wigner_3j=e3nn_lite.wigner_3j)
+             TensorProduct=e3nn_lite.TensorProduct, Linear=e3nn_lite.Linear, wigner_3j=e3nn_lite.wigner_3j)
     enn = mod("e3nn.nn", BatchNorm=e3nn_lite.BatchNorm)
     mod("e3nn", o3=o3, nn=enn)
     mod("torch_scatter", scatter=graph_ops.scatter, scatter_mean=graph_ops.scatter_mean)
@@ -187,6 +187,15 @@ def main():
                                    n_res=14, n_lig=9, n_samples=2, seed=22, t=0.3)
     cases["tiny_nobn_noscale"] = dict(cfg=TINY.replace(batch_norm=False, scale_by_sigma=False, num_conv_layers=3), n_res=26, n_lig=13,
                                       n_samples=2, seed=25, t=0.55)
+    # round 5: sidechain_pred (sidechain_loss_weight > 0: an o3.Linear on the receptor rows of the last node table, the 4th element
+    # of the forward tuple, models/cg_model.py:173-178,397-402).  o3.Linear itself is the oracle's restatement (oracle/e3nn_lite.py)
+    cases["tiny_sidechain"] = dict(cfg=TINY.replace(sidechain_pred=True, num_conv_layers=3), n_res=23, n_lig=10, n_samples=2, seed=27, t=0.5)
+    # depthwise_convolution (models/tensor_layers.py:248-290,324-325): 'uvu' TensorProduct + linear_2 in the embedding and interaction
+    # layers; TensorProduct / Linear are the oracle's restatements of the e3nn classes (oracle/e3nn_lite.py)
+    cases["tiny_depthwise"] = dict(cfg=TINY.replace(depthwise_convolution=True, num_conv_layers=3, num_prot_emb_layers=1), n_res=22, n_lig=10,
+                                   n_samples=2, seed=28, t=0.5)
+    cases["tiny_depthwise_l2"] = dict(cfg=TINY.replace(depthwise_convolution=True, sh_lmax=2, num_conv_layers=4), n_res=20, n_lig=9,
+                                      n_samples=2, seed=29, t=0.4)
     if len(sys.argv) > 1:
         cases = {k: v for k, v in cases.items() if k in sys.argv[1:]}
     for name, c in cases.items():
@@ -228,6 +237,8 @@ def main():
             continue
         tr, rot, tor = out[:3]   # the legacy class returns a 3-tuple
         fixture["forward"] = {"tr": tr, "rot": rot, "tor": tor, "conv_out": layer_out}
+        if cfg.sidechain_pred:
+            fixture["forward"]["sidechain"] = out[3]
 
         # ---- reference sampling() with recorded Gaussian draws
         steps = 4
@@ -295,6 +306,19 @@ def main():
         torch.save({"steps": steps, "draws": draws, "crop_beyond": 18.0, "kept_residues": kept, "confidence": conf,
                     "final_pos": torch.stack([d["ligand"].pos for d in out_list])}, os.path.join(HERE, "conf_crop.pt"))
         print("conf_crop kept", kept, "confidence", conf.tolist())
+    if len(sys.argv) == 1 or "crop_aa" in sys.argv[1:]:
+        # ---- crop_beyond (utils/utils.py:388-413) with all_atoms: residues AND their atoms, atom-atom / atom-residue relations remapped
+        from diffdock_amd.synth import make_complex as mk, make_pose_list as mp
+        ga = mk(seed=31, n_res=40, n_lig=9, all_atoms=True, atoms_per_res=(3, 7))
+        da = mp(ga, 1, seed=32, initial_noise_std_proportion=0.05)[0]
+        dc = copy.deepcopy(da)
+        crop_beyond(dc, 8.0, True)
+        assert 0 < dc["receptor"].pos.shape[0] < da["receptor"].pos.shape[0]
+        torch.save({"graph": graph_to_dict(da), "cutoff": 8.0, "rec_pos": dc["receptor"].pos, "rec_x": dc["receptor"].x,
+                    "rec_edge_index": dc["receptor", "receptor"].edge_index, "atom_pos": dc["atom"].pos, "atom_x": dc["atom"].x,
+                    "atom_edge_index": dc["atom", "atom"].edge_index, "atom_rec_edge_index": dc["atom", "receptor"].edge_index},
+                   os.path.join(HERE, "crop_aa.pt"))
+        print("crop_aa kept residues", dc["receptor"].pos.shape[0], "of", da["receptor"].pos.shape[0], "atoms", dc["atom"].pos.shape[0])
     if len(sys.argv) > 1:
         return
     # ---- crop_beyond (utils/utils.py:388-413) on one complex

@@ -77,9 +77,19 @@ def test_get_model_rejects_arguments_outside_the_built_path():
     base = TINY.to_namespace()
     assert config_from_args(base).ns == TINY.ns
     for key, val in (("embedding_type", "learned"), ("esm_embeddings_model", "esm2_t33"), ("parallel", 2),
-                     ("depthwise_convolution", True), ("sidechain_loss_weight", 0.5), ("tp_weights_layers", 1)):
+                     ("include_miscellaneous_atoms", True), ("tp_weights_layers", 1)):
         ns = argparse.Namespace(**vars(base))
         setattr(ns, key, val)
+        with pytest.raises(NotImplementedError):
+            config_from_args(ns)
+    # built since round 5: depthwise convolutions and side-chain prediction -- rejected only where the reference asserts them away
+    # (AAModel, models/aa_model.py:38-39)
+    for key, val, field in (("depthwise_convolution", True, "depthwise_convolution"), ("sidechain_loss_weight", 0.5, "sidechain_pred"),
+                            ("backbone_loss_weight", 1.0, "sidechain_pred")):
+        ns = argparse.Namespace(**vars(base))
+        setattr(ns, key, val)
+        assert getattr(config_from_args(ns), field) is True
+        ns.all_atoms = True
         with pytest.raises(NotImplementedError):
             config_from_args(ns)
     ns = argparse.Namespace(**vars(base))
@@ -121,3 +131,30 @@ def test_shipped_score_norm_tables_equal_the_reference_modules():
     g_so3, g_tor = tables()
     assert np.array_equal(so3, g_so3, equal_nan=True)        # every index, unconverged small-eps entries and NaNs included
     assert np.array_equal(tor, g_tor)
+
+
+def test_all_atom_crop_beyond_matches_reference_execution():
+    """diffdock_amd.sampling.crop_beyond(..., all_atoms=True) -- the crop sampling() applies to the confidence graphs
+    (utils/sampling.py:213-217) -- against the reference's own utils/utils.py:388-413 executed on an all-atom complex
+    (tests/golden/make_golden.py crop_aa): kept residues and atoms, the three remapped relations, element for element."""
+    from diffdock_amd.sampling import crop_beyond
+    fx = load_fixture("crop_aa")
+    g = graph_from_dict(fx["graph"])
+    crop_beyond(g, fx["cutoff"], all_atoms=True)
+    assert torch.equal(g["receptor"].pos, fx["rec_pos"]) and torch.equal(g["receptor"].x, fx["rec_x"])
+    assert torch.equal(g["receptor", "receptor"].edge_index, fx["rec_edge_index"])
+    assert torch.equal(g["atom"].pos, fx["atom_pos"]) and torch.equal(g["atom"].x, fx["atom_x"])
+    assert torch.equal(g["atom", "atom"].edge_index, fx["atom_edge_index"])
+    assert torch.equal(g["atom", "receptor"].edge_index, fx["atom_rec_edge_index"])
+    assert 0 < g["receptor"].pos.shape[0] < fx["graph"]["rec_pos"].shape[0]
+
+
+def test_fully_cropped_confidence_graph_is_a_clear_error():
+    """A confidence graph whose ligand ended farther than crop_beyond from every residue has no receptor left.  The reference would
+    hand the empty graph to its model (an exception deep inside torch_cluster, caught by sampling()'s try / except as a failed
+    complex); here the crop raises a ValueError that names the cause before any native call."""
+    from diffdock_amd.sampling import crop_beyond
+    g = graph_from_dict(load_fixture("crop_aa")["graph"])
+    g["ligand"].pos = g["ligand"].pos + 1000.0
+    with pytest.raises(ValueError, match="crop_beyond"):
+        crop_beyond(g, 8.0, all_atoms=True)

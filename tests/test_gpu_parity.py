@@ -22,7 +22,9 @@ CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tin
          "tiny_noaa", "tiny_2nd", "tiny_aa_2nd",   # tiny_*2nd: use_second_order_repr (2e / 2o node blocks)
          "tiny_fourier", "tiny_tpw3",              # embedding_type='fourier'; tp_weights_layers=3
          "tiny_aa_emb_nolig",                      # AAModel: embedding layers without embed_also_ligand (zero-padded ligand rows)
-         "tiny_oddpar", "tiny_aa_oddpar", "tiny_nobn_noscale"]   # odd_parity (CG + all-atom); batch_norm off + scale_by_sigma off
+         "tiny_oddpar", "tiny_aa_oddpar", "tiny_nobn_noscale",   # odd_parity (CG + all-atom); batch_norm off + scale_by_sigma off
+         "tiny_sidechain",                                        # sidechain_pred: o3.Linear on the receptor rows, 4th tuple element
+         "tiny_depthwise", "tiny_depthwise_l2"]                   # depthwise_convolution: 'uvu' TensorProduct + linear_2 (sh_lmax 1 and 2)
 
 
 def gpu_model(cfg, sd):
@@ -43,9 +45,13 @@ def test_forward_matches_reference_fixture(name):
     m = gpu_model(cfg, fx["state_dict"])
     batch = HeteroBatch.from_data_list(data_list)
     set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
-    tr, rot, tor, none = m(to_gpu(batch))
+    tr, rot, tor, side = m(to_gpu(batch))
     ref = fx["forward"]
-    assert none is None and tr.is_cuda
+    assert tr.is_cuda
+    if cfg.sidechain_pred:   # 4th tuple element (models/cg_model.py:397-402): [n_rec, 10]
+        assert side.shape == ref["sidechain"].shape and rel_err(side.cpu(), ref["sidechain"]) < REL
+    else:
+        assert side is None
     assert_scores_close((tr, rot, tor), (ref["tr"], ref["rot"], ref["tor"]))
     if cfg.num_prot_emb_layers == 0:
         for l, ref_nodes in enumerate(ref["conv_out"]):

@@ -17,7 +17,9 @@ CASES = ["tiny_l1", "tiny_l2", "tiny_l1_1group_emb", "tiny_l2_fixedcenter", "tin
          "tiny_noaa", "tiny_2nd", "tiny_aa_2nd",   # tiny_*2nd: use_second_order_repr (2e / 2o node blocks)
          "tiny_fourier", "tiny_tpw3",              # embedding_type='fourier'; tp_weights_layers=3
          "tiny_aa_emb_nolig",                      # AAModel: embedding layers without embed_also_ligand (zero-padded ligand rows)
-         "tiny_oddpar", "tiny_aa_oddpar", "tiny_nobn_noscale"]   # odd_parity (CG + all-atom); batch_norm off + scale_by_sigma off
+         "tiny_oddpar", "tiny_aa_oddpar", "tiny_nobn_noscale",   # odd_parity (CG + all-atom); batch_norm off + scale_by_sigma off
+         "tiny_sidechain",                                        # sidechain_pred: o3.Linear on the receptor rows, 4th tuple element
+         "tiny_depthwise", "tiny_depthwise_l2"]                   # depthwise_convolution: 'uvu' TensorProduct + linear_2 (sh_lmax 1 and 2)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -27,8 +29,12 @@ def test_forward_matches_reference(name):
     model = oracle_model(cfg, fx["state_dict"], so3_t, tor_t)
     batch = HeteroBatch.from_data_list(data_list)
     set_time(batch, fx["t"], fx["t"], fx["t"], batch.num_graphs)
-    tr, rot, tor, _, inter = model(batch, return_intermediates=True)
+    tr, rot, tor, side, inter = model(batch, return_intermediates=True)
     ref = fx["forward"]
+    if cfg.sidechain_pred:   # models/cg_model.py:397-402
+        assert side.shape == ref["sidechain"].shape == (batch["receptor"].pos.shape[0], 10) and rel_err(side, ref["sidechain"]) < 2e-5
+    else:
+        assert side is None
     for l, ref_nodes in enumerate(ref["conv_out"]):
         mine = inter[f"node_attr{l + 1}"]
         assert rel_err(mine, ref_nodes) < 2e-5, (l, rel_err(mine, ref_nodes))

@@ -98,6 +98,15 @@ struct Work {
       w.bs[i][0] = v[0]; w.bs[i][1] = v[1]; w.bs[i][2] = v[2];
     }
   }
+  static __device__ __forceinline__ void loadw1(W& w, i32x4 wb, unsigned lane16, unsigned soff, int i) {   // request i of the row
+    if (i < 3) {
+      const f32x4 v = raw_ld4(wb, (int)(lane16 + 1024u * i), (int)soff, 0);
+      w.b0[4 * i] = v[0]; w.b0[4 * i + 1] = v[1]; w.b0[4 * i + 2] = v[2]; w.b0[4 * i + 3] = v[3];
+    } else {
+      const f32x3 v = raw_ld3(wb, (int)(lane16 / 16u * 12u + 3072u + 768u * (i - 3)), (int)soff, 0);
+      w.bs[i - 3][0] = v[0]; w.bs[i - 3][1] = v[1]; w.bs[i - 3][2] = v[2];
+    }
+  }
   static __device__ __forceinline__ float wfrag(const W& w, int slot, int step) {
     if (slot == 0) return w.b0[step];
     return w.bs[NW3 == 1 ? 0 : (slot - 1) / 3][step];
@@ -152,7 +161,9 @@ __device__ __forceinline__ void epilogue_pair(const f32x4 (&acc)[NCB], float* gw
 }
 
 // =========================================================================================== MODE 0: lock-step, 8 waves
-template <int G>
+// XW: x fragments re-read from the x tile in LDS five contraction positions ahead of their MFMA (what the packed loops of k_conv_fused
+// do to save 30 registers) instead of resident registers; SPREAD: one weight request per second edge-MFMA slot instead of a burst
+template <int G, bool XW = false, bool SPREAD = false>
 __global__ __launch_bounds__(512) void k_lock(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using Wk = Work<G>; using S = Shape<G>; using D = Dim<S::NBK>;
@@ -214,9 +225,16 @@ __global__ __launch_bounds__(512) void k_lock(Args a) {
 #pragma unroll
           for (int t = 0; t < NSL; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
           r0b = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (XW) {
+            const float* xp = xbuf + lr * XSTR + lq;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) xa[i] = xp[4 * i];
+          }
           sfor<0, NCT>([&](auto ic) {
-            Wk::template cmma<decltype(ic)::value>(r, r0b, xa, w);
-            if (decltype(ic)::value == NCT - 3) readq(0, 0);
+            constexpr int i = decltype(ic)::value;
+            if constexpr (XW && i + 5 < NCT) xa[i + 5] = (xbuf + lr * XSTR + lq)[4 * (i + 5)];
+            Wk::template cmma<i>(r, r0b, xa, w);
+            if (i == NCT - 3) readq(0, 0);
             FENCE();
           });
           r[0] += r0b;
@@ -235,7 +253,8 @@ __global__ __launch_bounds__(512) void k_lock(Args a) {
           const float4& h = hC[vi][rt];
           const float av = (g & 1) ? (sub == 0 ? h.z : h.w) : (sub == 0 ? h.x : h.y);
           acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
-          if constexpr (m == 0) { if (do_w) { Wk::loadw(wn, wb, lane16, woff); } }
+          if constexpr (!SPREAD) { if constexpr (m == 0) { if (do_w) { Wk::loadw(wn, wb, lane16, woff); } } }
+          else { if constexpr (m % 2 == 0 && m / 2 < 3 + Wk::NW3) { if (do_w) Wk::loadw1(wn, wb, lane16, woff, m / 2); } }
           if constexpr (m >= 8 && m < 12) {
             if (do_h) { const f32x4 v = raw_ld4(hbuf, (int)lane16, (int)(hoff + (unsigned)(m - 8) * 9u * 1024u), 0); hN[(m - 8) >> 1][(m - 8) & 1] = make_float4(v[0], v[1], v[2], v[3]); }
           }
@@ -530,9 +549,120 @@ __global__ __launch_bounds__(256) void k_solo(Args a) {
   if (blockIdx.x == 0 && tid == 0) { a.clk[0] = c1 - c0; a.clk[1] = w1 - w0; }
 }
 
+// =========================================================================================== MODE 3: two 4-wave workgroups per CU
+// TWO independent workgroups per CU, 4 waves each (one per SIMD), <= 256 registers and <= 80 KB of LDS per workgroup: the two
+// waves of a SIMD then belong to different tiles and drift into different phases by themselves -- the coupling epilogue and
+// the granule prologue of one tile run beside the main loop of the other.  Per workgroup the chunk is SINGLE-buffered and a
+// step is [edge product of chunk g] barrier [contract rows 2w, 2w+1 of chunk g+1, one row at a time, weights just in time]
+// barrier: nothing is overlapped inside a workgroup, the partner workgroup is the overlap.  Classic granules only: 4 virtual
+// nodes x 2 row tiles x 4 column blocks = 128 accumulator registers per wave (the 5-block packed granule would need 160).
+template <int G>
+__global__ __launch_bounds__(256, 2) void k_duo(Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using Wk = Work<G>; using S = Shape<G>; using D = Dim<S::NBK>;
+  constexpr int NCT = S::NCT, NCB = S::NCB, NSL = S::NSL, NP = 4 * NSL, NE = 16 * NCB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = UNI(tid >> 6), lr = lane & 15, lq = lane >> 4;
+  float* xbuf = lds;
+  float* ybuf = xbuf + 16 * XSTR;            // [YB] one chunk
+  float* gscr = ybuf + D::YB;
+  float* stg = gscr + 4 * 16 * 36;
+  for (int i = tid; i < 16 * XSTR; i += 256) xbuf[i] = 1e-3f * (float)(i % 97);
+  __syncthreads();
+  const i32x4 wb = mkbuf(a.wpack, (unsigned)HKROWS * KSROW * 4u);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int cstep = G == 0 ? 16 : (lr < 8 ? 8 : lr < 10 ? 2 : 0);
+  float* const ywr = ybuf + (4 * lq) * D::YVN + (2 * wave) * D::YROW + (G == 0 ? lr : (lr < 8 ? lr : lr < 10 ? 16 * (NCB - 1) + lr - 8 : 16 * S::NBK + lr - 10));
+  const float* const yrd = ybuf + (4 * wave) * D::YVN + (2 * lq) * D::YROW + lr;
+  float sum = 0.f;
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int tl = 0; tl < a.tiles; ++tl) {
+    const int tile = (blockIdx.x + 512 * tl) % a.hb_tiles;
+    const i32x4 hbuf = mkbuf(a.hb + (size_t)tile * 16 * 2 * 9 * 256, 16u * 2u * 9u * 1024u);
+    for (int gi = 0; gi < NGR; ++gi) {
+      f32x4 acc[4][2][NCB];
+#pragma unroll
+      for (int i = 0; i < 8 * NCB; ++i) acc[i / (2 * NCB)][(i / NCB) & 1][i % NCB] = f32x4{0.f, 0.f, 0.f, 0.f};
+      typename Wk::W w;
+      unsigned woff = (unsigned)((2 * wave * KSROW + gi * 1280) * 4);
+      unsigned hoff = (unsigned)(4 * wave) * 2u * 9u * 1024u;
+      f32x4 hC[4][2];
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) hC[pc >> 1][pc & 1] = raw_ld4(hbuf, (int)lane16, (int)(hoff + (unsigned)pc * 9u * 1024u), 0);
+      hoff += 1024u;
+      auto contract_rows = [&]() __attribute__((always_inline)) {   // rows 2w, 2w + 1 of the next chunk, one after the other
+        int xo = lr * XSTR + lq;
+        asm volatile("" : "+v"(xo));           // (x fragments are re-read per chunk: resident they would not fit beside 128 accumulators)
+        float xa[NCT];
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) xa[i] = xbuf[xo + 4 * i];
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          Wk::loadw(w, wb, lane16, woff + (unsigned)row * KSROW * 4u);
+          f32x4 r[NSL], r0b;
+#pragma unroll
+          for (int t = 0; t < NSL; ++t) r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          r0b = f32x4{0.f, 0.f, 0.f, 0.f};
+          sfor<0, NCT>([&](auto ic) { Wk::template cmma<decltype(ic)::value>(r, r0b, xa, w); FENCE(); });
+          r[0] += r0b;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) Wk::store_piece(ywr + row * D::YROW, cstep, r, p);
+        }
+        woff += 8u * KSROW * 4u;
+      };
+      contract_rows();
+      __syncthreads();
+      for (int g = 0; g < NCH; ++g) {
+        const bool do_c = g + 1 < NCH, do_h = (g & 1) && g + 1 < NCH;
+        float q[2][NCB];
+        auto readq = [&](int par, int grp) __attribute__((always_inline)) {
+          const float* yb = yrd + (grp >> 1) * D::YVN + (grp & 1) * D::YROW;
+#pragma unroll
+          for (int c = 0; c < NCB; ++c) q[par][c] = yb[16 * c];
+        };
+        readq(0, 0);
+        sfor<0, NE>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          constexpr int grp = m / (2 * NCB), t8 = m % (2 * NCB), vi = grp >> 1, sub = grp & 1, rt = t8 / NCB, c = t8 % NCB;
+          const f32x4& h = hC[vi][rt];
+          const float av = (g & 1) ? (sub == 0 ? h[2] : h[3]) : (sub == 0 ? h[0] : h[1]);
+          acc[vi][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, q[grp & 1][c], acc[vi][rt][c], 0, 0, 0);
+          if constexpr (m % (4 * NCB) == 4 * NCB - 1) {   // hidden rows of the next pair of chunks, in place behind the node's last MFMA
+            if (do_h) {
+              constexpr int v = m / (4 * NCB);
+              hC[v][0] = raw_ld4(hbuf, (int)lane16, (int)(hoff + (unsigned)(2 * v) * 9u * 1024u), 0);
+              hC[v][1] = raw_ld4(hbuf, (int)lane16, (int)(hoff + (unsigned)(2 * v + 1) * 9u * 1024u), 0);
+            }
+          }
+          if constexpr (t8 == 1 && grp < 7) readq((grp + 1) & 1, grp + 1);
+          FENCE();
+        });
+        if (do_h) hoff += 1024u;
+        __syncthreads();                       // every wave is done reading the chunk
+        if (do_c) { contract_rows(); __syncthreads(); }
+      }
+      if (a.epi) {
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            epilogue_pair<NCB>(acc[vi][rt], gscr + wave * 16 * 36, stg + wave * 16 * 48,
+                               a.msg + ((size_t)((blockIdx.x & 255) * 16 + 4 * wave + vi) * 32 + 16 * rt) * 160, lane);
+            FENCE();
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8 * NCB; ++i) sum += acc[i / (2 * NCB)][(i / NCB) & 1][i % NCB][0];
+      }
+    }
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  a.out[(blockIdx.x & 255) * 512 + tid] = sum;
+  if (blockIdx.x == 0 && tid == 0) { a.clk[0] = c1 - c0; a.clk[1] = w1 - w0; }
+}
+
 // =========================================================================================== host
 template <class K>
-static void run(const char* name, K kern, int threads, size_t smem, Args a, int G) {
+static void run(const char* name, K kern, int threads, size_t smem, Args a, int G, int grid = 256) {
   if (smem > 160 * 1024) { printf("%-44s LDS %zu KB > 160 KB: does not fit\n", name, smem / 1024); return; }
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -540,7 +670,7 @@ static void run(const char* name, K kern, int threads, size_t smem, Args a, int 
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(a.err, 0, 4);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), smem, 0, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, 0, a);
     hipEventRecord(e1);
     if (hipEventSynchronize(e1) != hipSuccess) { printf("%-44s launch failed: %s\n", name, hipGetErrorString(hipGetLastError())); return; }
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -550,7 +680,7 @@ static void run(const char* name, K kern, int threads, size_t smem, Args a, int 
     if (rep > 0 && ms < best) { best = ms; clock_mhz = (double)h[0] / ((double)h[1] / 100.0); }
   }
   const int NCT = G == 0 ? 21 : 30, NCB = G == 0 ? 4 : 5;
-  const double granules = (double)a.tiles * NGR;
+  const double granules = (double)a.tiles * NGR * (grid / 256);   // per CU
   const double mfma_simd = granules * ((NCH + 0) * (8.0 * NCT + 16.0 * 4 * NCB) + 0) / 4.0;   // per SIMD (prologue contraction ~ the last step's missing one)
   const double cyc = best * 1e-3 * clock_mhz * 1e6;
   printf("%-44s epi=%d  %8.3f ms  %7.1f ns/granule  clock %4.0f MHz  %6.2f cycles per MFMA and SIMD  (LDS %zu KB)\n", name, a.epi, best,
@@ -568,6 +698,7 @@ int main(int argc, char** argv) {
   a.wpack = wpack; a.hb = hb; a.msg = msg; a.out = out; a.clk = clk; a.err = err; a.tiles = tiles; a.hb_tiles = hb_tiles;
   auto lds_lock = [](int nbk) { return (size_t)(16 * XSTR + 2 * (16 * (8 * (16 * nbk + 8) + 4)) + 8 * 16 * 36 + 8 * 16 * 48) * 4; };
   auto lds_pc = [](int nbk, int R) { return (size_t)(16 * XSTR + R * (16 * (8 * (16 * nbk + 8) + 4)) + 4 * 16 * 36 + 4 * 16 * 48 + 16) * 4; };
+  auto lds_duo = [](int nbk) { return (size_t)(16 * XSTR + (16 * (8 * (16 * nbk + 8) + 4)) + 4 * 16 * 36 + 4 * 16 * 48) * 4; };
   auto lds_solo = [](int nbk) { return (size_t)(16 * XSTR + 2 * (16 * (8 * (16 * nbk + 8) + 4)) + 4 * 16 * 36 + 4 * 16 * 48) * 4; };
   for (int epi = 0; epi < 2; ++epi) {
     a.epi = epi;
@@ -576,7 +707,11 @@ int main(int argc, char** argv) {
     run("classic PC    4 + 4 waves, ring 3", k_pc<0, 3>, 512, lds_pc(4, 3), a, 0);
     run("classic PC    4 + 4 waves, ring 4", k_pc<0, 4>, 512, lds_pc(4, 4), a, 0);
     run("classic SOLO  4 waves, one per SIMD", k_solo<0>, 256, std::max(lds_solo(4), (size_t)84 * 1024), a, 0);
+    run("classic DUO   2 workgroups x 4 waves per CU", k_duo<0>, 256, lds_duo(4), a, 0, 512);
     run("packed  LOCK  8 waves, barrier per chunk", k_lock<1>, 512, lds_lock(5), a, 1);
+    run("packed  LOCK  + x fragments through LDS", k_lock<1, true, false>, 512, lds_lock(5), a, 1);
+    run("packed  LOCK  + x window + spread requests", k_lock<1, true, true>, 512, lds_lock(5), a, 1);
+    run("classic LOCK  + spread weight requests", k_lock<0, false, true>, 512, lds_lock(4), a, 0);
     run("packed  PC    4 + 4 waves, ring 2", k_pc<1, 2>, 512, lds_pc(5, 2), a, 1);
     run("packed  PC    4 + 4 waves, ring 3", k_pc<1, 3>, 512, lds_pc(5, 3), a, 1);
     run("packed  SOLO  4 waves, one per SIMD", k_solo<1>, 256, std::max(lds_solo(5), (size_t)84 * 1024), a, 1);

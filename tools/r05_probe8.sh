@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 5, GPU passes 8-9: epilogue variants (per-row selects: r05_e5 first half; compile-time row stride: r05_e5; one body per output width: r05_e6) against the round-4 kernel (var_old.so)
+out=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $out
+cd $GRAFT_REPO_ROOT
+export DDMI_HARNESS=1
+B=diffdock_amd/csrc/build
+( timeout 900 python -m pytest tests/test_gpu_parity.py -q -x ) > $out/r05_p11_pytest.log 2>&1
+tail -2 $out/r05_p11_pytest.log
+DDMI_TIME_GROUPS=1 timeout 1200 tools/ab.sh r05_e8 "A=1" "A=0 -- --lib $B/var_old.so" "A=1" "A=0 -- --lib $B/var_old.so" \
+  "A=1 -- --samples 5" "A=0 -- --samples 5 --lib $B/var_old.so" "A=1 -- --config configs1" "A=0 -- --config configs1 --lib $B/var_old.so"

@@ -5,6 +5,7 @@ tag=${1:-rXX}
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
+export DDMI_HARNESS=1
 ( time python -m pytest tests -m gpu -q -s ) > $out/${tag}_pytest_gpu.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/${tag}_smoke.log 2>&1
 cd /tmp && export TMPDIR=/tmp
@@ -31,6 +32,7 @@ python bench.py --config mix --steps 2 > $out/${tag}_bench_mix.json 2>> $out/${t
 python bench.py --config configs4 --steps 2 --warmup 1 > $out/${tag}_bench_configs4.json 2>> $out/${tag}_bench.err
 python bench.py --samples 5 --no-cpu-baseline > $out/${tag}_bench_b5.json 2>> $out/${tag}_bench.err
 python bench.py --all-atoms > $out/${tag}_bench_all_atoms.json 2>> $out/${tag}_bench.err
+python bench.py --tile-per-pose --no-cpu-baseline > $out/${tag}_bench_tile_per_pose.json 2>> $out/${tag}_bench.err
 # secondary line: split-bf16 edge product (its own dtype), with the whole GPU suite under that route
 python bench.py --edge-product bf16x4 --no-cpu-baseline > $out/${tag}_bench_bf16x4.json 2>> $out/${tag}_bench.err
 ( time DDMI_EDGE_PRODUCT=bf16x4 python -m pytest tests -m gpu -q ) > $out/${tag}_bf16x4_pytest_gpu.log 2>&1

@@ -31,6 +31,12 @@ out = {"kernel": sub, "config": config, "launches": n, "fetch_size_kb_per_launch
 src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffdock_amd", "csrc", "k_conv.hip")
 out["kernel_source"] = "diffdock_amd/csrc/k_conv.hip"
 out["kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
+# the scatter stage (k_reduce_bn) from the same passes: bench.py's roofline_scatter.traffic
+ns, sfkb = counter(fetch_db, "FETCH_SIZE", "k_reduce_bn")
+_, swkb = counter(write_db, "WRITE_SIZE", "k_reduce_bn")
+if ns:
+    out["scatter"] = {"kernel": "k_reduce_bn", "launches": ns, "fetch_size_kb_per_launch": sfkb, "write_size_kb_per_launch": swkb,
+                      "bytes_per_launch": sfkb * 1024 * 2 + swkb * 1024}
 if len(sys.argv) > 6:
     _, hit = counter(sys.argv[6], "TCC_HIT_sum", sub)
     _, miss = counter(sys.argv[6], "TCC_MISS_sum", sub)
