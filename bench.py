@@ -230,6 +230,9 @@ def main():
                          "its neighbours in the batch (bit-exact shard invariance).  Default: ON for --gpus N > 1 (measured cost 1.9 %: 148.2 vs "
                          "151.1 poses/s at 40 poses, profiles/r05_v1_bench_tile_per_pose.json), off at N = 1")
     ap.add_argument("--no-tile-per-pose", dest="tile_per_pose", action="store_false")
+    ap.add_argument("--layer-overlap", choices=["joined", "auto", "always"], default="joined",
+                    help="ddmi_exec_options.layer_overlap: joined = all groups of a layer, then one node update (the default), auto = layer "
+                         "boundaries overlapped for chip-filling batches, always = for every batch size (neutral at 40 poses, profiles/r05_e11_ab.txt)")
     ap.add_argument("--fixed-center-conv", action="store_true",
                     help="build the model with fixed_center_conv (models/cg_model.py:371-374: the default indexes the ligand table by graph id, "
                          "so a pose's score depends on its position in the batch -- in the reference too)")
@@ -267,6 +270,8 @@ def main():
         args.tile_per_pose = world > 1          # sharded runs: every rank's poses as the one-batch run would compute them
     if args.tile_per_pose:
         cfg = cfg.replace(exec_options=tuple(cfg.exec_options) + (("tile_per_pose", 1),))
+    if args.layer_overlap != "joined":
+        cfg = cfg.replace(exec_options=tuple(cfg.exec_options) + (("layer_overlap", {"auto": 1, "always": 2}[args.layer_overlap]),))
     sd = init_state_dict(cfg, seed=1234)
     so3_t, tor_t = default_tables()
     S = args.samples or wl["samples"]              # poses per complex

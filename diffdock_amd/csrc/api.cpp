@@ -40,7 +40,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
       in(x.packed_granules, 1, "packed_granules"); in(x.merged_granule, 1, "merged_granule"); in(x.pre_reduce, 1, "pre_reduce");
       in(x.hidden_mm, 1, "hidden_mm"); in(x.fc1_batch, 1, "fc1_batch"); in(x.tile_split, 8, "tile_split");
       in(x.tile_split_small, 8, "tile_split_small"); in(x.hidden_grid, 1 << 20, "hidden_grid"); in(x.tp_apply, 3, "tp_apply");
-      in(x.tile_per_pose, 1, "tile_per_pose");
+      in(x.tile_per_pose, 1, "tile_per_pose"); in(x.layer_overlap, 2, "layer_overlap");
       h->m.two_streams = x.streams == 0;
       h->m.fused_dense = x.dense_rows == 0 ? 1 : x.dense_rows == 1 ? 0 : 2;
       h->m.fused_shared = x.shared_tiles == 0 ? 1 : x.shared_tiles == 1 ? 0 : 2;
@@ -54,6 +54,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
       h->m.eh_grid = x.hidden_grid > 0 ? x.hidden_grid : 2048;
       h->m.tp_form = x.tp_apply == 0 ? -1 : x.tp_apply - 1;   // 0 wave, 1 edge, 2 thread
       h->m.tile_per_pose = x.tile_per_pose != 0;
+      h->m.layer_overlap = x.layer_overlap;
     }
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_fork));
@@ -68,6 +69,7 @@ void ddmi_destroy(ddmi_model* h) {
   Model& m = h->m;
   if (m.side_stream) { (void)hipStreamSynchronize(m.side_stream); (void)hipStreamDestroy(m.side_stream); }
   for (hipEvent_t e : {m.ev_fork, m.ev_join, m.ev_cross}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : m.ev_pipe) (void)hipEventDestroy(e);
   delete h;
 }
 

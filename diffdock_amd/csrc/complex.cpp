@@ -149,6 +149,161 @@ struct RunGroup {
   bool swap_pq = false;   // first Linear sees [edge, GATHER node, TARGET node] (legacy lig->rec layer, old_cg_model.py:263)
 };
 
+// tiles of 16 virtual nodes of an edge group ~ gather nodes x ceil(mean degree / 32) / 16; a SMALL layer = no group fills the chip once
+static long tiles_of(const RunGroup& q) {
+  const long gn = std::max(1, q.gcount);
+  return std::max(1L, gn * (((long)q.ea_rows / gn + 31) / 32) / 16);
+}
+
+// One edge group of a TensorProductConvLayer on stream gs: per-graph / per-node terms of the first Linear (unless mm_all: the
+// layer's batched launch already produced them), virtual-node lists (first use in this forward), hidden rows, fused launch.
+// side: the scratch set of the side stream.
+static void run_group(Model& m, const ConvW& L, const RunGroup& g, size_t gi, bool side, bool mm_all, bool small_layer,
+                      const float* Xin, hipStream_t gs) {
+  Cx& c = *m.cx;
+  const int ns = m.ns, H = L.H;
+  float *HE = side ? c.HE_b : c.HE, *P = side ? c.P_b : c.P, *Q = side ? c.Q_b : c.Q;
+  float* rowbias = side ? c.rowbias_b : c.rr_rowbias;
+  if (mm_all) { P = c.Pg[gi]; Q = c.Qg[gi]; rowbias = c.rbg[gi]; }
+  const int wg = std::min<int>((int)gi, L.G - 1);
+  const float* W1 = L.W1[wg];
+  const float* rb = nullptr;
+  // Every edge group runs k_conv_fused (a node-contracted layer always has its granule list; ligand gather nodes with many
+  // edges are cut into 32-edge virtual nodes like the others -- several virtual nodes of an atom share its contraction in the
+  // shared-node tiles, mode 4 of the kernel).
+  DDMI_REQUIRE(g.vn >= 0 && L.n_fgran > 0 && c.Hb, DDMI_ERR_STATE, "convolution layer without a granule list / virtual-node set");
+  float* Hb = side ? c.Hb_b : c.Hb;
+  const bool deep = L.TL > 2;   // FCBlock with hidden Linear layers: first layer as plain per-edge rows, the hidden ones as GEMMs
+  const bool fuse_mm = !deep && m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
+  if (mm_all) {
+    if (g.sig) rb = rowbias;
+  } else if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
+    PhaseTimer t(m, "conv_fc1_gemms", gs);
+    const float* W1p = L.W1p[wg];
+    GemmBatch gb;   // the group's per-graph and per-node terms of the first Linear: independent, one launch
+    auto add = [&](const float* A, int lda, const float* W, const float* bias, float* C, int M) {
+      GemmArgs& x = gb.g[gb.n++];
+      x.A = A; x.lda = lda; x.W = W; x.ldw = L.n_edge; x.bias = bias; x.C = C; x.ldc = H; x.M = M; x.N = H; x.K = ns;
+    };
+    if (g.sig) { add(g.sig, ns, W1p, nullptr, rowbias, c.B); rb = rowbias; }
+    add(Xin + (size_t)g.tbase * XS, XS, W1p + (g.swap_pq ? 2 : 1) * ns, nullptr, P, g.tcount);
+    add(Xin + (size_t)g.gbase * XS, XS, W1p + (g.swap_pq ? 1 : 2) * ns, L.b1p[wg], Q, g.gcount);
+    launch_gemm_batch(gb, gs);
+  } else {
+    PhaseTimer t(m, "conv_fc1_gemms", gs);
+    if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]
+      gemm(g.sig, ns, W1, L.n_edge, nullptr, rowbias, H, c.B, H, ns, 0, gs);
+      rb = rowbias;
+    }
+    gemm(g.ea, ns, W1, L.n_edge, nullptr, HE, H, g.ea_rows, H, ns, 0, gs, g.ea_rows_dev, rb, g.sig_idx, H);
+    gemm(Xin + (size_t)g.tbase * XS, XS, W1 + (g.swap_pq ? 2 : 1) * ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
+    gemm(Xin + (size_t)g.gbase * XS, XS, W1 + (g.swap_pq ? 1 : 2) * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
+  }
+  {
+    Cx::VnSet& vs = c.vn[g.vn];
+    if (vs.built_goff != g.goff || vs.epoch != c.epoch || vs.built_tgt != g.tgt || vs.built_tslot != g.tslot || vs.built_arow != g.arow ||
+        vs.built_nvec != g.nvec || vs.built_ew != g.ew || vs.built_sgn != g.sgn || vs.built_tbase != g.tbase) {
+      PhaseTimer t(m, "vn_build", gs);
+      VnRowsArgs vr{};
+      vr.arow = g.arow; vr.nvec = g.nvec; vr.ew = g.ew; vr.tslot = g.tslot; vr.sgn = g.sgn; vr.sh_lmax = m.cfg.sh_lmax;
+      vr.tgt = g.tgt; vr.tbase = g.tbase;
+      vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
+      VnPoseTiles pp{};
+      if (vs.nvn_pad) {   // graph of every gather node: ligand / receptor / atom rows of the node table
+        static const char vn_type[9] = {'R', 'R', 'L', 'L', 'A', 'A', 'A', 'L', 'R'};   // gather-node type of every virtual-node list (set_complex)
+        const bool lig = vn_type[g.vn] == 'L', atom = vn_type[g.vn] == 'A';
+        pp.node_batch = lig ? c.lig_batch : atom ? c.atom_batch : c.rec_batch;
+        pp.graph_ptr = lig ? c.lig_ptr : atom ? c.atom_ptr : c.rec_ptr;
+        pp.n_graphs = c.B; pp.nvn_pad = vs.nvn_pad;
+      }
+      launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs, vs.nvn_pad ? &pp : nullptr);
+      if (g.vn == 0 && c.prered) launch_vn_tiles(vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
+      vs.built_goff = g.goff; vs.epoch = c.epoch; vs.built_tgt = g.tgt; vs.built_tslot = g.tslot; vs.built_arow = g.arow;
+      vs.built_nvec = g.nvec; vs.built_ew = g.ew; vs.built_sgn = g.sgn; vs.built_tbase = g.tbase;
+    }
+    const int* nvn = vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount;
+    // dense-row loop: groups with >= 20 edges per gather node (both row tiles of every virtual node are multiplied)
+    // split-bf16 edge product (ddmi_config.edge_product = 1): the static l <= 1 loops only; other layers keep the f32 route
+    const bool bf = m.cfg.edge_product == 1 && !L.fgran_generic && L.maxd <= 3 && m.cfg.sh_lmax <= 1;
+    const bool dense_rows = m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount));
+    if (fuse_mm) {
+      PhaseTimer t(m, "k_edge_hidden", gs);
+      EdgeHiddenArgs h{};
+      h.nvn = nvn; h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
+      h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = L.W1p[wg]; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
+      h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb; h.bf = bf ? 1 : 0;
+      h.zero_fill = (!L.fgran_generic && dense_rows) ? 1 : 0;
+      if (m.cfg.sh_lmax <= 1) { h.vrows = vs.rows; h.vn_ne = vs.ne; }
+      h.grid = m.eh_grid;
+      launch_edge_hidden_mm(h, gs);
+    } else if (deep) {
+      PhaseTimer t(m, "k_edge_hidden", gs);
+      float* cur = side ? c.HD_b[0] : c.HD[0];
+      float* nxt = side ? c.HD_b[1] : c.HD[1];
+      DDMI_REQUIRE(cur && nxt, DDMI_ERR_STATE, "tp_weights_layers > 2: hidden-row scratch missing");
+      launch_edge_rows(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, cur, gs);
+      for (int j = 0; j + 2 < L.TL; ++j) {   // hidden Linear + ReLU layers (models/layers.py:14-15), rows in gather order
+        gemm(cur, H, L.Wmid[wg][j], H, L.bmid[wg][j], nxt, H, g.ea_rows, H, H, 1, gs, g.ea_rows_dev);
+        std::swap(cur, nxt);
+      }
+      launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, nullptr, g.tgt, g.tbase, cur, nullptr, nullptr, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
+    } else {
+      PhaseTimer t(m, "k_edge_hidden", gs);
+      launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
+    }
+    FusedConvArgs f{};
+    f.nvn = nvn; f.vcap = vs.vcap; f.vn_node = vs.node; f.vrows = vs.rows; f.vn_ne = vs.ne;
+    f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
+    f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.cgt = L.cgt;
+    f.max_nb = L.max_nb; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
+    f.dense = dense_rows ? 1 : 0;
+    f.bf = bf ? 1 : 0;
+    f.tile_hdr = (g.vn == 0 && c.prered) ? vs.tile_hdr : nullptr;
+    // ligand gather nodes with >= 2 virtual nodes on average (rec<-lig): a tile of 16 virtual nodes holds few distinct nodes
+    f.shared = (dense_rows && (m.fused_shared == 2 || (m.fused_shared == 1 && g.load && (long)g.ea_rows >= 48L * std::max(1, g.gcount)))) ? 1 : 0;
+    f.prof_slot = (int)gi;
+    // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
+    int ys_req = m.fused_ysplit;
+    if (ys_req <= 0) {
+      // Small batches (no group of the layer fills the chip once; tiles ~ gather nodes x ceil(mean degree / 32) / 16): up to
+      // one granule per workgroup, 5 poses 94 -> 100 poses/s.  Otherwise the round-2 rule (at most 6 ranges, tiles estimated
+      // from nodes + edges / 32): the small lig-lig launch that runs next to the big groups is sensitive to its split -- 4
+      // ranges at 40 poses; 5-6 cost the headline 2.5 % (profiles/r03_e27..e37_ab.txt).
+      if (small_layer) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
+      else ys_req = (int)std::min(6L, std::max(1L, 768 / std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16)));
+      const int ys_small = m.fused_ysplit_small;   // tuning: split of a small group next to big ones
+      if (ys_small > 0 && !small_layer && tiles_of(g) < 256) ys_req = ys_small;
+    }
+    ys_req = std::max(ys_req, (L.n_fgran + 19) / 20);   // a workgroup keeps at most 24 granule descriptors in LDS
+    const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
+    f.ysplit = ys;
+    f.gsplit[0] = 0;
+    for (int y = 1; y < ys; ++y) {   // split points at unit boundaries (later granules of a unit add to the first one's stores)
+      int b = L.n_fgran * y / ys;
+      while (b < L.n_fgran && b > 0 && L.fgran_unit[b] == L.fgran_unit[b - 1]) ++b;
+      f.gsplit[y] = std::max(b, f.gsplit[y - 1]);
+    }
+    f.gsplit[ys] = L.n_fgran;
+    f.n_units = 0;
+    for (int gq = 0; gq < L.n_fgran && f.n_units < 48; ++gq)
+      if (gq == 0 || L.fgran_unit[gq] != L.fgran_unit[gq - 1]) f.ustart[f.n_units++] = (short)gq;
+    for (int y = 0; y < ys; ++y) {   // units of every granule range (ranges start at unit boundaries)
+      f.ufirst[y] = 0; f.ucount[y] = 0;
+      for (int u = 0; u < f.n_units; ++u)
+        if (f.ustart[u] >= f.gsplit[y] && f.ustart[u] < f.gsplit[y + 1]) { if (f.ucount[y] == 0) f.ufirst[y] = (short)u; ++f.ucount[y]; }
+    }
+    if (m.timing && m.timing_level >= 2) {   // ddmi_set_kernel_timing(h, 2 | 3): one timing row per edge group / per (layer, edge group)
+      const bool per_layer = m.timing_level >= 3;
+      const std::string tname = "k_conv_fused:" + (per_layer ? "L" + L.name.substr(L.name.size() - 1) : std::string()) + "g" + std::to_string(gi);
+      PhaseTimer t(m, tname.c_str(), gs);
+      launch_conv_fused(f, gs);
+    } else {
+      PhaseTimer t(m, "k_conv_fused", gs);
+      launch_conv_fused(f, gs);
+    }
+  }
+}
+
 // One TensorProductConvLayer in the node-contracted form (k_conv.hip).
 void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, const ReduceGroup* rg_dev, int n_rg,
               const float* Xin, float* Xout, int nbase, int ncount, hipStream_t s) {
@@ -163,11 +318,6 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     for (auto& g : groups) any_main = any_main || !(g.gbase == 0 && g.gcount == c.nL);
     forked = forked && any_main;
   }
-  // tiles of 16 virtual nodes per group ~ gather nodes x ceil(mean degree / 32) / 16; a SMALL layer = no group fills the chip once
-  auto tiles_of = [](const RunGroup& q) {
-    const long gn = std::max(1, q.gcount);
-    return std::max(1L, gn * (((long)q.ea_rows / gn + 31) / 32) / 16);
-  };
   long biggest = 1;
   for (auto& q : groups) biggest = std::max(biggest, tiles_of(q));
   const bool small_layer = biggest < 256;
@@ -207,147 +357,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const RunGroup& g = groups[gi];
     const bool side = forked && g.gbase == 0 && g.gcount == c.nL;
-    hipStream_t gs = side ? m.side_stream : s;
-    float *HE = side ? c.HE_b : c.HE, *P = side ? c.P_b : c.P, *Q = side ? c.Q_b : c.Q;
-    float* rowbias = side ? c.rowbias_b : c.rr_rowbias;
-    if (mm_all) { P = c.Pg[gi]; Q = c.Qg[gi]; rowbias = c.rbg[gi]; }
-    const int wg = std::min<int>((int)gi, L.G - 1);
-    const float* W1 = L.W1[wg];
-    const float* rb = nullptr;
-    // Every edge group runs k_conv_fused (a node-contracted layer always has its granule list; ligand gather nodes with many
-    // edges are cut into 32-edge virtual nodes like the others -- several virtual nodes of an atom share its contraction in the
-    // shared-node tiles, mode 4 of the kernel).
-    DDMI_REQUIRE(g.vn >= 0 && L.n_fgran > 0 && c.Hb, DDMI_ERR_STATE, "convolution layer without a granule list / virtual-node set");
-    float* Hb = side ? c.Hb_b : c.Hb;
-    const bool deep = L.TL > 2;   // FCBlock with hidden Linear layers: first layer as plain per-edge rows, the hidden ones as GEMMs
-    const bool fuse_mm = !deep && m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
-    if (mm_all) {
-      if (g.sig) rb = rowbias;
-    } else if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
-      PhaseTimer t(m, "conv_fc1_gemms", gs);
-      const float* W1p = L.W1p[wg];
-      GemmBatch gb;   // the group's per-graph and per-node terms of the first Linear: independent, one launch
-      auto add = [&](const float* A, int lda, const float* W, const float* bias, float* C, int M) {
-        GemmArgs& x = gb.g[gb.n++];
-        x.A = A; x.lda = lda; x.W = W; x.ldw = L.n_edge; x.bias = bias; x.C = C; x.ldc = H; x.M = M; x.N = H; x.K = ns;
-      };
-      if (g.sig) { add(g.sig, ns, W1p, nullptr, rowbias, c.B); rb = rowbias; }
-      add(Xin + (size_t)g.tbase * XS, XS, W1p + (g.swap_pq ? 2 : 1) * ns, nullptr, P, g.tcount);
-      add(Xin + (size_t)g.gbase * XS, XS, W1p + (g.swap_pq ? 1 : 2) * ns, L.b1p[wg], Q, g.gcount);
-      launch_gemm_batch(gb, gs);
-    } else {
-      PhaseTimer t(m, "conv_fc1_gemms", gs);
-      if (g.sig) {  // W1e * (edge_attr + sig[b]) = W1e*edge_attr + (W1e*sig)[b]
-        gemm(g.sig, ns, W1, L.n_edge, nullptr, rowbias, H, c.B, H, ns, 0, gs);
-        rb = rowbias;
-      }
-      gemm(g.ea, ns, W1, L.n_edge, nullptr, HE, H, g.ea_rows, H, ns, 0, gs, g.ea_rows_dev, rb, g.sig_idx, H);
-      gemm(Xin + (size_t)g.tbase * XS, XS, W1 + (g.swap_pq ? 2 : 1) * ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
-      gemm(Xin + (size_t)g.gbase * XS, XS, W1 + (g.swap_pq ? 1 : 2) * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
-    }
-    {
-      Cx::VnSet& vs = c.vn[g.vn];
-      if (vs.built_goff != g.goff || vs.epoch != c.epoch || vs.built_tgt != g.tgt || vs.built_tslot != g.tslot || vs.built_arow != g.arow ||
-          vs.built_nvec != g.nvec || vs.built_ew != g.ew || vs.built_sgn != g.sgn || vs.built_tbase != g.tbase) {
-        PhaseTimer t(m, "vn_build", gs);
-        VnRowsArgs vr{};
-        vr.arow = g.arow; vr.nvec = g.nvec; vr.ew = g.ew; vr.tslot = g.tslot; vr.sgn = g.sgn; vr.sh_lmax = m.cfg.sh_lmax;
-        vr.tgt = g.tgt; vr.tbase = g.tbase;
-        vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
-        VnPoseTiles pp{};
-        if (vs.nvn_pad) {   // graph of every gather node: ligand / receptor / atom rows of the node table
-          static const char vn_type[9] = {'R', 'R', 'L', 'L', 'A', 'A', 'A', 'L', 'R'};   // gather-node type of every virtual-node list (set_complex)
-          const bool lig = vn_type[g.vn] == 'L', atom = vn_type[g.vn] == 'A';
-          pp.node_batch = lig ? c.lig_batch : atom ? c.atom_batch : c.rec_batch;
-          pp.graph_ptr = lig ? c.lig_ptr : atom ? c.atom_ptr : c.rec_ptr;
-          pp.n_graphs = c.B; pp.nvn_pad = vs.nvn_pad;
-        }
-        launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs, vs.nvn_pad ? &pp : nullptr);
-        if (g.vn == 0 && c.prered) launch_vn_tiles(vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
-        vs.built_goff = g.goff; vs.epoch = c.epoch; vs.built_tgt = g.tgt; vs.built_tslot = g.tslot; vs.built_arow = g.arow;
-        vs.built_nvec = g.nvec; vs.built_ew = g.ew; vs.built_sgn = g.sgn; vs.built_tbase = g.tbase;
-      }
-      const int* nvn = vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount;
-      // dense-row loop: groups with >= 20 edges per gather node (both row tiles of every virtual node are multiplied)
-      // split-bf16 edge product (ddmi_config.edge_product = 1): the static l <= 1 loops only; other layers keep the f32 route
-      const bool bf = m.cfg.edge_product == 1 && !L.fgran_generic && L.maxd <= 3 && m.cfg.sh_lmax <= 1;
-      const bool dense_rows = m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount));
-      if (fuse_mm) {
-        PhaseTimer t(m, "k_edge_hidden", gs);
-        EdgeHiddenArgs h{};
-        h.nvn = nvn; h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
-        h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = L.W1p[wg]; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
-        h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb; h.bf = bf ? 1 : 0;
-        h.zero_fill = (!L.fgran_generic && dense_rows) ? 1 : 0;
-        if (m.cfg.sh_lmax <= 1) { h.vrows = vs.rows; h.vn_ne = vs.ne; }
-        h.grid = m.eh_grid;
-        launch_edge_hidden_mm(h, gs);
-      } else if (deep) {
-        PhaseTimer t(m, "k_edge_hidden", gs);
-        float* cur = side ? c.HD_b[0] : c.HD[0];
-        float* nxt = side ? c.HD_b[1] : c.HD[1];
-        DDMI_REQUIRE(cur && nxt, DDMI_ERR_STATE, "tp_weights_layers > 2: hidden-row scratch missing");
-        launch_edge_rows(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, cur, gs);
-        for (int j = 0; j + 2 < L.TL; ++j) {   // hidden Linear + ReLU layers (models/layers.py:14-15), rows in gather order
-          gemm(cur, H, L.Wmid[wg][j], H, L.bmid[wg][j], nxt, H, g.ea_rows, H, H, 1, gs, g.ea_rows_dev);
-          std::swap(cur, nxt);
-        }
-        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, nullptr, g.tgt, g.tbase, cur, nullptr, nullptr, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
-      } else {
-        PhaseTimer t(m, "k_edge_hidden", gs);
-        launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
-      }
-      FusedConvArgs f{};
-      f.nvn = nvn; f.vcap = vs.vcap; f.vn_node = vs.node; f.vrows = vs.rows; f.vn_ne = vs.ne;
-      f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
-      f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.cgt = L.cgt;
-      f.max_nb = L.max_nb; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
-      f.dense = dense_rows ? 1 : 0;
-      f.bf = bf ? 1 : 0;
-      f.tile_hdr = (g.vn == 0 && c.prered) ? vs.tile_hdr : nullptr;
-      // ligand gather nodes with >= 2 virtual nodes on average (rec<-lig): a tile of 16 virtual nodes holds few distinct nodes
-      f.shared = (dense_rows && (m.fused_shared == 2 || (m.fused_shared == 1 && g.load && (long)g.ea_rows >= 48L * std::max(1, g.gcount)))) ? 1 : 0;
-      f.prof_slot = (int)gi;
-      // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
-      int ys_req = m.fused_ysplit;
-      if (ys_req <= 0) {
-        // Small batches (no group of the layer fills the chip once; tiles ~ gather nodes x ceil(mean degree / 32) / 16): up to
-        // one granule per workgroup, 5 poses 94 -> 100 poses/s.  Otherwise the round-2 rule (at most 6 ranges, tiles estimated
-        // from nodes + edges / 32): the small lig-lig launch that runs next to the big groups is sensitive to its split -- 4
-        // ranges at 40 poses; 5-6 cost the headline 2.5 % (profiles/r03_e27..e37_ab.txt).
-        if (small_layer) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
-        else ys_req = (int)std::min(6L, std::max(1L, 768 / std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16)));
-        const int ys_small = m.fused_ysplit_small;   // tuning: split of a small group next to big ones
-        if (ys_small > 0 && !small_layer && tiles_of(g) < 256) ys_req = ys_small;
-      }
-      ys_req = std::max(ys_req, (L.n_fgran + 19) / 20);   // a workgroup keeps at most 24 granule descriptors in LDS
-      const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
-      f.ysplit = ys;
-      f.gsplit[0] = 0;
-      for (int y = 1; y < ys; ++y) {   // split points at unit boundaries (later granules of a unit add to the first one's stores)
-        int b = L.n_fgran * y / ys;
-        while (b < L.n_fgran && b > 0 && L.fgran_unit[b] == L.fgran_unit[b - 1]) ++b;
-        f.gsplit[y] = std::max(b, f.gsplit[y - 1]);
-      }
-      f.gsplit[ys] = L.n_fgran;
-      f.n_units = 0;
-      for (int gq = 0; gq < L.n_fgran && f.n_units < 48; ++gq)
-        if (gq == 0 || L.fgran_unit[gq] != L.fgran_unit[gq - 1]) f.ustart[f.n_units++] = (short)gq;
-      for (int y = 0; y < ys; ++y) {   // units of every granule range (ranges start at unit boundaries)
-        f.ufirst[y] = 0; f.ucount[y] = 0;
-        for (int u = 0; u < f.n_units; ++u)
-          if (f.ustart[u] >= f.gsplit[y] && f.ustart[u] < f.gsplit[y + 1]) { if (f.ucount[y] == 0) f.ufirst[y] = (short)u; ++f.ucount[y]; }
-      }
-      if (m.timing && m.timing_level >= 2) {   // ddmi_set_kernel_timing(h, 2 | 3): one timing row per edge group / per (layer, edge group)
-        const bool per_layer = m.timing_level >= 3;
-        const std::string tname = "k_conv_fused:" + (per_layer ? "L" + L.name.substr(L.name.size() - 1) : std::string()) + "g" + std::to_string(gi);
-        PhaseTimer t(m, tname.c_str(), gs);
-        launch_conv_fused(f, gs);
-      } else {
-        PhaseTimer t(m, "k_conv_fused", gs);
-        launch_conv_fused(f, gs);
-      }
-    }
+    run_group(m, L, g, gi, side, mm_all, small_layer, Xin, side ? m.side_stream : s);
   }
   if (forked) {
     DDMI_CHECK_HIP(hipEventRecord(m.ev_join, m.side_stream));
@@ -356,6 +366,65 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
   PhaseTimer t(m, "k_reduce_bn", s);
   launch_reduce_bn(rg_dev, n_rg, nbase, ncount, L.D_in, L.D_out, L.has_bn ? L.bn_mean : nullptr,
                    L.has_bn ? L.bn_scale : nullptr, L.has_bn ? L.bn_bias : nullptr, L.residual ? 1 : 0, Xin, Xout, XS, s);
+}
+
+// The interaction layers of the CG model with the layer boundaries overlapped (round 5, ddmi_exec_options.layer_overlap; NOT the
+// default: measured neutral at 40 poses -- 154.1 / 154.7 against 154.8 / 155.1 poses/s joined, profiles/r05_e11_ab.txt: the lig-lig
+// launch that now runs alone at the boundary takes half its time, the rec<-lig launch next to the boundary kernels a third more;
+// the forward is the SUM of its kernels' stand-alone times on either schedule -- and 6 % slower at 5 poses).
+// run_conv joins both streams behind a layer's four fused launches, reduces every node and only then starts the next layer's
+// chains: per boundary the chip runs [k_reduce_bn -> first-Linear GEMMs -> k_edge_hidden_mm] with no fused workgroup in flight
+// (2.0 ms of a 13.7-ms forward at 40 poses, profiles/r05_v1_timeline.txt).  The node update is per node, so it splits by node
+// type -- ligand rows need the lig-lig and lig<-rec messages, receptor rows the rec-rec and rec<-lig ones -- and every chain
+// starts as soon as the rows IT reads exist:
+//   main stream: lig<-rec(l) | reduce ligand rows(l) | rec-rec(l) | reduce receptor rows(l) | lig<-rec(l+1) ...
+//   side stream: lig-lig(l)  | rec<-lig(l)           | lig-lig(l+1) [behind rec-rec(l)'s launch] | rec<-lig(l+1) ...
+// lig-lig(l+1) reads ligand rows only: it is deliberately held until the rec-rec launch of layer l has finished, so that its
+// fused workgroups fill the chip while the main stream is in the receptor update and the lig<-rec chain of layer l+1.
+// Same kernels, same arguments, same arithmetic as run_conv (bit-identical scores); only the order of the launches differs.
+void run_conv_layers_overlapped(Model& m, const RunGroup& g_ll, const RunGroup& g_lr, const RunGroup& g_rr, const RunGroup& g_rl,
+                                const ReduceGroup* rg, int& xi, hipStream_t s) {
+  Cx& c = *m.cx;
+  const int Lc = (int)m.conv_layers.size(), nL = c.nL, nR = c.nR;
+  hipStream_t side = m.side_stream;
+  enum { E_LL, E_RL, E_RR, E_RED_L, E_RED_R, E_N };   // fused launch of a group finished / rows of a node type written
+  while ((int)m.ev_pipe.size() < E_N * Lc) {
+    hipEvent_t e;
+    DDMI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    m.ev_pipe.push_back(e);
+  }
+  auto ev = [&](int l, int k) { return m.ev_pipe[(size_t)l * E_N + k]; };
+  auto record = [&](int l, int k, hipStream_t st) { DDMI_CHECK_HIP(hipEventRecord(ev(l, k), st)); };
+  auto wait = [&](hipStream_t st, int l, int k) { DDMI_CHECK_HIP(hipStreamWaitEvent(st, ev(l, k), 0)); };   // (always behind its record in host order)
+  auto reduce = [&](const ConvW& L, const ReduceGroup* groups, int nbase, int ncount, const float* Xin, float* Xout) {
+    PhaseTimer t(m, "k_reduce_bn", s);
+    launch_reduce_bn(groups, 2, nbase, ncount, L.D_in, L.D_out, L.has_bn ? L.bn_mean : nullptr, L.has_bn ? L.bn_scale : nullptr,
+                     L.has_bn ? L.bn_bias : nullptr, L.residual ? 1 : 0, Xin, Xout, XS, s);
+  };
+  DDMI_CHECK_HIP(hipEventRecord(m.ev_fork, s));            // the layer-0 table
+  DDMI_CHECK_HIP(hipStreamWaitEvent(side, m.ev_fork, 0));
+  for (int l = 0; l < Lc; ++l, ++xi) {
+    const ConvW& L = m.conv_layers[l];
+    const float* Xin = c.X[xi];
+    float* Xout = c.X[xi + 1];
+    const bool last = l == Lc - 1;   // the last layer updates the ligand rows only (cg_model.py:345-349)
+    if (l > 0) { wait(side, l - 1, E_RR); wait(side, l - 1, E_RED_L); }
+    run_group(m, L, g_ll, 0, true, false, false, Xin, side);
+    record(l, E_LL, side);
+    run_group(m, L, g_lr, 1, false, false, false, Xin, s);
+    wait(s, l, E_LL);
+    reduce(L, rg, 0, last && m.cfg.sidechain_pred ? c.N : nL, Xin, Xout);
+    if (last) continue;
+    record(l, E_RED_L, s);
+    run_group(m, L, g_rr, 2, false, false, false, Xin, s);
+    record(l, E_RR, s);
+    if (l > 0) wait(side, l - 1, E_RED_R);
+    run_group(m, L, g_rl, 3, true, false, false, Xin, side);
+    record(l, E_RL, side);
+    wait(s, l, E_RL);
+    reduce(L, rg + 2, nL, nR, Xin, Xout);
+    record(l, E_RED_R, s);
+  }
 }
 
 // final_conv / tor_bond_conv: per-edge weights, then the table-driven tensor product.
@@ -1151,6 +1220,16 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     }
   } else {
     t_phase.reset();
+    // layer boundaries overlapped on request (ddmi_exec_options.layer_overlap, see run_conv_layers_overlapped): 1 = chip-filling
+    // batches (small ones keep the joined form with its one batched first-Linear launch per layer), 2 = every batch
+    bool overlapped = m.layer_overlap && m.two_streams && m.side_stream && nR > 0 && Lc >= 2;
+    if (overlapped) {
+      long biggest = 1;
+      for (const RunGroup* q : {&g_ll, &g_lr, &g_rr, &g_rl}) biggest = std::max(biggest, tiles_of(*q));
+      overlapped = biggest >= 256 || m.layer_overlap == 2;
+    }
+    if (overlapped) run_conv_layers_overlapped(m, g_ll, g_lr, g_rr, g_rl, crop ? c.rg_all_crop : c.rg_all, xi, s);
+    else
     for (int l = 0; l < Lc; ++l, ++xi) {
       if (l < Lc - 1)
         run_conv(m, m.conv_layers[l], {g_ll, g_lr, g_rr, g_rl}, crop ? c.rg_all_crop : c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s);

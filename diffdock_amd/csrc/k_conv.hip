@@ -20,6 +20,7 @@
 #include <utility>
 
 #include "kernels.h"
+#include "fc_layout.h"
 
 
 namespace ddmi {
@@ -42,7 +43,7 @@ static int ablate_mask() { return 0; }
 #if defined(DDMI_PROFILING) && DDMI_PROFILING >= 2   // (the clocks cost registers: -DDDMI_PROFILING=1 builds carry the ablation hooks only)
 #define DDMI_PHASE_CLOCKS 1
 // per-wave phase clocks of k_conv_fused (s_memtime at the phase boundaries, summed per edge-group slot)
-constexpr int FC_NPROF = 16, FC_PROF_SLOTS = 12;
+constexpr int FC_NPROF = 20, FC_PROF_SLOTS = 12;
 __device__ unsigned long long g_fc_prof[FC_PROF_SLOTS * FC_NPROF];
 struct FcProf {
   unsigned t; unsigned acc[FC_NPROF];
@@ -68,8 +69,11 @@ struct FcProf {
 #define DDMI_PROF_FINE 0
 #endif
 static const char* const fc_prof_names[FC_NPROF] = {"kernel_prologue", "granule_setup", "ml_prologue", "ml_steady", "bias", "barrier_pre_couple",
-                                                    "G_rows", "couple_stage", "store_rows", "barrier_end", "wave_total", "ml_barrier_wait", "-", "-",
-                                                    "granules", "waves"};
+                                                    "G_rows", "couple_stage", "store_rows", "barrier_end", "wave_total", "ml_barrier_wait",
+                                                    "ml_pro_chunk0", "ml_pro_weights1", "granules", "waves", "tile_pro_issue", "tile_pro_arrive", "-", "-"};
+// (ml_pro_chunk0 + ml_pro_weights1 + ml_prologue = the main-loop prologue: up to chunk 0 contracted and stored | chunk 1's weights
+// in registers | barrier and bias rows; tile_pro_issue + tile_pro_arrive + kernel_prologue = the tile prologue: every request
+// issued | all of them arrived and copied to LDS | the rest)
 void fc_prof_report() {
   unsigned long long h[FC_PROF_SLOTS * FC_NPROF];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fc_prof), sizeof(h)) != hipSuccess) return;
@@ -77,7 +81,7 @@ void fc_prof_report() {
     const unsigned long long* r = h + sl * FC_NPROF;
     if (r[15] == 0) continue;
     fprintf(stderr, "FCPROF slot=%d waves=%llu granules_per_wave=%.2f", sl, r[15], (double)r[14] / (double)r[15]);
-    for (int i = 0; i < 12; ++i) fprintf(stderr, " %s=%.0f", fc_prof_names[i], (double)r[i] / (double)r[15]);
+    for (int i = 0; i < 18; ++i) if (i != 14 && i != 15) fprintf(stderr, " %s=%.0f", fc_prof_names[i], (double)r[i] / (double)r[15]);
     fprintf(stderr, "\n");
   }
   memset(h, 0, sizeof(h));
@@ -263,208 +267,6 @@ __global__ __launch_bounds__(256) void k_vn_tiles(const int* __restrict__ nvn_p,
 void launch_vn_tiles(const int* nvn, int vcap, const float* vrows, const int* vn_ne, int* tile_hdr, unsigned char* live, hipStream_t s) {
   if (vcap <= 0) return;
   hipLaunchKernelGGL(k_vn_tiles, dim3(cdiv(vcap, 16)), dim3(256), 0, s, nvn, vrows, vn_ne, tile_hdr, live);
-  DDMI_CHECK_HIP(hipGetLastError());
-}
-
-// Hidden rows of the edge MLP in virtual-node order and in the A-fragment order of k_conv_fused, two 8-k groups per float4:
-//   Hb[v][rt][g >> 1][lane = 16q + r][2 (g & 1) + sub] = relu(HE[arow] + P[tgt] + Q[d])[k = 8g + 2q + sub]   (edge row el = 16rt + r)
-// (zero for k >= H and for the padding rows el >= ne): a wave fetches one (row tile, PAIR of 8-k groups) as 1 KB contiguous,
-// and the MFMA first layer (k_edge_hidden_mm) writes it with one float4 per lane.
-__host__ __device__ __forceinline__ int fc_ngp(int NG8) { return (NG8 + 1) >> 1; }
-__device__ __forceinline__ size_t fc_hb_off(int v, int rt, int g, int lane, int NGP) {
-  return ((((size_t)v * 2 + rt) * NGP + (g >> 1)) * 64 + lane) * 4 + 2 * (g & 1);
-}
-__global__ __launch_bounds__(256) void k_edge_hidden(const int* __restrict__ nvn, const int* __restrict__ vn_node,
-                                                    const int* __restrict__ vn_e0, const int* __restrict__ goff,
-                                                    const int* __restrict__ arow, const int* __restrict__ tgt, int tbase,
-                                                    const float* __restrict__ HE, const float* __restrict__ P,
-                                                    const float* __restrict__ Q, int H, int NG8, float* __restrict__ Hb, int bf) {
-  const int v = blockIdx.x;
-  if (v >= *nvn) return;
-  const int d = vn_node[v], e0 = vn_e0[v];
-  const int ne = min(32, goff[d + 1] - e0);
-  const int NGP = fc_ngp(NG8), q4 = 4 * NGP;   // 4-k pieces per row, padded to whole group pairs
-  for (int idx = threadIdx.x; idx < 32 * q4; idx += blockDim.x) {
-    const int el = idx / q4, k = 4 * (idx - el * q4);
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (el < ne && k < H) {
-      const int e = e0 + el;
-      const int ar = arow ? arow[e] : e;
-      const float4 x = nt_load4(HE + (size_t)ar * H + k);
-      if (P) {   // (P == nullptr: HE already holds the finished hidden rows of a deeper edge MLP, k_edge_rows + GEMMs)
-        const float4 p = *reinterpret_cast<const float4*>(P + (size_t)(tgt[e] - tbase) * H + k);
-        const float4 q = *reinterpret_cast<const float4*>(Q + (size_t)d * H + k);
-        o.x = fmaxf(x.x + p.x + q.x, 0.f); o.y = fmaxf(x.y + p.y + q.y, 0.f);
-        o.z = fmaxf(x.z + p.z + q.z, 0.f); o.w = fmaxf(x.w + p.w + q.w, 0.f);
-      } else {
-        o = x;
-      }
-    }
-    if (bf) { bf_split2(o.x, o.y, o.x, o.y); bf_split2(o.z, o.w, o.z, o.w); }   // split-bf16 edge product: packed (hi | lo) words
-    const int rt = el >> 4, r = el & 15, g = k >> 3, q0 = (k & 7) >> 1;
-    *reinterpret_cast<float2*>(Hb + fc_hb_off(v, rt, g, q0 * 16 + r, NGP)) = make_float2(o.x, o.y);
-    *reinterpret_cast<float2*>(Hb + fc_hb_off(v, rt, g, (q0 + 1) * 16 + r, NGP)) = make_float2(o.z, o.w);
-  }
-}
-// First hidden layer of a deeper edge MLP (tp_weights_layers > 2, models/layers.py:10-17), one plain row per edge in gather
-// order: rows[e] = relu(HE[arow[e]] + P[tgt[e]] + Q[d]); the hidden Linear layers then are ordinary GEMMs over these rows and
-// k_edge_hidden (P == nullptr) only re-orders the last one into fragment order.
-__global__ __launch_bounds__(256) void k_edge_rows(const int* __restrict__ nvn, const int* __restrict__ vn_node,
-                                                  const int* __restrict__ vn_e0, const int* __restrict__ goff,
-                                                  const int* __restrict__ arow, const int* __restrict__ tgt, int tbase,
-                                                  const float* __restrict__ HE, const float* __restrict__ P,
-                                                  const float* __restrict__ Q, int H, float* __restrict__ rows) {
-  const int v = blockIdx.x;
-  if (v >= *nvn) return;
-  const int d = vn_node[v], e0 = vn_e0[v];
-  const int ne = min(32, goff[d + 1] - e0);
-  for (int idx = threadIdx.x; idx < ne * H; idx += blockDim.x) {
-    const int el = idx / H, k = idx - el * H, e = e0 + el;
-    const int ar = arow ? arow[e] : e;
-    rows[(size_t)e * H + k] = fmaxf(HE[(size_t)ar * H + k] + P[(size_t)(tgt[e] - tbase) * H + k] + Q[(size_t)d * H + k], 0.f);
-  }
-}
-void launch_edge_rows(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
-                      const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, float* rows, hipStream_t s) {
-  if (vcap <= 0) return;
-  hipLaunchKernelGGL(k_edge_rows, dim3(vcap), dim3(256), 0, s, nvn, vn_node, vn_e0, goff, arow, tgt, tbase, HE, P, Q, H, rows);
-  DDMI_CHECK_HIP(hipGetLastError());
-}
-void launch_edge_hidden(const int* nvn, int vcap, const int* vn_node, const int* vn_e0, const int* goff, const int* arow,
-                        const int* tgt, int tbase, const float* HE, const float* P, const float* Q, int H, int NG8,
-                        float* Hb, hipStream_t s, int bf) {
-  if (vcap <= 0) return;
-  hipLaunchKernelGGL(k_edge_hidden, dim3(vcap), dim3(256), 0, s, nvn, vn_node, vn_e0, goff, arow, tgt, tbase, HE, P, Q, H,
-                     NG8, Hb, bf);
-  DDMI_CHECK_HIP(hipGetLastError());
-}
-
-__device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
-
-// One wave per virtual node (grid-stride), the edge-attribute block of the first Linear in LDS.  The product is taken
-// transposed -- D[hidden k][edge row] = W[k][:] . attr[row][:] with the weights as the A operand -- so that lane
-// (row, q) ends up with 4 consecutive hidden values of ITS row: exactly two (k pair) slots of the fragment order
-// Hb[v][rt][g][16q' + row][sub], k = 8g + 2q' + sub.  The target-node term P[tgt], Q[d] (+ the per-graph term) are
-// added as 16-B row pieces, relu applied, and each lane writes two 8-B pieces (16 lanes = 128 contiguous bytes).
-// k-permuted MFMA steps: lane (row, q) fetches floats [q*ns/4, (q+1)*ns/4) of its attribute row with 16-B loads; step t
-// multiplies attr[row][q*ns/4 + t] with W[k][q*ns/4 + t].
-template <int NSQ>   // ns = 16 * NSQ, H = 3 * ns
-__global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
-  DDMI_DYN_SMEM(float, smem);
-  constexpr int KS = 4 * NSQ;                        // MFMA steps = floats per lane quarter
-  constexpr int H = 48 * NSQ, NB = H / 16, NG8 = H / 8;
-  constexpr int HP = H + 1;                          // odd row stride: the staging writes (consecutive threads = consecutive rows) spread over the banks
-  float* wl = smem;                                  // [KS][4][HP]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = DDMI_UNIFORM(tid >> 6);
-  const int lr = lane & 15, lq = lane >> 4;
-  const int nvn = *a.nvn;
-  if ((int)blockIdx.x * 4 >= nvn) return;
-  // a.W1 is the permuted copy of the first layer (weights.cpp): output position 4a + i of a 16-block holds hidden unit
-  // 8 (i >> 1) + 2a + (i & 1), so lane (row, quarter a) ends with k = 8g + 2a + {0, 1} of BOTH 8-k groups g = 2nb, 2nb + 1 --
-  // the float4 of fragment lane 16a + row; P, Q and the sigma rows arrive in the same order.
-  {   // k fastest: coalesced reads of the weight rows; every request of the thread is issued before the first LDS store (the
-      // rolled loop was a chain of 27 request -> store round trips per workgroup: ~a quarter of the kernel)
-    constexpr int NW = (H * 4 * KS + 255) / 256;
-    float wreg[NW];
-#pragma unroll
-    for (int it = 0; it < NW; ++it) {
-      const int idx = tid + 256 * it;
-      wreg[it] = idx < H * 4 * KS ? a.W1[(size_t)(idx / (4 * KS)) * a.ldw + idx % (4 * KS)] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < NW; ++it) {
-      const int idx = tid + 256 * it;
-      const int k = idx % (4 * KS), n = idx / (4 * KS);
-      const int q = k / KS, t = k - q * KS;
-      if (idx < H * 4 * KS) wl[(t * 4 + q) * HP + n] = wreg[it];
-    }
-  }
-  __syncthreads();
-  for (int v = blockIdx.x * 4 + wave; v < nvn; v += gridDim.x * 4) {
-    const int d = a.vn_node[v], e0 = a.vn_e0[v];
-    const int ne = a.vn_ne ? a.vn_ne[v] : min(32, a.goff[d + 1] - e0);
-    // All requests of a (virtual node, row tile) are issued before the first use and nothing in the tile body branches:
-    // a load -> wait -> MFMA -> store chain per 16 hidden units made this kernel latency-bound (0.24 of the HBM write
-    // roofline in round 1).  Rows past the node's edge count read the tile's first edge (valid memory) and store zeros.
-    float4 qv[NB];
-    {
-      const float* __restrict__ qrow = a.Q + (size_t)d * H + 4 * lq;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) qv[nb] = *reinterpret_cast<const float4*>(qrow + 16 * nb);
-      if (a.rowbias && ne > 0) {   // wave-uniform
-        const float* __restrict__ rbrow = a.rowbias + (size_t)a.ridx[a.arow ? a.arow[e0] : e0] * H + 4 * lq;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const float4 t = *reinterpret_cast<const float4*>(rbrow + 16 * nb);
-          qv[nb].x += t.x; qv[nb].y += t.y; qv[nb].z += t.z; qv[nb].w += t.w;
-        }
-      }
-    }
-#pragma unroll 1   // (unrolled, the second row tile's requests do not move ahead of the first one's MFMAs anyway and the kernel loses 9 %: r03_e51)
-    for (int rt = 0; rt < 2; ++rt) {
-      float* __restrict__ hp = a.Hb + fc_hb_off(v, rt, 0, lane, NG8 / 2);   // + 256 per pair of 8-k groups
-      if (16 * rt >= ne) {   // empty row tile (wave-uniform): zero fragments where the consumer multiplies them
-        if (!a.zero_fill) continue;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<float4*>(hp + (size_t)nb * 256) = make_float4(0.f, 0.f, 0.f, 0.f);
-        continue;
-      }
-      const int el = 16 * rt + lr;
-      const bool live = el < ne;
-      int ar, tg;
-      if (a.vrows) {   // attribute row / target row of the lane's edge row, prepared by k_vn_rows: one dependent request less
-        const int2 at = *reinterpret_cast<const int2*>(a.vrows + ((size_t)v * 32 + el) * 8 + 6);
-        ar = at.x; tg = at.y;
-      } else {
-        const int e = e0 + (live ? el : 16 * rt);
-        ar = a.arow ? a.arow[e] : e;
-        tg = a.tgt[e] - a.tbase;
-      }
-      const float* __restrict__ ep = a.ea + (size_t)ar * a.ns + KS * lq;
-      const float* __restrict__ prow = a.P + (size_t)tg * H + 4 * lq;
-      float4 ae[NSQ], pv[NB];
-#pragma unroll
-      for (int j = 0; j < NSQ; ++j) ae[j] = *reinterpret_cast<const float4*>(ep + 4 * j);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) pv[nb] = *reinterpret_cast<const float4*>(prow + 16 * nb);
-      DDMI_SCHED_FENCE();   // every request of the tile is in flight before the first MFMA (the scheduler would sink them to their uses)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        f32x4 acc = f32x4{qv[nb].x + pv[nb].x, qv[nb].y + pv[nb].y, qv[nb].z + pv[nb].z, qv[nb].w + pv[nb].w};
-        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};   // two chains: a dependent f32 MFMA waits 40 cycles
-        const float* __restrict__ wp = wl + lq * HP + 16 * nb + lr;
-#pragma unroll
-        for (int j = 0; j < NSQ; ++j) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 0) * 4 * HP], ae[j].x, acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 1) * 4 * HP], ae[j].y, acc2, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 2) * 4 * HP], ae[j].z, acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(4 * j + 3) * 4 * HP], ae[j].w, acc2, 0, 0, 0);
-        }
-        float4 o;
-        o.x = live ? fmaxf(acc[0] + acc2[0], 0.f) : 0.f; o.y = live ? fmaxf(acc[1] + acc2[1], 0.f) : 0.f;
-        o.z = live ? fmaxf(acc[2] + acc2[2], 0.f) : 0.f; o.w = live ? fmaxf(acc[3] + acc2[3], 0.f) : 0.f;
-        if (a.bf) { bf_split2(o.x, o.y, o.x, o.y); bf_split2(o.z, o.w, o.z, o.w); }   // split-bf16 edge product: packed (hi | lo) words
-        *reinterpret_cast<float4*>(hp + (size_t)nb * 256) = o;
-      }
-    }
-  }
-}
-
-void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {
-  if (a.vcap <= 0) return;
-  if (a.ns % 16 != 0 || a.ns > 64 || a.H != 3 * a.ns || a.NG8 * 8 != a.H)
-    throw Error(DDMI_ERR_ARG, "k_edge_hidden_mm: unsupported width");
-  const size_t smem = (size_t)(a.ns * (a.H + 1)) * sizeof(float);
-  // Many short workgroups (not a persistent grid of 3 per CU, which is 6 % faster alone): with the two streams a long-lived
-  // workgroup holds 27 KB of LDS on its CU and keeps the concurrent k_conv_fused workgroups (131 KB) off it.
-  const int grid = std::min(cdiv(a.vcap, 4), a.grid > 0 ? a.grid : 2048);
-  switch (a.ns / 16) {
-    case 1: hipLaunchKernelGGL(k_edge_hidden_mm<1>, dim3(grid), dim3(256), smem, s, a); break;
-    case 2: hipLaunchKernelGGL(k_edge_hidden_mm<2>, dim3(grid), dim3(256), smem, s, a); break;
-    case 3: hipLaunchKernelGGL(k_edge_hidden_mm<3>, dim3(grid), dim3(256), smem, s, a); break;
-    default: hipLaunchKernelGGL(k_edge_hidden_mm<4>, dim3(grid), dim3(256), smem, s, a); break;
-  }
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
@@ -690,6 +492,7 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   auto xi = [](int i) constexpr { return SAMEX ? O::step(i) : i; };
   float xa_[NXA];
   float bw[4][S0 > 3 ? S0 : 3];   // weight fragments [slot][step] (slot 0: S0 steps, slots 1..3: SN steps)
+  float bw1[4][S0 > 3 ? S0 : 3];  // prologue only: chunk 1's fragments, requested together with chunk 0's
   fc_sfor<0, NC>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     if constexpr (!SAMEX || O::slot(i) == 0) xa_[xi(i)] = sl[O::slot(i)].xp[O::step(i) * sl[O::slot(i)].xstride];
@@ -714,21 +517,22 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   auto wsl = [](int t) constexpr { return DUP == 1 ? (t == 0 ? 0 : 1) : DUP == 2 ? (t == 3 ? 3 : 0) : DUP == 3 ? 0 : t; };
   static_assert(S0 % 4 == 0 || S0 == 3, "slot-0 chains are whole 4-step pieces or one 3-step piece");
   static_assert(SN == 0 || SN == 3 || SN == 12, "slots 1..3 hold 3-step chains (or 12-step chains of slot 0's path)");
-  auto loadw = [&](auto ic) __attribute__((always_inline)) {
+  auto loadw_to = [&](auto ic, float (&B)[4][S0 > 3 ? S0 : 3], unsigned ahead) __attribute__((always_inline)) {   // ahead: uniform byte offset on top of the current chunk's
     constexpr int i = decltype(ic)::value;
     constexpr int t = i < NL0 ? 0 : (DUP == 2 ? 3 : 1 + (i - NL0) / PSN);   // DUP 2: the one extra request is slot 3's
     if constexpr (t == 0 && S0 >= 4) {
-      const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0]);   // piece i of the chain: one contiguous KB per wave
-      bw[0][4 * i] = v.x; bw[0][4 * i + 1] = v.y; bw[0][4 * i + 2] = v.z; bw[0][4 * i + 3] = v.w;
+      const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0] + ahead);   // piece i of the chain: one contiguous KB per wave
+      B[0][4 * i] = v.x; B[0][4 * i + 1] = v.y; B[0][4 * i + 2] = v.z; B[0][4 * i + 3] = v.w;
     } else if constexpr (SN >= 4) {
       constexpr int pc = (i - NL0) % PSN;
-      const float4 v = fc_buf_ld4(wbuf, lo[t] + 1024u * pc, woff[t]);
-      bw[t][4 * pc] = v.x; bw[t][4 * pc + 1] = v.y; bw[t][4 * pc + 2] = v.z; bw[t][4 * pc + 3] = v.w;
+      const float4 v = fc_buf_ld4(wbuf, lo[t] + 1024u * pc, woff[t] + ahead);
+      B[t][4 * pc] = v.x; B[t][4 * pc + 1] = v.y; B[t][4 * pc + 2] = v.z; B[t][4 * pc + 3] = v.w;
     } else {
-      const float3 v = fc_buf_ld3(wbuf, lo[t], woff[t]);
-      bw[t][0] = v.x; bw[t][1] = v.y; bw[t][2] = v.z;
+      const float3 v = fc_buf_ld3(wbuf, lo[t], woff[t] + ahead);
+      B[t][0] = v.x; B[t][1] = v.y; B[t][2] = v.z;
     }
   };
+  auto loadw = [&](auto ic) __attribute__((always_inline)) { loadw_to(ic, bw, 0u); };
   constexpr bool FC_R0B = SH || FC_R0B_ALL;
   auto cmma = [](float av, float bv, f32x4 c) __attribute__((always_inline)) -> f32x4 {   // contraction MFMA
 #ifdef FCV_NOCMMA   // timing-only: no contraction MFMAs (the weight requests stay alive)
@@ -915,9 +719,10 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   using Even = std::integral_constant<int, 0>;
   using Odd = std::integral_constant<int, 1>;
   // prologue: chunk 0 contracted, chunk 1 requested  (NG8 is even and >= 2 here: the host selects this loop for H % 16 == 0)
+  // Round 5: the requests go out as [weights of chunk 0][bias row][weights of chunk 1][hidden rows of pair 0] -- vector memory
+  // returns in order, so the contraction of chunk 0 waits for the first two only, and the first in-loop contraction finds its
+  // weights in registers (they used to be requested BEHIND the contraction of chunk 0: one more exposed round trip per granule).
   fc_sfor<0, NL>(loadw);
-#pragma unroll
-  for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
   // The bias row of the packed second layer (k = H, hidden value 1 for every edge) rides along with the prologue: wave t
   // contracts slot t with it and leaves the 16 x 16 result in the bias rows; after the barrier every accumulator STARTS from
   // its node's bias value.  (No separate phase behind the main loop: that one exposed an L2 round trip, a dependent MFMA chain
@@ -942,6 +747,9 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
       }
     }
   });
+  fc_sfor<0, NL>([&](auto ic) { loadw_to(ic, bw1, gstep); });
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
 #pragma unroll
   for (int t = 0; t < 4; ++t) woff[t] += gstep;
   hoff += 1024u;
@@ -979,7 +787,16 @@ __device__ __forceinline__ void fc_mainloop_dense(f32x4 (&acc)[2][2][NBK], const
   }
 #pragma unroll
   for (int pc = 0; pc < NP; ++pc) store_piece(0, pc);
-  fc_sfor<0, NL>(loadw);
+  FC_STAMP(pf, 12);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < (S0 > 3 ? S0 : 3); ++j) bw[t][j] = bw1[t][j];   // chunk 1's fragments (entries no request wrote are never read)
+#ifdef DDMI_PHASE_CLOCKS
+#pragma unroll
+  for (int t = 0; t < 4; ++t) DDMI_OPAQUE(bw[t][0]);   // (the clock below then includes the wait for these requests)
+  FC_STAMP(pf, 13);
+#endif
 #pragma unroll
   for (int t = 0; t < 4; ++t) woff[t] += gstep;
   __syncthreads();
@@ -1095,6 +912,7 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
     }
   };
   float bw0[S0 > 0 ? S0 : 1], bwg[NG][3];   // weight fragments: the long chain, one 3-step set per group
+  float bw0n[S0 > 0 ? S0 : 1], bwgn[NG][3]; // prologue only: chunk 1's fragments, requested together with chunk 0's (fc_mainloop_dense)
   unsigned woff[1 + NG], lo[1 + NG];        // uniform byte offset of row k = 8g + wave / per-lane byte offset, per request source
 #pragma unroll
   for (int t = 0; t < 1 + NG; ++t) {
@@ -1104,17 +922,18 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
   const unsigned gstep = 32u * (unsigned)KS;
   const FcBuf wbuf = fc_buf(wpack, (unsigned)HK * (unsigned)KS * 4u);
   constexpr int NL0 = S0 / 4, NL = NL0 + NG;
-  auto loadw = [&](auto ic) __attribute__((always_inline)) {
+  auto loadw_to = [&](auto ic, float (&B0)[S0 > 0 ? S0 : 1], float (&BG)[NG][3], unsigned ahead) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     if constexpr (i < NL0) {
-      const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0]);
-      bw0[4 * i] = v.x; bw0[4 * i + 1] = v.y; bw0[4 * i + 2] = v.z; bw0[4 * i + 3] = v.w;
+      const float4 v = fc_buf_ld4(wbuf, lo[0] + 1024u * i, woff[0] + ahead);
+      B0[4 * i] = v.x; B0[4 * i + 1] = v.y; B0[4 * i + 2] = v.z; B0[4 * i + 3] = v.w;
     } else {
       constexpr int g = i - NL0;
-      const float3 v = fc_buf_ld3(wbuf, lo[1 + g], woff[1 + g]);
-      bwg[g][0] = v.x; bwg[g][1] = v.y; bwg[g][2] = v.z;
+      const float3 v = fc_buf_ld3(wbuf, lo[1 + g], woff[1 + g] + ahead);
+      BG[g][0] = v.x; BG[g][1] = v.y; BG[g][2] = v.z;
     }
   };
+  auto loadw = [&](auto ic) __attribute__((always_inline)) { loadw_to(ic, bw0, bwg, 0u); };
   float4 hC[2][2], hN[2][2];
 #pragma unroll
   for (int pc = 0; pc < 4; ++pc) hC[pc >> 1][pc & 1] = hN[pc >> 1][pc & 1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1276,10 +1095,8 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
   using F = std::false_type;
   using Even = std::integral_constant<int, 0>;
   using Odd = std::integral_constant<int, 1>;
-  // prologue: chunk 0 contracted, chunk 1 requested
+  // prologue: chunk 0 contracted, chunk 1 requested -- [weights 0][bias row][weights 1][hidden rows of pair 0], see fc_mainloop_dense
   fc_sfor<0, NL>(loadw);
-#pragma unroll
-  for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
   // bias row (k = H) with the prologue: wave t contracts slot t, every accumulator starts from its node's bias (fc_mainloop_dense)
   float bb[S0 > 3 ? S0 : 3];
   int lane_b = lane;
@@ -1303,6 +1120,9 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
       }
     }
   });
+  fc_sfor<0, NL>([&](auto ic) { loadw_to(ic, bw0n, bwgn, gstep); });
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) loadh(hC, pc);
 #pragma unroll
   for (int t = 0; t < 1 + NG; ++t) woff[t] += gstep;
   hoff += 1024u;
@@ -1333,7 +1153,19 @@ __device__ __forceinline__ void fc_mainloop_packed(f32x4 (&acc)[2][2][NBK], cons
   for (int t = 0; t < NS; ++t)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) store_slot(0, t, rr);
-  fc_sfor<0, NL>(loadw);
+  FC_STAMP(pf, 12);
+#pragma unroll
+  for (int j = 0; j < (S0 > 0 ? S0 : 1); ++j) bw0[j] = bw0n[j];   // chunk 1's fragments
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bwg[g][j] = bwgn[g][j];
+#ifdef DDMI_PHASE_CLOCKS
+  DDMI_OPAQUE(bw0[0]);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) DDMI_OPAQUE(bwg[g][0]);
+  FC_STAMP(pf, 13);
+#endif
 #pragma unroll
   for (int t = 0; t < 1 + NG; ++t) woff[t] += gstep;
   fc_sfor<0, XW>(xread);   // window of the first in-loop contraction
@@ -1512,6 +1344,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     if (xj < XS / 4 - 32) xv1 = xrow[32 + xj];
   }
   static_assert(XS % 4 == 0 && XS / 4 > 32 && XS / 4 <= 64 && (NC_XS % 2) == 0, "x tile copy: 40 pieces per row, 8-B aligned LDS rows");
+  FC_STAMP(pf, 16);
   // ---- everything to LDS
 #pragma unroll
   for (int it = 0; it < GD_IT; ++it) {
@@ -1552,6 +1385,7 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
       *reinterpret_cast<float2*>(xd + 130) = make_float2(xv1.z, xv1.w);
     }
   }
+  FC_STAMP(pf, 17);
   __syncthreads();
   const int H = a.HK - 1;
   const int NG8 = a.NG8;
@@ -1748,6 +1582,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
     static_assert(WST - 68 >= (PACK ? (BATCH_FITS ? 2048 + 16 * GS2 : BATCH_FITS_NOTAIL ? 1536 + 16 * GS2 : 1792) : 16 * 16 * MAXD + 256),
                   "the per-lane dump words of the masked stores lie behind everything else in the wave's scratch");
     const bool packed_rt = PACK && packed, tri_rt = tri, pre_rt = PRE_OK && pre;
+    // (Tried and dropped, profiles/r05_e12_ab.txt: touching the NEXT granule's first weight rows here, one dword per 16-B piece,
+    // so that its prologue's requests -- 4 k cycles of exposed wait per granule -- find the lines in L2: 151.5 against 154.1 poses/s.)
     // One instance of the coupling phase per granule kind and pre-reduction state (round 5): the wave-uniform tests on them --
     // per value, per row, per phase in the run-time form -- fold at compile time inside an instance (the epilogue is bound by
     // its instruction count).  KIND: 0 packed, 1 merged (three scalar channel tiles), 2 scalar block,
@@ -1967,6 +1803,8 @@ __global__ __launch_bounds__(512) void k_conv_fused(FusedConvArgs a) {
           const int nrows = min(16, ne - 16 * rt);
           const float* __restrict__ er = erow + rt * 16 * ES;
           const int accum = DDMI_ABL(a.dbg, 8192) ? 0 : Gd.accumulate;   // (timing-only: later granules of a unit overwrite instead of adding)
+          // (every staged piece read before the first store instead of this rolled loop: null, profiles/r05_e12_ab.txt -- the 7 % of a
+          // rec-rec launch spent here wait on the store queue, not on LDS)
           if (V == 4) fc_store_rows<4>(stgx, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
           else if (V == 2) fc_store_rows<2>(stgx, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);
           else fc_store_rows<1>(stgx, RS, L, nrows, er, ES, SHD + 1, a.msg, c0, accum, lane_e);

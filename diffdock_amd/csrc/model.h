@@ -96,6 +96,8 @@ struct Model {
   hipStream_t side_stream = nullptr;   // ligand-gather edge groups run here, concurrently with the receptor-gather ones
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cross = nullptr;
   bool two_streams = true;
+  int layer_overlap = 0;               // 0 joined layers (run_conv), 1 overlapped layer boundaries for chip-filling batches, 2 for every batch
+  std::vector<hipEvent_t> ev_pipe;     // run_conv_layers_overlapped: [layer][group launch done / node rows written]
   int fused_shared = 1;     // 1: rec<-lig group contracts the distinct gather nodes of a tile on the 4x4x1 MFMA; 0: per virtual node; 2: every dense group (tests)
   bool fused_tri = true;    // the three light granules of a single-chain 48-channel scalar block as one (exec.merged_granule = 1: separate)
   bool fused_pack = true;   // packed granules for output blocks of <= 10 channels (exec.packed_granules = 1: classic granules only)

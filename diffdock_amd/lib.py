@@ -27,7 +27,7 @@ EDGE_PRODUCTS = {"f32": 0, "bf16x4": 1}   # ddmi_config.edge_product (include/dd
 class ExecOptions(C.Structure):   # ddmi_exec_options (include/ddmi.h): all 0 = defaults
     _fields_ = [(n, C.c_int32) for n in ("streams", "dense_rows", "shared_tiles", "packed_granules", "merged_granule", "pre_reduce",
                                          "hidden_mm", "fc1_batch", "tile_split", "tile_split_small", "hidden_grid", "tp_apply",
-                                         "debug", "tile_per_pose")]
+                                         "debug", "tile_per_pose", "layer_overlap")]
 
 
 # Harness knobs: libddmi.so reads no environment variable; the test / bench harness selects kernel routes through these
@@ -74,6 +74,10 @@ def exec_options_from_env(base=()) -> ExecOptions:
         x.tp_apply = {"auto": 0, "wave": 1, "edge": 2, "thread": 3}[tp]
     if os.environ.get("DDMI_DEBUG_GRAN"): x.debug = 1
     if e("DDMI_TILE_PER_POSE") is not None: x.tile_per_pose = 1 if e("DDMI_TILE_PER_POSE") else 0
+    if e("DDMI_LAYER_OVERLAP") is not None:     # 0 = joined layers (default), 1 = overlapped boundaries for chip-filling batches, 2 = always
+        if e("DDMI_LAYER_OVERLAP") not in (0, 1, 2):
+            raise DdmiError("DDMI_LAYER_OVERLAP: 0 (joined layers), 1 (chip-filling batches) or 2 (always)")
+        x.layer_overlap = e("DDMI_LAYER_OVERLAP")
     return x
 
 

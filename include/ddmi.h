@@ -60,6 +60,10 @@ typedef struct ddmi_exec_options {
   int32_t tile_per_pose;    /* 1 = the 16-virtual-node tiles of k_conv_fused never span two graphs of the batch (dead virtual nodes
                              * pad every graph to whole tiles): the arithmetic of a pose then does not depend on the poses batched
                              * with it -- a sharded run is BIT-identical to the one-batch run.  0 = dense tiles.     */
+  int32_t layer_overlap;    /* interaction layers on the two streams: 0 = joined -- all groups of a layer, then one node update; 1 = node
+                             * update split by node type and every group's chain started as soon as the rows it reads exist, for
+                             * chip-filling batches; 2 = that for every batch size.  Same kernels and arithmetic (bit-identical scores);
+                             * measured neutral at 40 poses and -6 % at 5 (profiles/r05_e11_ab.txt), hence not the default.            */
 } ddmi_exec_options;
 
 /* Hyper-parameters: the keyword arguments get_model passes to CGModel

@@ -617,3 +617,36 @@ def test_tile_per_pose_makes_shards_bit_identical(emu_lib):
     pos = pp.sample_batch(HeteroBatch.from_data_list(dl), 2, (sched, sched, sched), seed=11, sample_ids=[0, 1, 2], no_final_step_noise=True).reshape(3, -1, 3)
     one = pp.sample_batch(HeteroBatch.from_data_list(dl[1:2]), 2, (sched, sched, sched), seed=11, sample_ids=[1], no_final_step_noise=True).reshape(1, -1, 3)
     assert torch.equal(one[0], pos[1])
+
+
+def test_layer_overlap_is_bit_identical(emu_lib):
+    """ddmi_exec_options.layer_overlap: the interaction layers with the node update split by node type and every group's chain
+    started as soon as its rows exist (run_conv_layers_overlapped) launch the SAME kernels
+    with the SAME arguments as the joined form (run_conv) -- only the order differs, so the scores are bit-identical.  Forced on
+    (2) against off (0) on a small batch: forward scores with sidechain_pred (the last layer then reduces every row) and one step
+    of the device loop with the per-step receptor crop (its own reduce-group list).  (The emulator runs streams in launch order:
+    this covers the data flow; the stream dependencies are covered on the GPU, test_layer_overlap_is_bit_identical_at_full_size.)"""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    g = make_complex(seed=4, n_res=16, n_lig=10, lm_dim=0)
+    dl = make_pose_list(g, 2, tr_sigma_max=5.0, seed=6, initial_noise_std_proportion=0.3)
+    sched = get_t_schedule(1)
+    cfg = replace(DDL_SYNTH, num_conv_layers=3, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_max=5.0,
+                  sidechain_pred=True)
+    sd = init_state_dict(cfg, seed=3)
+    outs, traj = [], []
+    for mode in (0, 2):
+        m = make_model(cfg.replace(exec_options=(("layer_overlap", mode),)), sd, emu_lib)
+        b = HeteroBatch.from_data_list(dl)
+        set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+        outs.append([o.clone() for o in m(b)])
+        traj.append(m.sample_batch(HeteroBatch.from_data_list(dl), 1, (sched, sched, sched), seed=11, sample_ids=[0, 1],
+                                   no_final_step_noise=True, crop_beyond=12.0).clone())
+        keep = m.debug_buffer("crop_keep")
+        assert 0 < keep.sum() < keep.size
+    assert len(outs[0]) == len(outs[1]) == 4
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    assert torch.equal(traj[0], traj[1])

@@ -455,3 +455,32 @@ def test_tile_per_pose_shards_are_bit_identical_at_full_size():
         part = m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl[lo:lo + 5])), 5, (sched, sched, sched), seed=123,
                               sample_ids=list(range(lo, lo + 5)), no_final_step_noise=True).reshape(5, -1, 3)
         assert torch.equal(part, full[lo:lo + 5]), lo
+
+
+def test_layer_overlap_is_bit_identical_at_full_size():
+    """ddmi_exec_options.layer_overlap: BASELINE configs[2] shapes (40 poses), the overlapped layer boundaries (1: the rule for chip-filling
+    batches, 2: forced) against the joined form (all groups of a layer, then one node update) -- same kernels and arguments in another launch order on
+    two streams, so every score and the 5-step device loop (per-step crop included) are equal bit for bit.  A missing dependency
+    between the streams (a chain started before its rows were written) shows up here as a difference; repeated to give a race a
+    second chance."""
+    sd = init_state_dict(DDL_SYNTH, seed=1234)
+    B = 40
+    g = make_complex(seed=4, n_res=300, n_lig=30)
+    dl = make_pose_list(g, B, tr_sigma_max=DDL_SYNTH.tr_sigma_max, seed=5, initial_noise_std_proportion=0.6)
+    sched = get_t_schedule(5)
+    res = {}
+    for mode in (0, 1, 2):   # joined | overlapped by the size rule (on at this size) | always
+        m = gpu_model(DDL_SYNTH.replace(exec_options=(("layer_overlap", mode),)), sd)
+        outs = []
+        for rep in range(3):
+            b = HeteroBatch.from_data_list(dl)
+            set_time(b, 0.5, 0.5, 0.5, B)
+            outs.append([o.clone() for o in m(to_gpu(b))[:3]])
+        for o in outs[1:]:
+            assert all(torch.equal(x, y) for x, y in zip(o, outs[0])), mode
+        traj = m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl)), 5, (sched, sched, sched), seed=123, sample_ids=list(range(B)),
+                              no_final_step_noise=True, crop_beyond=20.0).clone()
+        res[mode] = (outs[0], traj)
+    for mode in (1, 2):
+        assert all(torch.equal(x, y) for x, y in zip(res[mode][0], res[0][0])), mode
+        assert torch.equal(res[mode][1], res[0][1]), mode

@@ -14,7 +14,7 @@ if [ -n "$BASE" ]; then
   cp build/var_${BASE}/*.o build/var_${name}/
   cc $@ -x hip -c k_conv.hip -o build/var_${name}/k_conv.o
 else
-  for f in k_gemm k_conv k_graph k_embed k_readout k_sample; do
+  for f in k_gemm k_conv k_hidden k_graph k_embed k_readout k_sample; do
     cc $@ -x hip -c $f.hip -o build/var_${name}/$f.o &
     pids="$pids $!"
   done

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Device-code sanity of a built object (no GPU needed): tools/check_isa.sh [diffdock_amd/csrc/build/k_conv.o]
 # Prints the number of scratch_ (register spills / stack arrays) and flat_ (address space lost) instructions of the gfx950 code object.
-# k_conv.o must show 0 scratch_ (flat_ ~1 700: global accesses through generic pointers): the round-5 "one select per row" epilogue compiled to 11 747 scratch_
+# k_conv.o must show < 100 scratch_ (a few spilled registers in the tile prologue of each kernel) and ~10 flat_: the round-5 "one select per row" epilogue compiled to 11 747 scratch_
 # instructions and ran at 62 instead of 147 poses/s (profiles/r05_e5_ab.txt).
 o=${1:-$(dirname "$0")/../diffdock_amd/csrc/build/k_conv.o}
 t=$(mktemp -d)
