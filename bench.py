@@ -227,8 +227,8 @@ def main():
                          "trajectories (utils/sampling.py:80,91-93); noise is keyed by global sample id, so the poses are the one-batch poses")
     ap.add_argument("--tile-per-pose", dest="tile_per_pose", action="store_true", default=None,
                     help="ddmi_exec_options.tile_per_pose: tiles of k_conv_fused never span two poses -> a pose's arithmetic does not depend on "
-                         "its neighbours in the batch (bit-exact shard invariance).  Default: ON for --gpus N > 1 (measured cost 1.9 %: 148.2 vs "
-                         "151.1 poses/s at 40 poses, profiles/r05_v1_bench_tile_per_pose.json), off at N = 1")
+                         "its neighbours in the batch (bit-exact shard invariance).  Default: ON for --gpus N > 1 (measured cost 1.9 - 2.6 %: 148.2 vs "
+                         "151.1 and 150.9 vs 154.9 poses/s at 40 poses, profiles/r05_v1 / r05_v2_bench_tile_per_pose.json), off at N = 1")
     ap.add_argument("--no-tile-per-pose", dest="tile_per_pose", action="store_false")
     ap.add_argument("--layer-overlap", choices=["joined", "auto", "always"], default="joined",
                     help="ddmi_exec_options.layer_overlap: joined = all groups of a layer, then one node update (the default), auto = layer "

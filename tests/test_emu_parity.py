@@ -633,8 +633,8 @@ def test_layer_overlap_is_bit_identical(emu_lib):
     g = make_complex(seed=4, n_res=16, n_lig=10, lm_dim=0)
     dl = make_pose_list(g, 2, tr_sigma_max=5.0, seed=6, initial_noise_std_proportion=0.3)
     sched = get_t_schedule(1)
-    cfg = replace(DDL_SYNTH, num_conv_layers=3, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_max=5.0,
-                  sidechain_pred=True)
+    cfg = replace(DDL_SYNTH, num_conv_layers=3, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_min=0.1,
+                  tr_sigma_max=0.5, sidechain_pred=True)     # (per-step crop radius = 3 sigma_tr(t) + crop_beyond = 4.5 A at t = 1)
     sd = init_state_dict(cfg, seed=3)
     outs, traj = [], []
     for mode in (0, 2):
@@ -643,7 +643,7 @@ def test_layer_overlap_is_bit_identical(emu_lib):
         set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
         outs.append([o.clone() for o in m(b)])
         traj.append(m.sample_batch(HeteroBatch.from_data_list(dl), 1, (sched, sched, sched), seed=11, sample_ids=[0, 1],
-                                   no_final_step_noise=True, crop_beyond=12.0).clone())
+                                   no_final_step_noise=True, crop_beyond=3.0).clone())
         keep = m.debug_buffer("crop_keep")
         assert 0 < keep.sum() < keep.size
     assert len(outs[0]) == len(outs[1]) == 4
