@@ -37,4 +37,4 @@ python bench.py --tile-per-pose --no-cpu-baseline > $out/${tag}_bench_tile_per_p
 python bench.py --edge-product bf16x4 --no-cpu-baseline > $out/${tag}_bench_bf16x4.json 2>> $out/${tag}_bench.err
 ( time DDMI_EDGE_PRODUCT=bf16x4 python -m pytest tests -m gpu -q ) > $out/${tag}_bf16x4_pytest_gpu.log 2>&1
 # where the wall clock of a forward goes (tools/timeline.py)
-python $GRAFT_REPO_ROOT/tools/timeline.py $(find /tmp/prof_kt -name "*.db" | head -1) k_perturb 10 > $out/${tag}_timeline.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/timeline.py $(find /tmp/prof_kt -name "*.db" | head -1) k_perturb 10 22 > $out/${tag}_timeline.txt 2>&1   # (22: the trailing HIP-event pass of bench.py left out)
