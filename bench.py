@@ -71,18 +71,18 @@ WORKLOADS = {
 }
 # last committed PMC pass for the dominant kernel (tools/round_profile.sh, separate --pmc passes, gfx950 corrections applied)
 TRAFFIC_RECORD = os.path.join(ROOT, "profiles", "traffic_latest.json")
-KERNEL_SOURCE = os.path.join(ROOT, "diffdock_amd", "csrc", "k_conv.hip")
+KERNEL_SOURCE = os.path.join(ROOT, "diffdock_amd", "csrc", "k_conv_tile.h")     # the device code of k_conv_fused / k_conv_grouped
 
 
 def traffic_from_record(rec, kernel_source=KERNEL_SOURCE):
     """(bytes per launch, source note, L2 hit rate) of a counter record -- only when the record was collected on the kernel
-    source that is in the tree now (sha256 of k_conv.hip stored by tools/traffic_json.py): counters of an older kernel are not
+    source that is in the tree now (sha256 of k_conv_tile.h stored by tools/traffic_json.py): counters of an older kernel are not
     replayed next to a newer one."""
     import hashlib
     want = rec.get("kernel_source_sha256")
     have = hashlib.sha256(open(kernel_source, "rb").read()).hexdigest() if os.path.exists(kernel_source) else None
     if want is None or want != have:
-        return None, f"stale: {rec.get('source')} was collected on another k_conv.hip (re-run tools/round_profile.sh)", None
+        return None, f"stale: {rec.get('source')} was collected on another k_conv_tile.h (re-run tools/round_profile.sh)", None
     return rec["bytes_per_launch"], rec["source"], rec.get("l2_hit_rate")
 
 
@@ -333,17 +333,42 @@ def main():
             o.record_stream(cur)
         return torch.cat(outs)
 
+    gather_mode = os.environ.get("DDMI_BENCH_GATHER", "drain")      # drain (default) | enqueue (the collective behind the loop, no host sync) | host
+    trace_on = bool(os.environ.get("DDMI_BENCH_TRACE"))
+    trace_sync = os.environ.get("DDMI_BENCH_TRACE") == "2"      # 2: also drain the GPU behind the enqueue (changes what the all_gather waits for)
+    t_origin = time.perf_counter()
+
+    def trace(what):
+        """DDMI_BENCH_TRACE=1: per-rank wall clocks of the multi-rank step (stderr); `sync` entries drain the GPU first"""
+        if trace_on:
+            print(f"[trace rank {rank}] {time.perf_counter() - t_origin:10.4f} s  {what}", file=sys.stderr, flush=True)
+
     def one_step(seed, jobs_=None):
         last = None
         for j in (jobs if jobs_ is None else jobs_):
-            if True:
-                pos = sample_job(j, seed)
+            trace(f"seed {seed}: enqueue sample_job ({len(j['ids'])} poses)")
+            pos = sample_job(j, seed)
+            trace("  sample_job enqueued")
+            if trace_sync:
+                torch.cuda.synchronize()
+                trace("  sample_job drained (sync)")
             if world > 1:     # one all_gather per complex: the final coordinates of every pose on every rank
                 buf = pos
                 if pos.shape[0] != j["cap"] * j["n_lig"]:
                     buf = torch.zeros(j["cap"] * j["n_lig"], 3, device=dev)
                     buf[:pos.shape[0]] = pos
-                dist.all_gather(j["gathered"], buf)
+                if gather_mode == "drain":      # the rank's 20-step loop drained before the collective is entered (DESIGN 7)
+                    torch.cuda.current_stream(dev).synchronize()
+                    trace("  loop drained")
+                if gather_mode == "host":       # test hook: the collective on host tensors (no device-side stream of the backend involved)
+                    hb = buf.cpu()
+                    hl = [torch.empty_like(hb) for _ in range(world)]
+                    dist.all_gather(hl, hb)
+                    for dst, src in zip(j["gathered"], hl):
+                        dst.copy_(src)
+                else:
+                    dist.all_gather(j["gathered"], buf)
+                trace("  all_gather returned")
             last = pos
         return last
 
@@ -358,6 +383,7 @@ def main():
             last = one_step(100 + k, jobs_)
         if world > 1:
             dist.barrier()
+            trace("barrier behind the timed steps returned")
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
         if world > 1:
@@ -461,8 +487,11 @@ def main():
         if dom == "k_conv_fused" and not args.all_atoms:
             ms, n = kern[dom]
             avg_s = ms / max(n, 1) * 1e-3
-            w_dom = [w[dom] for w in work if dom in w]
-            n_launch = len(w_dom)                         # launches of this kernel in one forward of every complex
+            w_dom = [w[dom] for w in work if dom in w]    # one entry per (layer, edge group) of one forward of every complex
+            # launches of this kernel in one forward of every complex, as MEASURED by the event pass: 22 per complex with one
+            # k_conv_fused launch per (layer, edge group), 6 with the grouped dispatch (one k_conv_grouped launch per layer)
+            n_launch = max(1, round(n / max(n_forwards // len(jobs), 1)))
+            grouped_launches = n_launch < len(w_dom)
             flops = sum(w["flops"] for w in w_dom) / n_launch
             ref_flops = sum(w["ref_flops"] for w in w_dom) / n_launch
             bytes_ = sum(w["bytes"] for w in w_dom) / n_launch
@@ -484,14 +513,17 @@ def main():
                     "launches_per_forward": n_launch // len(jobs), "alg_flops_per_launch": flops, "alg_bytes_per_launch": bytes_,
                     "alg_flops_reference_assoc": ref_flops,
                     "forward_ms_timed_region": dt / n_forwards_timed * 1e3, "forward_ms_event_pass": fwd_ms,
-                    "kernel_two_streams" if streams == 2 else "kernel_one_stream": {
+                    "dispatch": "grouped: one k_conv_grouped launch per interaction layer walks the work items of all its edge groups"
+                                if grouped_launches else "one k_conv_fused launch per (layer, edge group)",
+                    ("kernel_grouped" if grouped_launches else "kernel_two_streams" if streams == 2 else "kernel_one_stream"): {
                         "avg_launch_ms": avg_s * 1e3, "launches": n, "achieved": flops / avg_s / 1e12,
                         "frac": flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
                         "note": "HIP events around every launch of one extra untimed step" +
-                                ("; the two streams run launches concurrently, so these durations overlap (their sum exceeds the forward)"
+                                ("; grouped launches run one after the other on one stream: the durations do not overlap" if grouped_launches else
+                                 "; the two streams run launches concurrently, so these durations overlap (their sum exceeds the forward)"
                                  if streams == 2 else "")},
                     "alg_definition": "mean over the launches of this kernel in one forward -- all four edge groups of every "
-                                      "layer (exact f32 on v_mfma_f32_16x16x4_f32, peak = dense f32 MFMA); "
+                                      "layer, per launch as dispatched (exact f32 on v_mfma_f32_16x16x4_f32, peak = dense f32 MFMA); "
                                       "k_conv_fused: 2*145*sum(mul_in*mul_out*din) flop per gather node "
                                       "+ 2*145*NT flop per edge (the re-associated contraction, DESIGN 2: 13x fewer flops than the "
                                       "reference's association, which alg_flops_reference_assoc prices by SURVEY 8d's formula), "
@@ -512,7 +544,8 @@ def main():
                 t1 = m1.kernel_timings()
                 rows = {k: v for k, v in t1.items() if k.startswith(dom)}
                 ms1, n1 = sum(v[0] for v in rows.values()), sum(v[1] for v in rows.values())
-                ach1 = flops / (ms1 / max(n1, 1) * 1e-3) / 1e12
+                flops1 = sum(w["flops"] for w in w_dom) / len(w_dom)        # per (layer, edge group) launch of this pass
+                ach1 = flops1 / (ms1 / max(n1, 1) * 1e-3) / 1e12
                 names = ["lig-lig", "lig<-rec", "rec-rec", "rec<-lig"]
                 per_group = {}
                 for gi in range(4):
@@ -521,7 +554,8 @@ def main():
                     if r and r[0] > 0:
                         per_group[names[gi]] = {"ms_per_forward": r[0] / INFERENCE_STEPS, "launches_per_forward": r[1] // INFERENCE_STEPS,
                                                 "frac": fl * INFERENCE_STEPS / (r[0] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
-                roof["serialised"] = {"avg_launch_ms": ms1 / max(n1, 1), "launches": n1, "achieved": ach1,
+                roof["serialised"] = {"dispatch": "one k_conv_fused launch per (layer, edge group) on one stream (level-2 kernel timers: per-group rows)",
+                                      "avg_launch_ms": ms1 / max(n1, 1), "launches": n1, "achieved": ach1,
                                       "frac": ach1 / MFMA_F32_PEAK_TFLOPS,
                                       "forward_ms": t1["forward_total"][0] / max(t1["forward_total"][1], 1),
                                       "per_group": per_group}

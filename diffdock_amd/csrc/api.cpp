@@ -41,6 +41,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
       in(x.hidden_mm, 1, "hidden_mm"); in(x.fc1_batch, 1, "fc1_batch"); in(x.tile_split, 8, "tile_split");
       in(x.tile_split_small, 8, "tile_split_small"); in(x.hidden_grid, 1 << 20, "hidden_grid"); in(x.tp_apply, 3, "tp_apply");
       in(x.tile_per_pose, 1, "tile_per_pose"); in(x.layer_overlap, 2, "layer_overlap");
+      in(x.grouped, 2, "grouped"); in(x.grouped_split, 8, "grouped_split");
       h->m.two_streams = x.streams == 0;
       h->m.fused_dense = x.dense_rows == 0 ? 1 : x.dense_rows == 1 ? 0 : 2;
       h->m.fused_shared = x.shared_tiles == 0 ? 1 : x.shared_tiles == 1 ? 0 : 2;
@@ -55,6 +56,8 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
       h->m.tp_form = x.tp_apply == 0 ? -1 : x.tp_apply - 1;   // 0 wave, 1 edge, 2 thread
       h->m.tile_per_pose = x.tile_per_pose != 0;
       h->m.layer_overlap = x.layer_overlap;
+      h->m.grouped = x.grouped;
+      h->m.grouped_split = x.grouped_split;
     }
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_fork));
@@ -259,9 +262,9 @@ int ddmi_debug_normal(uint64_t seed, int64_t sample0, int n_samples, int step, i
 int ddmi_set_kernel_timing(ddmi_model* h, int enabled) {
   if (!h) return DDMI_ERR_ARG;
   resolve_timings(h->m);
-#if defined(DDMI_PROFILING) && DDMI_PROFILING >= 2
+#if defined(DDMI_PROFILING)
   (void)hipDeviceSynchronize();
-  ddmi::fc_prof_report();   // in-kernel phase clocks since the last call (profiling builds only)
+  ddmi::fc_prof_report();   // in-kernel phase clocks / workgroup stamps since the last call (profiling builds only)
 #endif
   h->m.timing = enabled != 0;
   h->m.timing_level = enabled;

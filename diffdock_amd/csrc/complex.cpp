@@ -70,6 +70,7 @@ struct Model::Cx {
   ReduceGroup *rg_aa_all = nullptr, *rg_aa_lig = nullptr;
   long epoch = 0;
   float *Hb = nullptr, *Hb_b = nullptr;   // hidden rows of the main-stream / side-stream group in flight
+  float* Hbg[9] = {};                       // grouped dispatch: hidden rows of every virtual-node list (all groups of a layer are in flight at once)
   float *HD[2] = {nullptr, nullptr}, *HD_b[2] = {nullptr, nullptr};   // tp_weights_layers > 2: plain per-edge hidden rows [E][H]
   ReduceGroup *rg_all, *rg_lig, *rg_ll, *rg_rr;
   // read-outs
@@ -155,6 +156,109 @@ static long tiles_of(const RunGroup& q) {
   return std::max(1L, gn * (((long)q.ea_rows / gn + 31) / 32) / 16);
 }
 
+// Virtual-node lists and per-edge rows of an edge group (k_vn_count -> scan -> k_vn_fill -> k_vn_rows [-> k_vn_tiles]): built on the
+// first use in a forward, rebuilt when any input they bake in changes.
+static void ensure_vn(Model& m, const RunGroup& g, hipStream_t gs) {
+  Cx& c = *m.cx;
+  Cx::VnSet& vs = c.vn[g.vn];
+  if (vs.built_goff == g.goff && vs.epoch == c.epoch && vs.built_tgt == g.tgt && vs.built_tslot == g.tslot && vs.built_arow == g.arow &&
+      vs.built_nvec == g.nvec && vs.built_ew == g.ew && vs.built_sgn == g.sgn && vs.built_tbase == g.tbase) return;
+  PhaseTimer t(m, "vn_build", gs);
+  VnRowsArgs vr{};
+  vr.arow = g.arow; vr.nvec = g.nvec; vr.ew = g.ew; vr.tslot = g.tslot; vr.sgn = g.sgn; vr.sh_lmax = m.cfg.sh_lmax;
+  vr.tgt = g.tgt; vr.tbase = g.tbase;
+  vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
+  VnPoseTiles pp{};
+  if (vs.nvn_pad) {   // graph of every gather node: ligand / receptor / atom rows of the node table
+    static const char vn_type[9] = {'R', 'R', 'L', 'L', 'A', 'A', 'A', 'L', 'R'};   // gather-node type of every virtual-node list (set_complex)
+    const bool lig = vn_type[g.vn] == 'L', atom = vn_type[g.vn] == 'A';
+    pp.node_batch = lig ? c.lig_batch : atom ? c.atom_batch : c.rec_batch;
+    pp.graph_ptr = lig ? c.lig_ptr : atom ? c.atom_ptr : c.rec_ptr;
+    pp.n_graphs = c.B; pp.nvn_pad = vs.nvn_pad;
+  }
+  launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs, vs.nvn_pad ? &pp : nullptr);
+  if (g.vn == 0 && c.prered) launch_vn_tiles(vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
+  vs.built_goff = g.goff; vs.epoch = c.epoch; vs.built_tgt = g.tgt; vs.built_tslot = g.tslot; vs.built_arow = g.arow;
+  vs.built_nvec = g.nvec; vs.built_ew = g.ew; vs.built_sgn = g.sgn; vs.built_tbase = g.tbase;
+}
+
+// row mode / arithmetic of an edge group's fused launch
+struct GroupRoute { bool bf, dense_rows; };
+static GroupRoute group_route(const Model& m, const ConvW& L, const RunGroup& g) {
+  GroupRoute r;
+  // split-bf16 edge product (ddmi_config.edge_product = 1): the static l <= 1 loops only; other layers keep the f32 route
+  r.bf = m.cfg.edge_product == 1 && !L.fgran_generic && L.maxd <= 3 && m.cfg.sh_lmax <= 1;
+  // dense-row loop: groups with >= 20 edges per gather node (both row tiles of every virtual node are multiplied)
+  r.dense_rows = m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount));
+  return r;
+}
+
+// arguments of k_edge_hidden_mm for one edge group (first Linear straight from the edge attributes)
+static EdgeHiddenArgs hidden_args(Model& m, const ConvW& L, const RunGroup& g, int wg, const float* P, const float* Q, const float* rb,
+                                  float* Hb, const GroupRoute& rt) {
+  Cx& c = *m.cx;
+  Cx::VnSet& vs = c.vn[g.vn];
+  EdgeHiddenArgs h{};
+  h.nvn = vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount;
+  h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
+  h.tbase = g.tbase; h.ea = g.ea; h.ns = m.ns; h.W1 = L.W1p[wg]; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
+  h.H = L.H; h.NG8 = L.HKq / 8; h.Hb = Hb; h.bf = rt.bf ? 1 : 0;
+  h.zero_fill = (!L.fgran_generic && rt.dense_rows) ? 1 : 0;
+  if (m.cfg.sh_lmax <= 1) { h.vrows = vs.rows; h.vn_ne = vs.ne; }
+  h.grid = m.eh_grid;
+  return h;
+}
+
+// arguments of the fused convolution for one edge group; ys_force > 0: workgroups per tile chosen by the caller (grouped dispatch)
+static FusedConvArgs fused_args(Model& m, const ConvW& L, const RunGroup& g, size_t gi, int wg, const float* Xin, const float* Hb,
+                                const GroupRoute& rt, bool small_layer, int ys_force) {
+  Cx& c = *m.cx;
+  Cx::VnSet& vs = c.vn[g.vn];
+  FusedConvArgs f{};
+  f.nvn = vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount;
+  f.vcap = vs.vcap; f.vn_node = vs.node; f.vrows = vs.rows; f.vn_ne = vs.ne;
+  f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
+  f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.cgt = L.cgt;
+  f.max_nb = L.max_nb; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
+  f.dense = rt.dense_rows ? 1 : 0;
+  f.bf = rt.bf ? 1 : 0;
+  f.tile_hdr = (g.vn == 0 && c.prered) ? vs.tile_hdr : nullptr;
+  // ligand gather nodes with >= 2 virtual nodes on average (rec<-lig): a tile of 16 virtual nodes holds few distinct nodes
+  f.shared = (rt.dense_rows && (m.fused_shared == 2 || (m.fused_shared == 1 && g.load && (long)g.ea_rows >= 48L * std::max(1, g.gcount)))) ? 1 : 0;
+  f.prof_slot = (int)gi;
+  // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
+  int ys_req = ys_force > 0 ? ys_force : m.fused_ysplit;
+  if (ys_req <= 0) {
+    // Small batches (no group of the layer fills the chip once; tiles ~ gather nodes x ceil(mean degree / 32) / 16): up to
+    // one granule per workgroup, 5 poses 94 -> 100 poses/s.  Otherwise the round-2 rule (at most 6 ranges, tiles estimated
+    // from nodes + edges / 32): the small lig-lig launch that runs next to the big groups is sensitive to its split -- 4
+    // ranges at 40 poses; 5-6 cost the headline 2.5 % (profiles/r03_e27..e37_ab.txt).
+    if (small_layer) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
+    else ys_req = (int)std::min(6L, std::max(1L, 768 / std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16)));
+    const int ys_small = m.fused_ysplit_small;   // tuning: split of a small group next to big ones
+    if (ys_small > 0 && !small_layer && tiles_of(g) < 256) ys_req = ys_small;
+  }
+  ys_req = std::max(ys_req, (L.n_fgran + 19) / 20);   // a workgroup keeps at most 24 granule descriptors in LDS
+  const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
+  f.ysplit = ys;
+  f.gsplit[0] = 0;
+  for (int y = 1; y < ys; ++y) {   // split points at unit boundaries (later granules of a unit add to the first one's stores)
+    int b = L.n_fgran * y / ys;
+    while (b < L.n_fgran && b > 0 && L.fgran_unit[b] == L.fgran_unit[b - 1]) ++b;
+    f.gsplit[y] = std::max(b, f.gsplit[y - 1]);
+  }
+  f.gsplit[ys] = L.n_fgran;
+  f.n_units = 0;
+  for (int gq = 0; gq < L.n_fgran && f.n_units < 48; ++gq)
+    if (gq == 0 || L.fgran_unit[gq] != L.fgran_unit[gq - 1]) f.ustart[f.n_units++] = (short)gq;
+  for (int y = 0; y < ys; ++y) {   // units of every granule range (ranges start at unit boundaries)
+    f.ufirst[y] = 0; f.ucount[y] = 0;
+    for (int u = 0; u < f.n_units; ++u)
+      if (f.ustart[u] >= f.gsplit[y] && f.ustart[u] < f.gsplit[y + 1]) { if (f.ucount[y] == 0) f.ufirst[y] = (short)u; ++f.ucount[y]; }
+  }
+  return f;
+}
+
 // One edge group of a TensorProductConvLayer on stream gs: per-graph / per-node terms of the first Linear (unless mm_all: the
 // layer's batched launch already produced them), virtual-node lists (first use in this forward), hidden rows, fused launch.
 // side: the scratch set of the side stream.
@@ -199,108 +303,114 @@ static void run_group(Model& m, const ConvW& L, const RunGroup& g, size_t gi, bo
     gemm(Xin + (size_t)g.tbase * XS, XS, W1 + (g.swap_pq ? 2 : 1) * ns, L.n_edge, nullptr, P, H, g.tcount, H, ns, 0, gs);
     gemm(Xin + (size_t)g.gbase * XS, XS, W1 + (g.swap_pq ? 1 : 2) * ns, L.n_edge, L.b1[wg], Q, H, g.gcount, H, ns, 0, gs);
   }
-  {
-    Cx::VnSet& vs = c.vn[g.vn];
-    if (vs.built_goff != g.goff || vs.epoch != c.epoch || vs.built_tgt != g.tgt || vs.built_tslot != g.tslot || vs.built_arow != g.arow ||
-        vs.built_nvec != g.nvec || vs.built_ew != g.ew || vs.built_sgn != g.sgn || vs.built_tbase != g.tbase) {
-      PhaseTimer t(m, "vn_build", gs);
-      VnRowsArgs vr{};
-      vr.arow = g.arow; vr.nvec = g.nvec; vr.ew = g.ew; vr.tslot = g.tslot; vr.sgn = g.sgn; vr.sh_lmax = m.cfg.sh_lmax;
-      vr.tgt = g.tgt; vr.tbase = g.tbase;
-      vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
-      VnPoseTiles pp{};
-      if (vs.nvn_pad) {   // graph of every gather node: ligand / receptor / atom rows of the node table
-        static const char vn_type[9] = {'R', 'R', 'L', 'L', 'A', 'A', 'A', 'L', 'R'};   // gather-node type of every virtual-node list (set_complex)
-        const bool lig = vn_type[g.vn] == 'L', atom = vn_type[g.vn] == 'A';
-        pp.node_batch = lig ? c.lig_batch : atom ? c.atom_batch : c.rec_batch;
-        pp.graph_ptr = lig ? c.lig_ptr : atom ? c.atom_ptr : c.rec_ptr;
-        pp.n_graphs = c.B; pp.nvn_pad = vs.nvn_pad;
-      }
-      launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs, vs.nvn_pad ? &pp : nullptr);
-      if (g.vn == 0 && c.prered) launch_vn_tiles(vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
-      vs.built_goff = g.goff; vs.epoch = c.epoch; vs.built_tgt = g.tgt; vs.built_tslot = g.tslot; vs.built_arow = g.arow;
-      vs.built_nvec = g.nvec; vs.built_ew = g.ew; vs.built_sgn = g.sgn; vs.built_tbase = g.tbase;
+  ensure_vn(m, g, gs);
+  Cx::VnSet& vs = c.vn[g.vn];
+  const int* nvn = vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount;
+  const GroupRoute rt = group_route(m, L, g);
+  const bool bf = rt.bf;
+  if (fuse_mm) {
+    PhaseTimer t(m, "k_edge_hidden", gs);
+    launch_edge_hidden_mm(hidden_args(m, L, g, wg, P, Q, rb, Hb, rt), gs);
+  } else if (deep) {
+    PhaseTimer t(m, "k_edge_hidden", gs);
+    float* cur = side ? c.HD_b[0] : c.HD[0];
+    float* nxt = side ? c.HD_b[1] : c.HD[1];
+    DDMI_REQUIRE(cur && nxt, DDMI_ERR_STATE, "tp_weights_layers > 2: hidden-row scratch missing");
+    launch_edge_rows(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, cur, gs);
+    for (int j = 0; j + 2 < L.TL; ++j) {   // hidden Linear + ReLU layers (models/layers.py:14-15), rows in gather order
+      gemm(cur, H, L.Wmid[wg][j], H, L.bmid[wg][j], nxt, H, g.ea_rows, H, H, 1, gs, g.ea_rows_dev);
+      std::swap(cur, nxt);
     }
-    const int* nvn = vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount;
-    // dense-row loop: groups with >= 20 edges per gather node (both row tiles of every virtual node are multiplied)
-    // split-bf16 edge product (ddmi_config.edge_product = 1): the static l <= 1 loops only; other layers keep the f32 route
-    const bool bf = m.cfg.edge_product == 1 && !L.fgran_generic && L.maxd <= 3 && m.cfg.sh_lmax <= 1;
-    const bool dense_rows = m.fused_dense == 2 || (m.fused_dense == 1 && (long)g.ea_rows >= 20L * std::max(1, g.gcount));
-    if (fuse_mm) {
-      PhaseTimer t(m, "k_edge_hidden", gs);
-      EdgeHiddenArgs h{};
-      h.nvn = nvn; h.vcap = vs.vcap; h.vn_node = vs.node; h.vn_e0 = vs.e0; h.goff = g.goff; h.arow = g.arow; h.tgt = g.tgt;
-      h.tbase = g.tbase; h.ea = g.ea; h.ns = ns; h.W1 = L.W1p[wg]; h.ldw = L.n_edge; h.P = P; h.Q = Q; h.rowbias = rb; h.ridx = g.sig_idx;
-      h.H = H; h.NG8 = L.HKq / 8; h.Hb = Hb; h.bf = bf ? 1 : 0;
-      h.zero_fill = (!L.fgran_generic && dense_rows) ? 1 : 0;
-      if (m.cfg.sh_lmax <= 1) { h.vrows = vs.rows; h.vn_ne = vs.ne; }
-      h.grid = m.eh_grid;
-      launch_edge_hidden_mm(h, gs);
-    } else if (deep) {
-      PhaseTimer t(m, "k_edge_hidden", gs);
-      float* cur = side ? c.HD_b[0] : c.HD[0];
-      float* nxt = side ? c.HD_b[1] : c.HD[1];
-      DDMI_REQUIRE(cur && nxt, DDMI_ERR_STATE, "tp_weights_layers > 2: hidden-row scratch missing");
-      launch_edge_rows(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, cur, gs);
-      for (int j = 0; j + 2 < L.TL; ++j) {   // hidden Linear + ReLU layers (models/layers.py:14-15), rows in gather order
-        gemm(cur, H, L.Wmid[wg][j], H, L.bmid[wg][j], nxt, H, g.ea_rows, H, H, 1, gs, g.ea_rows_dev);
-        std::swap(cur, nxt);
-      }
-      launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, nullptr, g.tgt, g.tbase, cur, nullptr, nullptr, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
-    } else {
-      PhaseTimer t(m, "k_edge_hidden", gs);
-      launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
+    launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, nullptr, g.tgt, g.tbase, cur, nullptr, nullptr, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
+  } else {
+    PhaseTimer t(m, "k_edge_hidden", gs);
+    launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
+  }
+  const FusedConvArgs f = fused_args(m, L, g, gi, wg, Xin, Hb, rt, small_layer, 0);
+  if (m.timing && m.timing_level >= 2) {   // ddmi_set_kernel_timing(h, 2 | 3): one timing row per edge group / per (layer, edge group)
+    const bool per_layer = m.timing_level >= 3;
+    const std::string tname = "k_conv_fused:" + (per_layer ? "L" + L.name.substr(L.name.size() - 1) : std::string()) + "g" + std::to_string(gi);
+    PhaseTimer t(m, tname.c_str(), gs);
+    launch_conv_fused(f, gs);
+  } else {
+    PhaseTimer t(m, "k_conv_fused", gs);
+    launch_conv_fused(f, gs);
+  }
+}
+
+// Grouped dispatch of a layer (round 6, ddmi_exec_options.grouped): on ONE stream, [per-node terms of the first Linear of every
+// group: one launch] -> [hidden rows of every group: one launch, each group into its own buffer] -> [k_conv_grouped: the work
+// items of every group in one grid].  Same device code and arguments per work item as the per-group launches (bit-identical
+// messages); what changes is that no group waits for another one's launch to drain, a small group (lig-lig: 10-79 tiles) never
+// has the chip to itself, and a layer is 4 launches instead of ~11.  Supported: exact-f32 l <= 1 layers with static chain
+// shapes, two-layer edge MLPs (the benchmark preset); anything else takes the per-group path of run_conv.
+static bool grouped_ok(const Model& m, const ConvW& L, const std::vector<RunGroup>& groups) {
+  const Cx& c = *m.cx;
+  if (!c.Hbg[0] || groups.size() < 2 || groups.size() > 9 || !c.Pg[0]) return false;
+  if (L.TL != 2 || !m.fused_mm || m.ns % 16 != 0 || m.ns > 64 || L.fgran_generic || L.maxd > 3 || m.cfg.sh_lmax > 1 || L.n_fgran <= 0) return false;
+  if (m.cfg.edge_product != 0) return false;
+  if (m.timing && m.timing_level >= 2) return false;   // per-group timing rows need per-group launches
+  for (size_t gi = 0; gi < groups.size(); ++gi)
+    if (!L.W1p[std::min<int>((int)gi, L.G - 1)] || groups[gi].vn < 0) return false;
+  return true;
+}
+static void run_groups_grouped(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, const float* Xin, hipStream_t s) {
+  Cx& c = *m.cx;
+  const int ns = m.ns, H = L.H;
+  {   // per-graph / per-node terms of the first Linear of every group
+    PhaseTimer t(m, "conv_fc1_gemms", s);
+    GemmBatch gb;
+    auto add = [&](const float* A, int lda, const float* W, const float* bias, float* C, int M) {
+      if (gb.n == GEMM_BATCH_MAX) { launch_gemm_batch(gb, s); gb.n = 0; }
+      GemmArgs& x = gb.g[gb.n++];
+      x = GemmArgs{};
+      x.A = A; x.lda = lda; x.W = W; x.ldw = L.n_edge; x.bias = bias; x.C = C; x.ldc = H; x.M = M; x.N = H; x.K = ns;
+    };
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      const RunGroup& g = groups[gi];
+      const int wg = std::min<int>((int)gi, L.G - 1);
+      const float* W1p = L.W1p[wg];
+      if (g.sig) add(g.sig, ns, W1p, nullptr, c.rbg[gi], c.B);
+      add(Xin + (size_t)g.tbase * XS, XS, W1p + (g.swap_pq ? 2 : 1) * ns, nullptr, c.Pg[gi], g.tcount);
+      add(Xin + (size_t)g.gbase * XS, XS, W1p + (g.swap_pq ? 1 : 2) * ns, L.b1p[wg], c.Qg[gi], g.gcount);
     }
-    FusedConvArgs f{};
-    f.nvn = nvn; f.vcap = vs.vcap; f.vn_node = vs.node; f.vrows = vs.rows; f.vn_ne = vs.ne;
-    f.X = Xin; f.gbase = g.gbase; f.wpack = L.wpack[wg]; f.KS = L.KS; f.HK = L.HK; f.Hb = Hb; f.NG8 = L.HKq / 8;
-    f.sh_lmax = m.cfg.sh_lmax; f.gran = L.fgran; f.cgt = L.cgt;
-    f.max_nb = L.max_nb; f.maxd = L.maxd; f.msg = g.msg; f.generic = L.fgran_generic ? 1 : 0;
-    f.dense = dense_rows ? 1 : 0;
-    f.bf = bf ? 1 : 0;
-    f.tile_hdr = (g.vn == 0 && c.prered) ? vs.tile_hdr : nullptr;
-    // ligand gather nodes with >= 2 virtual nodes on average (rec<-lig): a tile of 16 virtual nodes holds few distinct nodes
-    f.shared = (dense_rows && (m.fused_shared == 2 || (m.fused_shared == 1 && g.load && (long)g.ea_rows >= 48L * std::max(1, g.gcount)))) ? 1 : 0;
-    f.prof_slot = (int)gi;
-    // workgroups per tile (granule ranges): 0 = spread a launch with few tiles over the CUs
-    int ys_req = m.fused_ysplit;
-    if (ys_req <= 0) {
-      // Small batches (no group of the layer fills the chip once; tiles ~ gather nodes x ceil(mean degree / 32) / 16): up to
-      // one granule per workgroup, 5 poses 94 -> 100 poses/s.  Otherwise the round-2 rule (at most 6 ranges, tiles estimated
-      // from nodes + edges / 32): the small lig-lig launch that runs next to the big groups is sensitive to its split -- 4
-      // ranges at 40 poses; 5-6 cost the headline 2.5 % (profiles/r03_e27..e37_ab.txt).
-      if (small_layer) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
-      else ys_req = (int)std::min(6L, std::max(1L, 768 / std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16)));
-      const int ys_small = m.fused_ysplit_small;   // tuning: split of a small group next to big ones
-      if (ys_small > 0 && !small_layer && tiles_of(g) < 256) ys_req = ys_small;
+    launch_gemm_batch(gb, s);
+  }
+  for (auto& g : groups) ensure_vn(m, g, s);
+  // workgroups per tile: all groups of the layer share the chip, so the split follows the layer's total tile count
+  long tiles = 0;
+  for (auto& g : groups) tiles += tiles_of(g);
+  int ys = m.grouped_split;
+  if (ys <= 0) ys = (int)std::min(8L, std::max(1L, (long)m.grouped_target / std::max(1L, tiles)));
+  // launch order: the groups with the longest work items first (dense residue / atom gathers), sparse-row groups last -- the short
+  // items of the small groups fill the tail of the launch
+  std::vector<size_t> order(groups.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+    const GroupRoute ra = group_route(m, L, groups[a]), rb_ = group_route(m, L, groups[b]);
+    if (ra.dense_rows != rb_.dense_rows) return ra.dense_rows;
+    return tiles_of(groups[a]) > tiles_of(groups[b]);
+  });
+  for (size_t o0 = 0; o0 < order.size(); o0 += FC_GROUPS_MAX) {
+    const size_t n = std::min<size_t>(FC_GROUPS_MAX, order.size() - o0);
+    EdgeHiddenGroupedArgs HG;
+    FusedGroupedArgs FG;
+    HG.n = FG.n = (int)n;
+    for (size_t k = 0; k < n; ++k) {
+      const size_t gi = order[o0 + k];
+      const RunGroup& g = groups[gi];
+      const int wg = std::min<int>((int)gi, L.G - 1);
+      const GroupRoute rt = group_route(m, L, g);
+      HG.g[k] = hidden_args(m, L, g, wg, c.Pg[gi], c.Qg[gi], g.sig ? c.rbg[gi] : nullptr, c.Hbg[g.vn], rt);
+      HG.g[k].grid = std::max(64, (int)((long)m.eh_grid * tiles_of(g) / std::max(1L, tiles)));   // the launch's workgroups dealt by tile count
+      FG.g[k] = fused_args(m, L, g, gi, wg, Xin, c.Hbg[g.vn], rt, false, ys);
     }
-    ys_req = std::max(ys_req, (L.n_fgran + 19) / 20);   // a workgroup keeps at most 24 granule descriptors in LDS
-    const int ys = std::max(1, std::min(std::min(ys_req, 8), L.n_fgran));
-    f.ysplit = ys;
-    f.gsplit[0] = 0;
-    for (int y = 1; y < ys; ++y) {   // split points at unit boundaries (later granules of a unit add to the first one's stores)
-      int b = L.n_fgran * y / ys;
-      while (b < L.n_fgran && b > 0 && L.fgran_unit[b] == L.fgran_unit[b - 1]) ++b;
-      f.gsplit[y] = std::max(b, f.gsplit[y - 1]);
+    {
+      PhaseTimer t(m, "k_edge_hidden", s);
+      launch_edge_hidden_mm_grouped(HG, s);
     }
-    f.gsplit[ys] = L.n_fgran;
-    f.n_units = 0;
-    for (int gq = 0; gq < L.n_fgran && f.n_units < 48; ++gq)
-      if (gq == 0 || L.fgran_unit[gq] != L.fgran_unit[gq - 1]) f.ustart[f.n_units++] = (short)gq;
-    for (int y = 0; y < ys; ++y) {   // units of every granule range (ranges start at unit boundaries)
-      f.ufirst[y] = 0; f.ucount[y] = 0;
-      for (int u = 0; u < f.n_units; ++u)
-        if (f.ustart[u] >= f.gsplit[y] && f.ustart[u] < f.gsplit[y + 1]) { if (f.ucount[y] == 0) f.ufirst[y] = (short)u; ++f.ucount[y]; }
-    }
-    if (m.timing && m.timing_level >= 2) {   // ddmi_set_kernel_timing(h, 2 | 3): one timing row per edge group / per (layer, edge group)
-      const bool per_layer = m.timing_level >= 3;
-      const std::string tname = "k_conv_fused:" + (per_layer ? "L" + L.name.substr(L.name.size() - 1) : std::string()) + "g" + std::to_string(gi);
-      PhaseTimer t(m, tname.c_str(), gs);
-      launch_conv_fused(f, gs);
-    } else {
-      PhaseTimer t(m, "k_conv_fused", gs);
-      launch_conv_fused(f, gs);
-    }
+    PhaseTimer t(m, "k_conv_fused", s);
+    launch_conv_grouped(FG, s);
   }
 }
 
@@ -321,6 +431,13 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
   long biggest = 1;
   for (auto& q : groups) biggest = std::max(biggest, tiles_of(q));
   const bool small_layer = biggest < 256;
+  if (m.grouped != 1 && grouped_ok(m, L, groups) && (m.grouped == 2 || biggest < m.grouped_below)) {
+    run_groups_grouped(m, L, groups, Xin, s);
+    PhaseTimer t(m, "k_reduce_bn", s);
+    launch_reduce_bn(rg_dev, n_rg, nbase, ncount, L.D_in, L.D_out, L.has_bn ? L.bn_mean : nullptr,
+                     L.has_bn ? L.bn_scale : nullptr, L.has_bn ? L.bn_bias : nullptr, L.residual ? 1 : 0, Xin, Xout, XS, s);
+    return;
+  }
   // The per-graph and per-node terms of the first Linear of EVERY group (P = W1s x_target, Q = W1d x_gather + b1, sigma rows)
   // depend on the layer input only.  Small layers: one batched launch in front of the fork instead of one small launch at the
   // head of every group's chain (5 poses: 101.4 -> 102.9 poses/s).  Large layers keep them per group: there the other stream
@@ -730,6 +847,8 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
       if (lig_v[i]) vmax_b = std::max(vmax_b, vs.vcap);
     }
     c.Hb = HKq > 0 ? dalloc<float>(m, nullptr, {round_up(vmax, 16), 32, round_up(HKq, 16)}) : nullptr;   // whole 16-node tiles, whole pairs of 8-k groups
+    if (m.grouped != 1 && HKq > 0)
+      for (int i = 0; i < (cfg.all_atoms ? 9 : 4); ++i) c.Hbg[i] = dalloc<float>(m, nullptr, {round_up(c.vn[i].vcap, 16), 32, round_up(HKq, 16)});
     c.Hb_b = HKq > 0 ? dalloc<float>(m, nullptr, {round_up(vmax_b, 16), 32, round_up(HKq, 16)}) : nullptr;
   }
   const int ecap[4] = {c.Ell_cap, c.Elr_cap, c.Err, c.Elr_cap};
@@ -1239,7 +1358,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     }
   }
   const float* XL = c.X[xi];
-  c.x_last = XL;
+  c.x_last = conf ? nullptr : XL;   // (a confidence pass leaves no table for ddmi_sidechain_pred to read)
   PhaseTimer t_read(m, "readouts", s);
   if (conf) {   // cg_model.py:353-366: graph-mean of the even (and, from 3 layers on, the odd) scalars -> confidence_predictor
     const int total = cfg.num_conv_layers + cfg.num_prot_emb_layers;
@@ -1268,9 +1387,13 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   score_readouts(m, XL, lig_pos, t_tr, t_rot, t_tor, tr_out, rot_out, tor_out, s);
 }
 
-// models/cg_model.py:397-402: sidechain_predictor (o3.Linear, folded into one [10][K] matrix at commit) on the receptor rows
+// models/cg_model.py:397-402: sidechain_predictor (o3.Linear, folded into one [10][K] matrix at commit) on the receptor rows.
+// Rows = ALL residues of the complex, in their original order: with a device-side crop (ddmi_set_crop_cutoff) the cropped
+// residues are still rows of the node table (BatchNorm(0) + their input row) -- the reference crops the graph first and returns
+// the kept residues only, so the caller compacts the rows through the `crop_keep` mask (MIScoreModel.__call__ does).
 void sidechain_pred(Model& m, float* out, hipStream_t s) {
-  DDMI_REQUIRE(m.has_complex && m.cx->x_last && m.side_Mt, DDMI_ERR_STATE, "ddmi_forward must precede ddmi_sidechain_pred");
+  DDMI_REQUIRE(m.has_complex && m.cx->x_last && m.side_Mt, DDMI_ERR_STATE,
+               "ddmi_sidechain_pred reads the node table of the ddmi_forward directly before it (none since the last ddmi_confidence / ddmi_sample / ddmi_set_complex)");
   Cx& c = *m.cx;
   gemm(c.x_last + (size_t)c.nL * XS, XS, m.side_Mt, m.side_K, nullptr, out, 10, c.nR, 10, m.side_K, 0, s);
 }
@@ -1395,6 +1518,7 @@ void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) 
 #endif
     if (!freeze) modify_conformer(m, lig_pos, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
   }
+  c.x_last = nullptr;   // ddmi_sidechain_pred belongs to the ddmi_forward it follows: the loop's tables are not an answer to it
 }
 
 }  // namespace ddmi

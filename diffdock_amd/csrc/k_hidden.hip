@@ -89,9 +89,8 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 // added as 16-B row pieces, relu applied, and each lane writes two 8-B pieces (16 lanes = 128 contiguous bytes).
 // k-permuted MFMA steps: lane (row, q) fetches floats [q*ns/4, (q+1)*ns/4) of its attribute row with 16-B loads; step t
 // multiplies attr[row][q*ns/4 + t] with W[k][q*ns/4 + t].
-template <int NSQ>   // ns = 16 * NSQ, H = 3 * ns
-__global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
-  DDMI_DYN_SMEM(float, smem);
+template <int NSQ>   // ns = 16 * NSQ, H = 3 * ns; workgroup `block` of `nblocks` of the edge group described by `a`
+__device__ __forceinline__ void eh_body(const EdgeHiddenArgs& a, const int block, const int nblocks, float* __restrict__ smem) {
   constexpr int KS = 4 * NSQ;                        // MFMA steps = floats per lane quarter
   constexpr int H = 48 * NSQ, NB = H / 16, NG8 = H / 8;
   constexpr int HP = H + 1;                          // odd row stride: the staging writes (consecutive threads = consecutive rows) spread over the banks
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
   const int wave = DDMI_UNIFORM(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   const int nvn = *a.nvn;
-  if ((int)blockIdx.x * 4 >= nvn) return;
+  if (block * 4 >= nvn) return;
   // a.W1 is the permuted copy of the first layer (weights.cpp): output position 4a + i of a 16-block holds hidden unit
   // 8 (i >> 1) + 2a + (i & 1), so lane (row, quarter a) ends with k = 8g + 2a + {0, 1} of BOTH 8-k groups g = 2nb, 2nb + 1 --
   // the float4 of fragment lane 16a + row; P, Q and the sigma rows arrive in the same order.
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
   // tiles -- requested one virtual node ahead, two dependent round trips per node instead of five: 1.49 ms per forward either
   // way, profiles/r05_e13_ab.txt.  The kernel moves 215 MB out and 125 MB in per large launch at 3.95 TB/s; what is left is the
   // write-heavy stream itself, not the request chain.)
-  for (int v = blockIdx.x * 4 + wave; v < nvn; v += gridDim.x * 4) {
+  for (int v = block * 4 + wave; v < nvn; v += nblocks * 4) {
     const int d = a.vn_node[v], e0 = a.vn_e0[v];
     const int ne = a.vn_ne ? a.vn_ne[v] : min(32, a.goff[d + 1] - e0);
     // All requests of a (virtual node, row tile) are issued before the first use and nothing in the tile body branches:
@@ -194,6 +193,50 @@ __global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
       }
     }
   }
+}
+
+template <int NSQ>
+__global__ __launch_bounds__(256) void k_edge_hidden_mm(EdgeHiddenArgs a) {
+  DDMI_DYN_SMEM(float, smem);
+  eh_body<NSQ>(a, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+// the hidden rows of several edge groups in one launch: workgroups [first[g], first[g + 1]) serve group g
+template <int NSQ>
+__global__ __launch_bounds__(256) void k_edge_hidden_mm_grouped(EdgeHiddenGroupedArgs G) {
+  DDMI_DYN_SMEM(float, smem);
+  const int b = (int)blockIdx.x;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < EH_GROUPS_MAX; ++i)
+    if (i < G.n && b >= G.first[i]) g = i;
+  eh_body<NSQ>(G.g[g], b - G.first[g], G.first[g + 1] - G.first[g], smem);
+}
+
+void launch_edge_hidden_mm_grouped(const EdgeHiddenGroupedArgs& G_in, hipStream_t s) {
+  EdgeHiddenGroupedArgs G = G_in;
+  if (G.n <= 0) return;
+  if (G.n > EH_GROUPS_MAX) throw Error(DDMI_ERR_ARG, "k_edge_hidden_mm_grouped: too many edge groups in one launch");
+  int blocks = 0;
+  const int ns = G.g[0].ns, H = G.g[0].H;
+  for (int i = 0; i < G.n; ++i) {
+    const EdgeHiddenArgs& a = G.g[i];
+    if (a.ns != ns || a.H != H || a.ns % 16 != 0 || a.ns > 64 || a.H != 3 * a.ns || a.NG8 * 8 != a.H)
+      throw Error(DDMI_ERR_ARG, "k_edge_hidden_mm_grouped: unsupported / mixed widths");
+    G.first[i] = blocks;
+    // the launch has the chip to itself (no fused workgroups next to it): every group gets its share of a.grid workgroups by
+    // virtual-node capacity, at least one
+    blocks += a.vcap > 0 ? std::max(1, std::min(cdiv(a.vcap, 4), a.grid > 0 ? a.grid : 2048)) : 0;
+  }
+  G.first[G.n] = blocks;
+  if (blocks <= 0) return;
+  const size_t smem = (size_t)(ns * (H + 1)) * sizeof(float);
+  switch (ns / 16) {
+    case 1: hipLaunchKernelGGL(k_edge_hidden_mm_grouped<1>, dim3(blocks), dim3(256), smem, s, G); break;
+    case 2: hipLaunchKernelGGL(k_edge_hidden_mm_grouped<2>, dim3(blocks), dim3(256), smem, s, G); break;
+    case 3: hipLaunchKernelGGL(k_edge_hidden_mm_grouped<3>, dim3(blocks), dim3(256), smem, s, G); break;
+    default: hipLaunchKernelGGL(k_edge_hidden_mm_grouped<4>, dim3(blocks), dim3(256), smem, s, G); break;
+  }
+  DDMI_CHECK_HIP(hipGetLastError());
 }
 
 void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s) {

@@ -115,6 +115,14 @@ struct EdgeHiddenArgs {
   int grid;        // workgroups (ddmi_exec_options.hidden_grid); 0 = 2048
 };
 void launch_edge_hidden_mm(const EdgeHiddenArgs& a, hipStream_t s);
+// the hidden rows of several edge groups in one launch (each group into its own Hb; grouped dispatch of the convolution)
+constexpr int EH_GROUPS_MAX = 4;
+struct EdgeHiddenGroupedArgs {
+  int n = 0;
+  int first[EH_GROUPS_MAX + 1] = {};   // first workgroup of every group; first[n] = grid size
+  EdgeHiddenArgs g[EH_GROUPS_MAX];
+};
+void launch_edge_hidden_mm_grouped(const EdgeHiddenGroupedArgs& G, hipStream_t s);
 
 struct FusedConvArgs {
   const int* nvn; int vcap;              // live virtual nodes (device) and their capacity (grid size)
@@ -139,10 +147,26 @@ struct FusedConvArgs {
   int dbg = 0;
   int prof_slot = 0;                     // profiling builds: edge-group slot of the in-kernel phase clocks
 };
-#if defined(DDMI_PROFILING) && DDMI_PROFILING >= 2
+#if defined(DDMI_PROFILING)
 void fc_prof_report();                   // prints and clears the phase clocks of k_conv_fused (stderr)
 #endif
 void launch_conv_fused(const FusedConvArgs& a, hipStream_t s);
+
+// Grouped dispatch (round 6; k_conv_grp.hip): the work items (tile, granule range) of SEVERAL edge groups of one interaction layer
+// in one grid -- the groups are independent until the joint mean (models/tensor_layers.py:148-231).  Block b belongs to group g
+// with first[g] <= b < first[g + 1]; inside the group, block = first[g] + range * ntile[g] + tile (all tiles of range 0, then
+// range 1, ... -- the order the 2-D grid of k_conv_fused dispatches, measured better than range-adjacent, profiles/r05_e17_ab.txt).
+// Exact-f32 l <= 1 layers with static chain shapes only (mode 0 sparse rows, 3 dense rows, 4 shared-node tiles).
+constexpr int FC_GROUPS_MAX = 4;
+struct FusedGroupedArgs {
+  int n = 0;
+  int first[FC_GROUPS_MAX + 1] = {};
+  int ntile[FC_GROUPS_MAX] = {};
+  int mode[FC_GROUPS_MAX] = {};
+  FusedConvArgs g[FC_GROUPS_MAX];
+};
+static_assert(sizeof(FusedGroupedArgs) <= 3072, "kernel arguments of k_conv_grouped (4 KB limit)");
+void launch_conv_grouped(const FusedGroupedArgs& G, hipStream_t s);
 
 struct ReduceGroup { const int* toff; const float* msg; int tbase, tcount; const unsigned char* live = nullptr; };   // live: rows to read (nullptr: all)
 // X_out[s] = BN(mean over all groups' incoming messages) + pad(X_in[s]) for s in [nbase, nbase+ncount)

@@ -155,6 +155,12 @@ void build_weight_spec(Model& m) {
   const int TL = c.tp_weights_layers <= 0 ? 2 : c.tp_weights_layers;
   DDMI_REQUIRE(TL >= 2 && TL <= 8, DDMI_ERR_ARG, "tp_weights_layers must be >= 2 (FCBlock asserts it, models/layers.py:12)");
   DDMI_REQUIRE(c.embedding_type == 0 || c.embedding_type == 1, DDMI_ERR_ARG, "embedding_type: 0 sinusoidal, 1 fourier");
+  // (ahead of the early returns of the legacy / confidence branches below: init_conv_meta would otherwise build depthwise
+  // layers for class families that do not have them)
+  DDMI_REQUIRE(!(c.depthwise_convolution && (c.all_atoms || c.old_model)), DDMI_ERR_ARG,
+               "depthwise_convolution: CG models of the new class only (AAModel asserts it away, models/aa_model.py:39; get_model(old=True) never passes it)");
+  DDMI_REQUIRE(!(c.sidechain_pred && (c.all_atoms || c.old_model)), DDMI_ERR_ARG,
+               "sidechain_pred: CG models of the new class only (AAModel asserts it away, models/aa_model.py:38; the legacy class has no such head)");
   const Irreps sh = sh_irreps(c.sh_lmax);
   const bool faster = c.sh_lmax == 1 && !c.use_second_order_repr;
   const int K = c.num_prot_emb_layers, Lc = c.num_conv_layers;
@@ -283,10 +289,7 @@ void build_weight_spec(Model& m) {
     predictor("confidence_predictor", n_in, c.num_confidence_outputs + (c.affinity_prediction ? 1 : 0));
     return;
   }
-  DDMI_REQUIRE(!(c.depthwise_convolution && (c.all_atoms || c.old_model)), DDMI_ERR_ARG,
-               "depthwise_convolution: CG models of the new class only (AAModel asserts it away, models/aa_model.py:39; get_model(old=True) never passes it)");
   if (c.sidechain_pred) {   // models/cg_model.py:173-178: o3.Linear(last_out -> 4x0e + 2x1e + 4x0o + 2x1o), one flat weight vector
-    DDMI_REQUIRE(!c.all_atoms, DDMI_ERR_ARG, "sidechain_pred: CG models only (AAModel asserts it away, models/aa_model.py:38)");
     int n = 0;
     for (auto& b : last_out) n += b.mul * ((b.l == 0) ? 4 : (b.l == 1) ? 2 : 0);
     S.push_back({"sidechain_predictor.weight", {n}});

@@ -249,13 +249,16 @@ class MIScoreModel:
         if self.cfg.sidechain_pred:   # models/cg_model.py:397-402: [n_rec, 10]
             side = torch.empty(int(data["receptor"].pos.shape[0]), 10, device=dev)
             _lib.check(self.lib, self.lib.ddmi_sidechain_pred(self._h, _ptr(side), self._stream()))
+            if getattr(self, "_crop_cutoff", 0.0) > 0.0:   # the reference crops the graph first: rows of the kept residues only
+                side = side[torch.from_numpy(self.debug_buffer("crop_keep") != 0).to(dev)]
         return tr, rot, tor, side
 
     forward = __call__
 
     def set_crop_cutoff(self, cutoff):
         """crop_beyond(graph, cutoff) for the following model(batch) calls (utils/utils.py:388-413); None / 0 = off."""
-        _lib.check(self.lib, self.lib.ddmi_set_crop_cutoff(self._h, float(cutoff or 0.0)))
+        self._crop_cutoff = float(cutoff or 0.0)
+        _lib.check(self.lib, self.lib.ddmi_set_crop_cutoff(self._h, self._crop_cutoff))
 
     def modify_conformer_batch(self, pos, data, tr_update, rot_update, torsion_updates, mask_rotate=None):
         """utils/diffusion_utils.py:60-78 on the device (same argument order; mask_rotate comes from the batch)."""

@@ -158,17 +158,36 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             if confidence_model is not None:   # sampling.py:208-227
                 if conf_batches is not None:
                     cgraphs = next(conf_batches)
+                    alive = list(range(b))
                     if conf_crop is not None:   # sampling.py:213-217: every confidence graph cropped around ITS final pose
                         cgraphs = [g_.clone() for g_ in cgraphs]
+                        alive = []
                         for i, g_ in enumerate(cgraphs):
                             g_["ligand"].pos = pos[i].detach().to(g_["receptor"].pos.device, g_["receptor"].pos.dtype)
-                            crop_beyond(g_, conf_crop, bool(getattr(confidence_model_args, "all_atoms", False)))
-                    cbatch = _collate(cgraphs)
-                    cbatch["ligand"].pos = pos.reshape(b * n, 3).to(cbatch["ligand"].pos.device)
+                            try:
+                                crop_beyond(g_, conf_crop, bool(getattr(confidence_model_args, "all_atoms", False)))
+                                alive.append(i)
+                            except ValueError:
+                                # A pose that flew farther than the cutoff from EVERY residue has no receptor graph left to score.
+                                # The reference hands such an empty graph to the confidence model; the built path cannot, so that
+                                # ONE pose gets NaN (-> -1000 below, the value nan_to_num gives a failed pose) and the others of
+                                # the batch are scored as usual.  Only a batch without any scorable pose raises.
+                                pass
+                        if not alive:
+                            raise ValueError(f"crop_beyond({conf_crop}) removes every residue of every pose of the batch: nothing to score")
+                    cbatch = _collate([cgraphs[i] for i in alive])
+                    pos_alive = pos if len(alive) == b else pos[torch.as_tensor(alive, device=pos.device)]
+                    cbatch["ligand"].pos = pos_alive.reshape(len(alive) * n, 3).to(cbatch["ligand"].pos.device)
                     if device is not None:
                         cbatch = cbatch.to(device)
-                    set_time(cbatch, 0, 0, 0, b, device=cbatch["ligand"].pos.device)
+                    set_time(cbatch, 0, 0, 0, len(alive), device=cbatch["ligand"].pos.device)
                     out = confidence_model(cbatch)
+                    if len(alive) != b:   # graph-level outputs back in batch order, NaN for the poses that could not be scored
+                        def scatter_rows(o):
+                            full = torch.full((b,) + tuple(o.shape[1:]), float("nan"), device=o.device, dtype=o.dtype)
+                            full[torch.as_tensor(alive, device=o.device)] = o
+                            return full
+                        out = (scatter_rows(out[0]),) + tuple(out[1:]) if isinstance(out, tuple) else scatter_rows(out)
                 else:   # the sampling batch itself, still carrying the last step's times (sampling.py:113-114, 223)
                     batch["ligand"].pos = pos.reshape(b * n, 3)
                     set_time(batch, schedules[0][-1], schedules[1][-1], schedules[2][-1], b, device=batch["ligand"].pos.device)

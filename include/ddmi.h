@@ -64,6 +64,12 @@ typedef struct ddmi_exec_options {
                              * update split by node type and every group's chain started as soon as the rows it reads exist, for
                              * chip-filling batches; 2 = that for every batch size.  Same kernels and arithmetic (bit-identical scores);
                              * measured neutral at 40 poses and -6 % at 5 (profiles/r05_e11_ab.txt), hence not the default.            */
+  int32_t grouped;          /* grouped dispatch of an interaction layer (round 6): per layer ONE launch of the per-node first-Linear terms,
+                             * ONE of the hidden rows and ONE k_conv_grouped walking the (edge group, tile, granule range) work items of
+                             * every edge group, on one stream -- instead of a hidden-row + k_conv_fused launch per group on two streams.
+                             * 0 = the library's size rule, 1 = never (per-group launches), 2 = wherever supported (exact-f32 l <= 1
+                             * layers with a two-layer edge MLP; others keep the per-group path).  Bit-identical messages either way.   */
+  int32_t grouped_split;    /* workgroups per 16-virtual-node tile in grouped launches (granule ranges), 1..8; 0 = automatic           */
 } ddmi_exec_options;
 
 /* Hyper-parameters: the keyword arguments get_model passes to CGModel

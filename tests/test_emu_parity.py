@@ -548,6 +548,77 @@ def test_sampling_crops_confidence_graphs_like_the_reference(emu_lib):
     assert conf.shape == fx["confidence"].shape and rel_err(conf.cpu(), fx["confidence"]) < 1e-4
 
 
+def test_sampling_scores_the_other_poses_when_one_confidence_graph_is_fully_cropped(emu_lib):
+    """One pose farther than crop_beyond from every residue of ITS confidence graph (here: that graph's receptor moved 1000 A away)
+    must not cost the whole batch its confidence scores: that pose gets -1000 (what nan_to_num gives a failed pose,
+    utils/sampling.py:229), the others the scores they get without it; only a batch with no scorable pose raises."""
+    import argparse
+    import copy
+    from diffdock_amd.sampling import sampling
+    fx = load_fixture("conf_crop")
+    fs, cfg, data_list = fixture_case("tiny_l1")
+    fc, ccfg, _ = fixture_case("tiny_conf_l2")
+    score = make_model(cfg, fs["state_dict"], emu_lib)
+    conf_model = MIScoreModel(ccfg, device="cpu", lib_path=emu_lib)
+    conf_model.load_state_dict(fc["state_dict"])
+    B, R = len(data_list), int(data_list[0]["ligand"].edge_mask.sum())
+    sched = get_t_schedule(fx["steps"])
+    cargs = argparse.Namespace(crop_beyond=fx["crop_beyond"], all_atoms=False)
+
+    def run(conf_list):
+        return sampling(copy.deepcopy(data_list), score, fx["steps"], sched, sched, sched, model_args=cfg, confidence_model=conf_model,
+                        confidence_data_list=conf_list, confidence_model_args=cargs, batch_size=B, no_final_step_noise=True,
+                        noise=split_draws(fx["draws"], fx["steps"], B, R))[1]
+    full = run(copy.deepcopy(data_list))
+    far = copy.deepcopy(data_list)
+    far[1]["receptor"].pos = far[1]["receptor"].pos + 1000.0
+    conf = run(far)
+    assert conf.shape == full.shape
+    assert bool((conf[1] == -1000).all())
+    keep = [i for i in range(B) if i != 1]
+    assert rel_err(conf[keep].cpu(), full[keep].cpu()) < 1e-4
+    for g in far:
+        g["receptor"].pos = g["receptor"].pos + 1000.0
+    with pytest.raises(ValueError, match="every pose"):
+        run(far)
+
+
+def test_sidechain_pred_under_a_device_crop_and_after_other_passes(emu_lib):
+    """sidechain_pred with crop_beyond: the reference crops the graph first and returns rows for the KEPT residues only
+    (utils/utils.py:388-413, models/cg_model.py:397-402); the library's node table still holds every residue, so
+    MIScoreModel.__call__ compacts the rows through the device's crop mask.  And ddmi_sidechain_pred belongs to the ddmi_forward
+    directly before it: after a sampling loop on the same handle it raises instead of reading that pass's table."""
+    import copy
+    from diffdock_amd.lib import DdmiError
+    from oracle.sampling import crop_beyond
+    fs, cfg, data_list = fixture_case("tiny_sidechain")
+    m = make_model(cfg, fs["state_dict"], emu_lib)
+    d = torch.cdist(data_list[0]["ligand"].pos, data_list[0]["receptor"].pos).min(0).values
+    cutoff = float(d.sort().values[len(d) // 2]) + 1e-3      # about half of the residues of pose 0 survive
+    cropped = [crop_beyond(copy.deepcopy(g), cutoff) for g in data_list]
+    n_keep = sum(int(c["receptor"].pos.shape[0]) for c in cropped)
+    assert 0 < n_keep < sum(int(g["receptor"].pos.shape[0]) for g in data_list)
+    ob = HeteroBatch.from_data_list(cropped)
+    set_time(ob, 0.4, 0.4, 0.4, ob.num_graphs)
+    ref = oracle_model(cfg, fs["state_dict"])(ob)
+    batch = HeteroBatch.from_data_list(data_list)
+    set_time(batch, 0.4, 0.4, 0.4, batch.num_graphs)
+    m.set_crop_cutoff(cutoff)
+    out = m(batch)
+    m.set_crop_cutoff(None)
+    assert out[3].shape == ref[3].shape == (n_keep, 10)
+    assert rel_err(out[3], ref[3]) < 1e-4
+    for o, r in zip(out[:3], ref[:3]):
+        assert rel_err(o, r) < 1e-4
+    # a sampling loop in between: the table of its last step is not what ddmi_sidechain_pred may read
+    sched = get_t_schedule(2)
+    m.sample_batch(batch, 2, (sched, sched, sched), seed=1, sample_ids=list(range(batch.num_graphs)), no_final_step_noise=True)
+    side = torch.empty(int(batch["receptor"].pos.shape[0]), 10)
+    with pytest.raises(DdmiError):
+        from diffdock_amd import lib as _l
+        _l.check(m.lib, m.lib.ddmi_sidechain_pred(m._h, side.data_ptr(), None))
+
+
 def test_all_atom_ragged_batch_and_empty_ligand_atom_group(emu_lib):
     """AAModel on a batch of two DIFFERENT complexes (residue / atom / ligand counts differ), first with one ligand out of
     reach of every receptor atom, then with the ligand<->atom group completely empty (the reference's FasterTensorProduct
@@ -650,3 +721,41 @@ def test_layer_overlap_is_bit_identical(emu_lib):
     for a_, b_ in zip(*outs):
         assert torch.equal(a_, b_)
     assert torch.equal(traj[0], traj[1])
+
+
+def test_grouped_dispatch_is_bit_identical(emu_lib):
+    """ddmi_exec_options.grouped (round 6): per interaction layer ONE launch of the first-Linear node terms, ONE of the hidden rows
+    (each edge group into its own buffer) and ONE k_conv_grouped walking the (edge group, tile, granule range) work items of every
+    group -- the same device code and arguments per work item as the per-group k_conv_fused launches, so the scores are
+    bit-identical: grouped (2) against per-group launches (1), with two granule-range splits, on the CG model (4 groups, sidechain
+    rows, one step of the device loop under the per-step crop) and the all-atom model (9 groups = three grouped launches)."""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    sched = get_t_schedule(1)
+    for all_atoms in (False, True):
+        g = make_complex(seed=4, n_res=16, n_lig=10, lm_dim=0, all_atoms=all_atoms, **({"atoms_per_res": (2, 4)} if all_atoms else {}))
+        dl = make_pose_list(g, 2, tr_sigma_max=5.0, seed=6, initial_noise_std_proportion=0.3)
+        cfg = replace(DDL_SYNTH, num_conv_layers=3, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_min=0.1,
+                      tr_sigma_max=0.5, sidechain_pred=not all_atoms, all_atoms=all_atoms)
+        sd = init_state_dict(cfg, seed=3)
+        outs, traj, launches = [], [], []
+        for opts in ((("grouped", 1),), (("grouped", 2),), (("grouped", 2), ("grouped_split", 3))):
+            m = make_model(cfg.replace(exec_options=opts), sd, emu_lib)
+            b = HeteroBatch.from_data_list(dl)
+            set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+            m.set_kernel_timing(True)
+            outs.append([o.clone() for o in m(b) if o is not None])
+            launches.append(m.kernel_timings()["k_conv_fused"][1])
+            m.set_kernel_timing(False)
+            traj.append(m.sample_batch(HeteroBatch.from_data_list(dl), 1, (sched, sched, sched), seed=11, sample_ids=[0, 1],
+                                       no_final_step_noise=True, crop_beyond=None if all_atoms else 3.0).clone())
+        # per-group: one launch per (layer, group); grouped: one per layer (all-atom: nine groups in chunks of four)
+        assert launches[0] == (9 + 9 + 3 if all_atoms else 4 + 4 + 2)
+        assert launches[1] == launches[2] == (3 + 3 + 1 if all_atoms else 3)
+        for k in (1, 2):
+            assert len(outs[0]) == len(outs[k])
+            for a_, b_ in zip(outs[0], outs[k]):
+                assert torch.equal(a_, b_)
+            assert torch.equal(traj[0], traj[k])

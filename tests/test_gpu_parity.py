@@ -123,12 +123,15 @@ def width48_case():
 
 @pytest.mark.parametrize("env", [{"DDMI_FUSED_PACK": "0"}, {"DDMI_FUSED_DENSE": "0"},
                                  {"DDMI_FUSED_DENSE": "2"}, {"DDMI_FUSED_MM": "0"}, {"DDMI_STREAMS": "1"}, {"DDMI_FUSED_YS": "3"},
-                                 {"DDMI_FUSED_SHARED": "0"}, {"DDMI_FUSED_SHARED": "2", "DDMI_FUSED_DENSE": "2"}, {"DDMI_FC1_BATCH": "0"}, {"DDMI_FUSED_TRI": "0"}, {"DDMI_FUSED_PRERED": "0"}],
+                                 {"DDMI_FUSED_SHARED": "0"}, {"DDMI_FUSED_SHARED": "2", "DDMI_FUSED_DENSE": "2"}, {"DDMI_FC1_BATCH": "0"}, {"DDMI_FUSED_TRI": "0"}, {"DDMI_FUSED_PRERED": "0"},
+                                 {"DDMI_GROUPED": "1"}, {"DDMI_GROUPED": "2"}, {"DDMI_GROUPED": "2", "DDMI_GROUPED_YS": "3"},
+                                 {"DDMI_GROUPED": "2", "DDMI_FUSED_PRERED": "0", "DDMI_FUSED_SHARED": "0"}],
                          ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
 def test_selectable_kernel_paths_agree_on_the_gpu(env, width48_case, monkeypatch):
     """Every selectable route of an edge group (classic instead of packed granules for the 10-channel vector blocks,
     sparse- / dense-row loop, GEMM first layer, one stream, granule-range splits,
-    the rec<-lig group per virtual node instead of per distinct gather node / every group through the shared-node kernel)
+    the rec<-lig group per virtual node instead of per distinct gather node / every group through the shared-node kernel,
+    per-group launches on two streams / one grouped launch per layer)
     against the default route and the oracle at the benchmark width.  The routes are fields of ddmi_config.exec (the library
     reads no environment variable); diffdock_amd/lib.py maps these harness variables onto them when a model handle is created,
     so each handle is built under its own environment."""
@@ -484,3 +487,35 @@ def test_layer_overlap_is_bit_identical_at_full_size():
     for mode in (1, 2):
         assert all(torch.equal(x, y) for x, y in zip(res[mode][0], res[0][0])), mode
         assert torch.equal(res[mode][1], res[0][1]), mode
+
+
+def test_grouped_dispatch_is_bit_identical_at_full_size():
+    """ddmi_exec_options.grouped: BASELINE configs[2] shapes (40 poses) and one GPU's share of configs[3] (5 poses) -- one
+    k_conv_grouped launch per interaction layer (2, also with a forced granule-range split) against one k_conv_fused launch per
+    (layer, edge group) on two streams (1): the same device code and arguments per work item, so every score and the 5-step
+    device loop (per-step crop included) are equal bit for bit; the launch counts say which route ran."""
+    sd = init_state_dict(DDL_SYNTH, seed=1234)
+    g = make_complex(seed=4, n_res=300, n_lig=30)
+    sched = get_t_schedule(5)
+    for B in (40, 5):
+        dl = make_pose_list(g, B, tr_sigma_max=DDL_SYNTH.tr_sigma_max, seed=5, initial_noise_std_proportion=0.6)
+        res = {}
+        for key, opts in (("per_group", (("grouped", 1),)), ("grouped", (("grouped", 2),)), ("grouped_ys3", (("grouped", 2), ("grouped_split", 3)))):
+            m = gpu_model(DDL_SYNTH.replace(exec_options=opts), sd)
+            outs = []
+            for rep in range(2):
+                b = HeteroBatch.from_data_list(dl)
+                set_time(b, 0.5, 0.5, 0.5, B)
+                if rep == 1:
+                    m.set_kernel_timing(True)
+                outs.append([o.clone() for o in m(to_gpu(b))[:3]])
+            n_launch = m.kernel_timings()["k_conv_fused"][1]
+            m.set_kernel_timing(False)
+            assert n_launch == (22 if key == "per_group" else 6), (key, n_launch)
+            assert all(torch.equal(x, y) for x, y in zip(outs[1], outs[0])), key
+            traj = m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl)), 5, (sched, sched, sched), seed=123, sample_ids=list(range(B)),
+                                  no_final_step_noise=True, crop_beyond=20.0).clone()
+            res[key] = (outs[0], traj)
+        for key in ("grouped", "grouped_ys3"):
+            assert all(torch.equal(x, y) for x, y in zip(res[key][0], res["per_group"][0])), (B, key)
+            assert torch.equal(res[key][1], res["per_group"][1]), (B, key)

@@ -21,7 +21,7 @@ for p in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_VALU_M
   DDMI_STREAMS=1 rocprofv3 --kernel-trace --pmc $p -d /tmp/pmc$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-serialised-pass > /tmp/pmc$i.log 2>&1
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(find /tmp/pmc$i -name "*.db" | head -1) >> $out/${tag}_pmc_summary.txt 2>&1
 done
-python $GRAFT_REPO_ROOT/tools/traffic_json.py $(find /tmp/pmc3 -name "*.db" | head -1) $(find /tmp/pmc4 -name "*.db" | head -1) k_conv_fused configs2 \
+python $GRAFT_REPO_ROOT/tools/traffic_json.py $(find /tmp/pmc3 -name "*.db" | head -1) $(find /tmp/pmc4 -name "*.db" | head -1) k_conv_ configs2 \
   "profiles/${tag}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT+TCC_MISS passes, kernels serialised on one stream)" \
   $(find /tmp/pmc5 -name "*.db" | head -1) > $out/${tag}_traffic.json 2>> $out/${tag}_pmc_summary.txt
 cp $out/${tag}_traffic.json $GRAFT_REPO_ROOT/profiles/traffic_latest.json

@@ -22,14 +22,16 @@ def counter(db, name, sub):
 fetch_db, write_db, sub, config, note = sys.argv[1:6]
 n, fkb = counter(fetch_db, "FETCH_SIZE", sub)
 _, wkb = counter(write_db, "WRITE_SIZE", sub)
-out = {"kernel": sub, "config": config, "launches": n, "fetch_size_kb_per_launch": fkb, "write_size_kb_per_launch": wkb,
+# (the timer row of bench.py is "k_conv_fused" for both dispatches: k_conv_fused per (layer, group) and k_conv_grouped per layer --
+# pass the substring "k_conv_" to count whichever the run launched)
+out = {"kernel": "k_conv_fused" if sub.startswith("k_conv") else sub, "kernel_match": sub, "config": config, "launches": n, "fetch_size_kb_per_launch": fkb, "write_size_kb_per_launch": wkb,
        "bytes_per_launch": fkb * 1024 * 2 + wkb * 1024,
        "source": note,
        "corrections": "FETCH_SIZE doubled (gfx950 counts half of a wide coalesced read); WRITE_SIZE uncalibrated; counters come "
                       "from the L2's fabric side, so Infinity-Cache hits are included"}
-# the kernel source the counters were collected on: bench.py refuses to replay the record next to a different k_conv.hip
-src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffdock_amd", "csrc", "k_conv.hip")
-out["kernel_source"] = "diffdock_amd/csrc/k_conv.hip"
+# the kernel source the counters were collected on: bench.py refuses to replay the record next to a different k_conv_tile.h
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffdock_amd", "csrc", "k_conv_tile.h")
+out["kernel_source"] = "diffdock_amd/csrc/k_conv_tile.h"
 out["kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
 # the scatter stage (k_reduce_bn) from the same passes: bench.py's roofline_scatter.traffic
 ns, sfkb = counter(fetch_db, "FETCH_SIZE", "k_reduce_bn")
