@@ -70,6 +70,7 @@ struct Model::Cx {
   ReduceGroup *rg_aa_all = nullptr, *rg_aa_lig = nullptr;
   long epoch = 0;
   float *Hb = nullptr, *Hb_b = nullptr;   // hidden rows of the main-stream / side-stream group in flight
+  std::vector<float*> rb_l;                 // fused node-update route: per-graph first-Linear term of the rec-rec group of every interaction layer [B][H]
   float* Hbg[9] = {};                       // grouped dispatch: hidden rows of every virtual-node list (all groups of a layer are in flight at once)
   float *HD[2] = {nullptr, nullptr}, *HD_b[2] = {nullptr, nullptr};   // tp_weights_layers > 2: plain per-edge hidden rows [E][H]
   ReduceGroup *rg_all, *rg_lig, *rg_ll, *rg_rr;
@@ -148,6 +149,8 @@ struct RunGroup {
   int vn = -1;     // >= 0: virtual-node list id -> eligible for the fused kernel
   bool load = false;   // gather nodes are ligand atoms (few nodes, possibly many edges each): candidates for the shared-node tiles of k_conv_fused
   bool swap_pq = false;   // first Linear sees [edge, GATHER node, TARGET node] (legacy lig->rec layer, old_cg_model.py:263)
+  const float* rb_ready = nullptr;   // per-graph term W1e . sig of THIS layer already computed ([B][H]; fused node-update route)
+  bool static_topo = false;   // edges, geometry and slots are per-complex constants (rec-rec without a crop, the atom relations): lists built once
 };
 
 // tiles of 16 virtual nodes of an edge group ~ gather nodes x ceil(mean degree / 32) / 16; a SMALL layer = no group fills the chip once
@@ -158,19 +161,63 @@ static long tiles_of(const RunGroup& q) {
 
 // Virtual-node lists and per-edge rows of an edge group (k_vn_count -> scan -> k_vn_fill -> k_vn_rows [-> k_vn_tiles]): built on the
 // first use in a forward, rebuilt when any input they bake in changes.
-static void ensure_vn(Model& m, const RunGroup& g, hipStream_t gs) {
-  Cx& c = *m.cx;
+static bool vn_fresh(const Cx& c, const RunGroup& g) {
+  const Cx::VnSet& vs = c.vn[g.vn];
+  return vs.built_goff == g.goff && (vs.epoch == c.epoch || (g.static_topo && vs.epoch >= 0)) && vs.built_tgt == g.tgt && vs.built_tslot == g.tslot &&
+         vs.built_arow == g.arow && vs.built_nvec == g.nvec && vs.built_ew == g.ew && vs.built_sgn == g.sgn && vs.built_tbase == g.tbase;
+}
+static void vn_mark_built(Cx& c, const RunGroup& g) {
   Cx::VnSet& vs = c.vn[g.vn];
-  if (vs.built_goff == g.goff && vs.epoch == c.epoch && vs.built_tgt == g.tgt && vs.built_tslot == g.tslot && vs.built_arow == g.arow &&
-      vs.built_nvec == g.nvec && vs.built_ew == g.ew && vs.built_sgn == g.sgn && vs.built_tbase == g.tbase) return;
-  PhaseTimer t(m, "vn_build", gs);
+  vs.built_goff = g.goff; vs.epoch = c.epoch; vs.built_tgt = g.tgt; vs.built_tslot = g.tslot; vs.built_arow = g.arow;
+  vs.built_nvec = g.nvec; vs.built_ew = g.ew; vs.built_sgn = g.sgn; vs.built_tbase = g.tbase;
+}
+static VnRowsArgs vn_rows_args(const Model& m, const RunGroup& g) {
+  const Cx::VnSet& vs = m.cx->vn[g.vn];
   VnRowsArgs vr{};
   vr.arow = g.arow; vr.nvec = g.nvec; vr.ew = g.ew; vr.tslot = g.tslot; vr.sgn = g.sgn; vr.sh_lmax = m.cfg.sh_lmax;
   vr.tgt = g.tgt; vr.tbase = g.tbase;
   vr.vcap = vs.vcap; vr.rows = vs.rows; vr.vn_ne = vs.ne;
+  return vr;
+}
+static const char vn_type[9] = {'R', 'R', 'L', 'L', 'A', 'A', 'A', 'L', 'R'};   // gather-node type of every virtual-node list (set_complex)
+// the stale lists of a layer's groups in two launches (+ the tile headers of the pre-reduced group)
+static void ensure_vn_all(Model& m, const std::vector<RunGroup>& groups, hipStream_t gs) {
+  Cx& c = *m.cx;
+  VnListsArgs LA;
+  VnRowsArgs rows[VN_GROUPS_MAX];
+  const RunGroup* prered_g = nullptr;
+  for (auto& g : groups) {
+    if (vn_fresh(c, g) || g.gcount <= 0) continue;
+    DDMI_REQUIRE(LA.n < VN_GROUPS_MAX, DDMI_ERR_CAPACITY, "more edge groups than virtual-node list slots");
+    Cx::VnSet& vs = c.vn[g.vn];
+    VnListArgs& a = LA.g[LA.n];
+    a = VnListArgs{g.goff, g.gcount, vs.voff, vs.node, vs.e0, nullptr, nullptr, 0, nullptr};
+    if (vs.nvn_pad) {
+      const bool lig = vn_type[g.vn] == 'L', atom = vn_type[g.vn] == 'A';
+      a.node_batch = lig ? c.lig_batch : atom ? c.atom_batch : c.rec_batch;
+      a.graph_ptr = lig ? c.lig_ptr : atom ? c.atom_ptr : c.rec_ptr;
+      a.n_graphs = c.B; a.nvn_pad = vs.nvn_pad;
+    }
+    rows[LA.n++] = vn_rows_args(m, g);
+    if (g.vn == 0 && c.prered) prered_g = &g;
+    vn_mark_built(c, g);
+  }
+  if (LA.n == 0) return;
+  PhaseTimer t(m, "vn_build", gs);
+  launch_vn_build_all(LA, rows, m.cfg.sh_lmax, gs);
+  if (prered_g) {
+    Cx::VnSet& vs = c.vn[0];
+    launch_vn_tiles(vs.nvn_pad ? vs.nvn_pad : vs.voff + prered_g->gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
+  }
+}
+static void ensure_vn(Model& m, const RunGroup& g, hipStream_t gs) {
+  Cx& c = *m.cx;
+  Cx::VnSet& vs = c.vn[g.vn];
+  if (vn_fresh(c, g)) return;
+  PhaseTimer t(m, "vn_build", gs);
+  const VnRowsArgs vr = vn_rows_args(m, g);
   VnPoseTiles pp{};
   if (vs.nvn_pad) {   // graph of every gather node: ligand / receptor / atom rows of the node table
-    static const char vn_type[9] = {'R', 'R', 'L', 'L', 'A', 'A', 'A', 'L', 'R'};   // gather-node type of every virtual-node list (set_complex)
     const bool lig = vn_type[g.vn] == 'L', atom = vn_type[g.vn] == 'A';
     pp.node_batch = lig ? c.lig_batch : atom ? c.atom_batch : c.rec_batch;
     pp.graph_ptr = lig ? c.lig_ptr : atom ? c.atom_ptr : c.rec_ptr;
@@ -178,8 +225,7 @@ static void ensure_vn(Model& m, const RunGroup& g, hipStream_t gs) {
   }
   launch_vn_build(g.goff, g.gcount, vs.cnt, vs.voff, vs.node, vs.e0, vr, gs, vs.nvn_pad ? &pp : nullptr);
   if (g.vn == 0 && c.prered) launch_vn_tiles(vs.nvn_pad ? vs.nvn_pad : vs.voff + g.gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
-  vs.built_goff = g.goff; vs.epoch = c.epoch; vs.built_tgt = g.tgt; vs.built_tslot = g.tslot; vs.built_arow = g.arow;
-  vs.built_nvec = g.nvec; vs.built_ew = g.ew; vs.built_sgn = g.sgn; vs.built_tbase = g.tbase;
+  vn_mark_built(c, g);
 }
 
 // row mode / arithmetic of an edge group's fused launch
@@ -280,7 +326,7 @@ static void run_group(Model& m, const ConvW& L, const RunGroup& g, size_t gi, bo
   const bool deep = L.TL > 2;   // FCBlock with hidden Linear layers: first layer as plain per-edge rows, the hidden ones as GEMMs
   const bool fuse_mm = !deep && m.fused_mm && ns % 16 == 0 && ns <= 64 && L.W1p[wg];   // first Linear inside the hidden-row kernel
   if (mm_all) {
-    if (g.sig) rb = rowbias;
+    if (g.sig) rb = g.rb_ready ? g.rb_ready : rowbias;
   } else if (fuse_mm) {   // everything in the emission order of k_edge_hidden_mm (permuted copy of the first layer)
     PhaseTimer t(m, "conv_fc1_gemms", gs);
     const float* W1p = L.W1p[wg];
@@ -354,10 +400,10 @@ static bool grouped_ok(const Model& m, const ConvW& L, const std::vector<RunGrou
     if (!L.W1p[std::min<int>((int)gi, L.G - 1)] || groups[gi].vn < 0) return false;
   return true;
 }
-static void run_groups_grouped(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, const float* Xin, hipStream_t s) {
+static void run_groups_grouped(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, const float* Xin, hipStream_t s, bool pq_ready) {
   Cx& c = *m.cx;
   const int ns = m.ns, H = L.H;
-  {   // per-graph / per-node terms of the first Linear of every group
+  if (!pq_ready) {   // per-graph / per-node terms of the first Linear of every group
     PhaseTimer t(m, "conv_fc1_gemms", s);
     GemmBatch gb;
     auto add = [&](const float* A, int lda, const float* W, const float* bias, float* C, int M) {
@@ -370,13 +416,13 @@ static void run_groups_grouped(Model& m, const ConvW& L, const std::vector<RunGr
       const RunGroup& g = groups[gi];
       const int wg = std::min<int>((int)gi, L.G - 1);
       const float* W1p = L.W1p[wg];
-      if (g.sig) add(g.sig, ns, W1p, nullptr, c.rbg[gi], c.B);
+      if (g.sig && !g.rb_ready) add(g.sig, ns, W1p, nullptr, c.rbg[gi], c.B);
       add(Xin + (size_t)g.tbase * XS, XS, W1p + (g.swap_pq ? 2 : 1) * ns, nullptr, c.Pg[gi], g.tcount);
       add(Xin + (size_t)g.gbase * XS, XS, W1p + (g.swap_pq ? 1 : 2) * ns, L.b1p[wg], c.Qg[gi], g.gcount);
     }
     launch_gemm_batch(gb, s);
   }
-  for (auto& g : groups) ensure_vn(m, g, s);
+  ensure_vn_all(m, groups, s);
   // workgroups per tile: all groups of the layer share the chip, so the split follows the layer's total tile count
   long tiles = 0;
   for (auto& g : groups) tiles += tiles_of(g);
@@ -401,7 +447,7 @@ static void run_groups_grouped(Model& m, const ConvW& L, const std::vector<RunGr
       const RunGroup& g = groups[gi];
       const int wg = std::min<int>((int)gi, L.G - 1);
       const GroupRoute rt = group_route(m, L, g);
-      HG.g[k] = hidden_args(m, L, g, wg, c.Pg[gi], c.Qg[gi], g.sig ? c.rbg[gi] : nullptr, c.Hbg[g.vn], rt);
+      HG.g[k] = hidden_args(m, L, g, wg, c.Pg[gi], c.Qg[gi], g.sig ? (g.rb_ready ? g.rb_ready : c.rbg[gi]) : nullptr, c.Hbg[g.vn], rt);
       HG.g[k].grid = std::max(64, (int)((long)m.eh_grid * tiles_of(g) / std::max(1L, tiles)));   // the launch's workgroups dealt by tile count
       FG.g[k] = fused_args(m, L, g, gi, wg, Xin, c.Hbg[g.vn], rt, false, ys);
     }
@@ -415,10 +461,38 @@ static void run_groups_grouped(Model& m, const ConvW& L, const std::vector<RunGr
 }
 
 // One TensorProductConvLayer in the node-contracted form (k_conv.hip).
+// pq_mode: 0 = the per-node terms of the first Linear as the size rule says (per group, or batched for small layers), 1 = all of
+// them in one launch in front of the groups (first layer of the fused node-update route), 2 = already there (written by the
+// previous layer's k_node_update).  Lnext / gnext: the NEXT interaction layer and its groups -- the node update then also
+// produces their per-node terms (k_node_update instead of k_reduce_bn).
 void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, const ReduceGroup* rg_dev, int n_rg,
-              const float* Xin, float* Xout, int nbase, int ncount, hipStream_t s) {
+              const float* Xin, float* Xout, int nbase, int ncount, hipStream_t s, int pq_mode = 0, const ConvW* Lnext = nullptr,
+              const std::vector<RunGroup>* gnext = nullptr) {
   Cx& c = *m.cx;
   const int ns = m.ns, H = L.H;
+  auto node_update = [&]() {   // the layer's node update: mean over all groups' messages + BatchNorm + residual (+ the next layer's P / Q)
+    if (!Lnext) {
+      PhaseTimer t(m, "k_reduce_bn", s);
+      launch_reduce_bn(rg_dev, n_rg, nbase, ncount, L.D_in, L.D_out, L.has_bn ? L.bn_mean : nullptr,
+                       L.has_bn ? L.bn_scale : nullptr, L.has_bn ? L.bn_bias : nullptr, L.residual ? 1 : 0, Xin, Xout, XS, s);
+      return;
+    }
+    PhaseTimer t(m, "k_reduce_bn", s);   // (same timer row: the scatter stage of the layer)
+    NodeUpdateArgs a{};
+    a.groups = rg_dev; a.n_groups = n_rg; a.nbase = nbase; a.ncount = ncount; a.D_in = L.D_in; a.D_out = L.D_out;
+    a.bn_mean = L.has_bn ? L.bn_mean : nullptr; a.bn_scale = L.has_bn ? L.bn_scale : nullptr; a.bn_bias = L.has_bn ? L.bn_bias : nullptr;
+    a.residual = L.residual ? 1 : 0; a.X_in = Xin; a.X_out = Xout;
+    a.ns = ns; a.H = Lnext->H; a.ldw = Lnext->n_edge;
+    for (size_t gi = 0; gi < gnext->size(); ++gi) {
+      const RunGroup& g = (*gnext)[gi];
+      const int wg = std::min<int>((int)gi, Lnext->G - 1);
+      const float* W1p = Lnext->W1p[wg];
+      DDMI_REQUIRE(a.n_terms + 2 <= NU_TERMS_MAX, DDMI_ERR_CAPACITY, "k_node_update: more first-Linear terms than slots");
+      a.term[a.n_terms++] = NodeTerm{W1p + (g.swap_pq ? 2 : 1) * ns, nullptr, c.Pg[gi], g.tbase, g.tcount};
+      a.term[a.n_terms++] = NodeTerm{W1p + (g.swap_pq ? 1 : 2) * ns, Lnext->b1p[wg], c.Qg[gi], g.gbase, g.gcount};
+    }
+    launch_node_update(a, s);
+  };
   // Groups whose gather nodes are ligand atoms (few nodes, many edges each: MFMA-bound) run on the side stream with
   // their own scratch, concurrently with the receptor-gather groups (HBM-bound on the contracted rows).
   bool forked = false;
@@ -431,20 +505,22 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
   long biggest = 1;
   for (auto& q : groups) biggest = std::max(biggest, tiles_of(q));
   const bool small_layer = biggest < 256;
-  if (m.grouped != 1 && grouped_ok(m, L, groups) && (m.grouped == 2 || biggest < m.grouped_below)) {
-    run_groups_grouped(m, L, groups, Xin, s);
-    PhaseTimer t(m, "k_reduce_bn", s);
-    launch_reduce_bn(rg_dev, n_rg, nbase, ncount, L.D_in, L.D_out, L.has_bn ? L.bn_mean : nullptr,
-                     L.has_bn ? L.bn_scale : nullptr, L.has_bn ? L.bn_bias : nullptr, L.residual ? 1 : 0, Xin, Xout, XS, s);
+  // (default = per-group launches on two streams: the grouped dispatch shortens the time covered by fused workgroups by 3-5 % but
+  // leaves the hidden rows of the whole layer exposed in front of it -- 151.5 against 155.2 poses/s at 40 poses, 124.8 / 127.3 at
+  // 10, 106.8 / 107.9 at 5, profiles/r06_p2_*)
+  if (m.grouped == 2 && grouped_ok(m, L, groups)) {
+    run_groups_grouped(m, L, groups, Xin, s, pq_mode == 2);
+    node_update();
     return;
   }
   // The per-graph and per-node terms of the first Linear of EVERY group (P = W1s x_target, Q = W1d x_gather + b1, sigma rows)
   // depend on the layer input only.  Small layers: one batched launch in front of the fork instead of one small launch at the
   // head of every group's chain (5 poses: 101.4 -> 102.9 poses/s).  Large layers keep them per group: there the other stream
   // fills the gap, and a common launch in front of the fork delays the side stream (40 poses: -0.5 %; profiles/r03_e42_ab.txt).
-  bool mm_all = L.TL == 2 && m.fc1_batch && small_layer && m.fused_mm && ns % 16 == 0 && ns <= 64 && groups.size() <= 9 && c.Pg[0];
+  bool mm_all = L.TL == 2 && (pq_mode != 0 || (m.fc1_batch && small_layer)) && m.fused_mm && ns % 16 == 0 && ns <= 64 && groups.size() <= 9 && c.Pg[0];
   for (size_t gi = 0; gi < groups.size(); ++gi) mm_all = mm_all && L.W1p[std::min<int>((int)gi, L.G - 1)];
-  if (mm_all) {
+  DDMI_REQUIRE(pq_mode == 0 || mm_all, DDMI_ERR_STATE, "fused node-update route on a layer without batched first-Linear terms");
+  if (mm_all && pq_mode != 2) {
     PhaseTimer t(m, "conv_fc1_gemms", s);
     GemmBatch gb;
     auto add = [&](const float* A, int lda, const float* W, const float* bias, float* C, int M) {
@@ -457,12 +533,15 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
       const RunGroup& g = groups[gi];
       const int wg = std::min<int>((int)gi, L.G - 1);
       const float* W1p = L.W1p[wg];
-      if (g.sig) add(g.sig, ns, W1p, nullptr, c.rbg[gi], c.B);
+      if (g.sig && !g.rb_ready) add(g.sig, ns, W1p, nullptr, c.rbg[gi], c.B);
       add(Xin + (size_t)g.tbase * XS, XS, W1p + (g.swap_pq ? 2 : 1) * ns, nullptr, c.Pg[gi], g.tcount);
       add(Xin + (size_t)g.gbase * XS, XS, W1p + (g.swap_pq ? 1 : 2) * ns, L.b1p[wg], c.Qg[gi], g.gcount);
     }
     launch_gemm_batch(gb, s);
   }
+  // virtual-node lists and per-edge rows of every group whose topology changed since they were built (first layer of a forward):
+  // two launches in front of the fork instead of a count -> scan -> fill -> rows chain at the head of every group's stream
+  if (m.vn_merge) ensure_vn_all(m, groups, s);
   if (forked) {
     DDMI_CHECK_HIP(hipEventRecord(m.ev_fork, s));
     DDMI_CHECK_HIP(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0));
@@ -480,9 +559,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     DDMI_CHECK_HIP(hipEventRecord(m.ev_join, m.side_stream));
     DDMI_CHECK_HIP(hipStreamWaitEvent(s, m.ev_join, 0));
   }
-  PhaseTimer t(m, "k_reduce_bn", s);
-  launch_reduce_bn(rg_dev, n_rg, nbase, ncount, L.D_in, L.D_out, L.has_bn ? L.bn_mean : nullptr,
-                   L.has_bn ? L.bn_scale : nullptr, L.has_bn ? L.bn_bias : nullptr, L.residual ? 1 : 0, Xin, Xout, XS, s);
+  node_update();
 }
 
 // The interaction layers of the CG model with the layer boundaries overlapped (round 5, ddmi_exec_options.layer_overlap; NOT the
@@ -808,6 +885,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
   for (int i = 0; i < (cfg.all_atoms ? 9 : 4); ++i) {
     c.Pg[i] = dalloc<float>(m, nullptr, {N, H}); c.Qg[i] = dalloc<float>(m, nullptr, {N, H}); c.rbg[i] = dalloc<float>(m, nullptr, {B, H});
   }
+  for (size_t l = 0; l < m.conv_layers.size(); ++l) c.rb_l.push_back(dalloc<float>(m, nullptr, {B, H}));
   std::vector<const ConvW*> all_layers;
   for (auto* fam : {&m.conv_layers, &m.lig_emb_layers, &m.rec_emb_layers, &m.old_lig, &m.old_rec, &m.old_l2r, &m.old_r2l})
     for (auto& L : *fam) all_layers.push_back(&L);
@@ -847,7 +925,7 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
       if (lig_v[i]) vmax_b = std::max(vmax_b, vs.vcap);
     }
     c.Hb = HKq > 0 ? dalloc<float>(m, nullptr, {round_up(vmax, 16), 32, round_up(HKq, 16)}) : nullptr;   // whole 16-node tiles, whole pairs of 8-k groups
-    if (m.grouped != 1 && HKq > 0)
+    if (m.grouped == 2 && HKq > 0)
       for (int i = 0; i < (cfg.all_atoms ? 9 : 4); ++i) c.Hbg[i] = dalloc<float>(m, nullptr, {round_up(c.vn[i].vcap, 16), 32, round_up(HKq, 16)});
     c.Hb_b = HKq > 0 ? dalloc<float>(m, nullptr, {round_up(vmax_b, 16), 32, round_up(HKq, 16)}) : nullptr;
   }
@@ -1298,6 +1376,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   RunGroup g_rl{0, nL, nL, nR, c.offs_l, c.g3_tgt, c.g3_tslot, nullptr, c.cross_ea, c.Elr_cap, c.offs_l + nL, nullptr,
                 nullptr, c.pnvec, c.pew, -1.f, c.msg[3]};
   g_lr.vn = 0; g_rr.vn = 1; g_rl.vn = 3; g_rl.load = true;
+  g_rr.static_topo = !crop;   // the contact graph of an uncropped receptor is a per-complex constant: its lists and per-edge rows are built once
   // ligand gather nodes carry up to Nr edges each: their 32-edge passes are dealt over several workgroups
   const int Lc = (int)m.conv_layers.size();
   if (cfg.all_atoms) {
@@ -1330,6 +1409,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     RunGroup a_ar{nL, nR, aB, nA, c.se_ar.goff, c.se_ar.tgt, c.se_ar.tslot, c.se_ar.arow, c.ar_edge_base, c.Ear, nullptr, c.rec_sig,
                   c.ar_batch, c.ar_nvec, nullptr, 1.f, c.msg_aa[8]};
     a_la.vn = 4; a_ra.vn = 5; a_aa.vn = 6; a_al.vn = 7; a_al.load = true; a_ar.vn = 8;
+    a_ra.static_topo = a_aa.static_topo = a_ar.static_topo = true;   // static atom relations (set_complex)
     t_phase.reset();
     for (int l = 0; l < Lc; ++l, ++xi) {
       if (l < Lc - 1)
@@ -1347,12 +1427,41 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
       for (const RunGroup* q : {&g_ll, &g_lr, &g_rr, &g_rl}) biggest = std::max(biggest, tiles_of(*q));
       overlapped = biggest >= 256 || m.layer_overlap == 2;
     }
+    // Fused node update (ddmi_exec_options.node_update = 0): k_node_update writes a layer's rows AND the next layer's per-node
+    // first-Linear terms P / Q, so only the first layer launches its GEMMs; the per-graph sigma term of the rec-rec group of every
+    // layer comes from one batched launch here.
+    bool nu = m.node_update && !overlapped && Lc >= 2 && m.fused_mm && ns % 16 == 0 && ns <= 64 && c.Pg[0] && (int)c.rb_l.size() == Lc;
+    for (auto& L : m.conv_layers) {
+      nu = nu && L.TL == 2 && L.H == m.conv_layers[0].H && L.n_edge == m.conv_layers[0].n_edge;
+      for (int g = 0; g < 4; ++g) nu = nu && L.W1p[std::min(g, L.G - 1)];
+    }
+    if (nu) {
+      PhaseTimer t(m, "conv_fc1_gemms", s);
+      GemmBatch gb;
+      for (int l = 0; l < Lc - 1; ++l) {   // (the last layer has no rec-rec group)
+        const ConvW& L = m.conv_layers[l];
+        if (gb.n == GEMM_BATCH_MAX) { launch_gemm_batch(gb, s); gb.n = 0; }
+        GemmArgs& x = gb.g[gb.n++];
+        x = GemmArgs{};
+        x.A = c.rec_sig; x.lda = ns; x.W = L.W1p[std::min(2, L.G - 1)]; x.ldw = L.n_edge; x.C = c.rb_l[l]; x.ldc = L.H; x.M = B; x.N = L.H; x.K = ns;
+      }
+      if (gb.n) launch_gemm_batch(gb, s);
+    }
     if (overlapped) run_conv_layers_overlapped(m, g_ll, g_lr, g_rr, g_rl, crop ? c.rg_all_crop : c.rg_all, xi, s);
     else
     for (int l = 0; l < Lc; ++l, ++xi) {
+      RunGroup rr = g_rr;
+      if (nu && l < Lc - 1) rr.rb_ready = c.rb_l[l];
+      const std::vector<RunGroup> full = {g_ll, g_lr, rr, g_rl}, ligs = {g_ll, g_lr};
+      std::vector<RunGroup> next;
+      if (nu && l + 1 < Lc) {
+        if (l + 1 < Lc - 1) next = {g_ll, g_lr, g_rr, g_rl}; else next = ligs;
+      }
+      const int pq = !nu ? 0 : l == 0 ? 1 : 2;
+      const ConvW* Ln = next.empty() ? nullptr : &m.conv_layers[l + 1];
       if (l < Lc - 1)
-        run_conv(m, m.conv_layers[l], {g_ll, g_lr, g_rr, g_rl}, crop ? c.rg_all_crop : c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s);
-      else run_conv(m, m.conv_layers[l], {g_ll, g_lr}, c.rg_lig, 2, c.X[xi], c.X[xi + 1], 0, cfg.sidechain_pred ? c.N : nL, s);
+        run_conv(m, m.conv_layers[l], full, crop ? c.rg_all_crop : c.rg_all, 4, c.X[xi], c.X[xi + 1], 0, c.N, s, pq, Ln, Ln ? &next : nullptr);
+      else run_conv(m, m.conv_layers[l], ligs, c.rg_lig, 2, c.X[xi], c.X[xi + 1], 0, cfg.sidechain_pred ? c.N : nL, s, pq);
       // (sidechain_pred reads the RECEPTOR rows of the last table: in the reference the last layer writes them too -- no message
       // reaches them, so they are BatchNorm(0) + the padded input row, cg_model.py:345-349 -- the score read-outs only need the ligand rows)
     }

@@ -50,7 +50,11 @@ __global__ void k_vn_fill_pp(const int* __restrict__ goff, const int* __restrict
     const int nb = voff[graph_ptr[b + 1]] - voff[graph_ptr[b]];
     const int padb = ((nb + 15) & ~15) - nb;
     for (int j = 0; j < padb; ++j) { vn_node[v0 + n + j] = d; vn_e0[v0 + n + j] = e1; }
-    if (b == n_graphs - 1) *nvn_pad = voff[gcount] + pad + padb;
+  }
+  if (d == gcount - 1) {   // padded list length: from ONE thread over ALL graphs (a last graph without gather nodes of this type must not leave it unwritten)
+    int tot = 0;
+    for (int q = 0; q < n_graphs; ++q) { const int nq = voff[graph_ptr[q + 1]] - voff[graph_ptr[q]]; tot += ((nq + 15) & ~15) - nq; }
+    *nvn_pad = voff[gcount] + tot;
   }
 }
 // Per-edge rows of the fused kernel, once per forward and edge group (the six layers share the graph): virtual node v, edge
@@ -58,8 +62,8 @@ __global__ void k_vn_fill_pp(const int* __restrict__ goff, const int* __restrict
 // and for the dead virtual nodes of the last 16-node tile; vn_ne[v] = edges of the virtual node.  The tile prologue of
 // k_conv_fused then is one coalesced copy instead of the chain vn_e0 -> arow -> nvec / weight / slot.
 template <int SHD, int ES>
-__global__ __launch_bounds__(256) void k_vn_rows(VnRowsArgs a) {
-  const int v = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
+__device__ __forceinline__ void vn_rows_body(const VnRowsArgs& a, const int block) {
+  const int v = block * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
   const int nvn = *a.nvn;
   if (v >= ((nvn + 15) & ~15)) return;   // whole 16-node tiles (FC_VN)
   int ne = 0, e0 = 0;
@@ -91,6 +95,93 @@ __global__ __launch_bounds__(256) void k_vn_rows(VnRowsArgs a) {
     reinterpret_cast<int*>(er)[SHD + 3] = tg;
   }
   if (r == 0) a.vn_ne[v] = ne;
+}
+template <int SHD, int ES>
+__global__ __launch_bounds__(256) void k_vn_rows(VnRowsArgs a) { vn_rows_body<SHD, ES>(a, (int)blockIdx.x); }
+// the per-edge rows of several edge groups in one launch (grouped dispatch): workgroups [first[g], first[g + 1]) serve group g
+template <int SHD, int ES>
+__global__ __launch_bounds__(256) void k_vn_rows_grouped(VnRowsGroupedArgs G) {
+  const int b = (int)blockIdx.x;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < VN_GROUPS_MAX; ++i)
+    if (i < G.n && b >= G.first[i]) g = i;
+  vn_rows_body<SHD, ES>(G.g[g], b - G.first[g]);
+}
+
+// Virtual-node lists of several edge groups in ONE launch (round 6): workgroup = edge group; count -> scan -> fill in one pass
+// over the group's gather nodes (thread t owns the nodes [t * per, (t + 1) * per): its running offset is the block scan of the
+// chunk sums), instead of k_vn_count -> k_exclusive_scan -> k_vn_fill per group (three dependent launches each, 12 per forward).
+// node_batch != nullptr: tile_per_pose lists (every graph padded to whole 16-node tiles by dead virtual nodes, k_vn_fill_pp).
+__global__ __launch_bounds__(1024) void k_vn_lists(VnListsArgs A) {
+  __shared__ int part[1024];
+  const VnListArgs& a = A.g[blockIdx.x];
+  const int t = threadIdx.x, n = a.gcount;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(t * per, n), hi = min(lo + per, n);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += (a.goff[i + 1] - a.goff[i] + 31) >> 5;
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  const int total = part[1023];
+  if (!a.node_batch) {
+    for (int i = lo; i < hi; ++i) {
+      const int e0 = a.goff[i], e1 = a.goff[i + 1], c = (e1 - e0 + 31) >> 5;
+      a.voff[i] = run;
+      for (int b = 0; b < c; ++b) { a.vn_node[run + b] = i; a.vn_e0[run + b] = min(e0 + 32 * b, e1); }
+      run += c;
+    }
+    if (t == 1023) a.voff[n] = total;
+    return;
+  }
+  for (int i = lo, r2 = run; i < hi; ++i) { a.voff[i] = r2; r2 += (a.goff[i + 1] - a.goff[i] + 31) >> 5; }
+  if (t == 1023) a.voff[n] = total;
+  __syncthreads();   // voff of the whole group (written by this workgroup) before the per-graph sizes are read
+  for (int i = lo; i < hi; ++i) {
+    const int b = a.node_batch[i];
+    int pad = 0;
+    for (int q = 0; q < b; ++q) { const int nq = a.voff[a.graph_ptr[q + 1]] - a.voff[a.graph_ptr[q]]; pad += ((nq + 15) & ~15) - nq; }
+    const int e0 = a.goff[i], e1 = a.goff[i + 1], c = (e1 - e0 + 31) >> 5, v0 = a.voff[i] + pad;
+    for (int j = 0; j < c; ++j) { a.vn_node[v0 + j] = i; a.vn_e0[v0 + j] = min(e0 + 32 * j, e1); }
+    if (i == a.graph_ptr[b + 1] - 1) {   // last gather node of its graph: dead virtual nodes up to the tile boundary
+      const int nb = a.voff[a.graph_ptr[b + 1]] - a.voff[a.graph_ptr[b]];
+      const int padb = ((nb + 15) & ~15) - nb;
+      for (int j = 0; j < padb; ++j) { a.vn_node[v0 + c + j] = i; a.vn_e0[v0 + c + j] = e1; }
+    }
+  }
+  if (t == 0) {
+    int tot = 0;
+    for (int q = 0; q < a.n_graphs; ++q) { const int nq = a.voff[a.graph_ptr[q + 1]] - a.voff[a.graph_ptr[q]]; tot += ((nq + 15) & ~15) - nq; }
+    *a.nvn_pad = total + tot;
+  }
+}
+void launch_vn_build_all(const VnListsArgs& L, const VnRowsArgs* rows, int sh_lmax, hipStream_t s) {
+  if (L.n <= 0) return;
+  hipLaunchKernelGGL(k_vn_lists, dim3(L.n), dim3(1024), 0, s, L);
+  VnRowsGroupedArgs R;
+  int blocks = 0;
+  for (int i = 0; i < L.n; ++i) {
+    if (!rows[i].rows) continue;
+    VnRowsArgs r = rows[i];
+    r.nvn = L.g[i].node_batch ? L.g[i].nvn_pad : L.g[i].voff + L.g[i].gcount;
+    r.vn_node = L.g[i].vn_node; r.vn_e0 = L.g[i].vn_e0; r.goff = L.g[i].goff;
+    R.first[R.n] = blocks;
+    R.g[R.n++] = r;
+    blocks += cdiv(round_up(r.vcap, 16), 8);
+  }
+  R.first[R.n] = blocks;
+  if (blocks > 0) {
+    if (sh_lmax <= 1) hipLaunchKernelGGL((k_vn_rows_grouped<4, 8>), dim3(blocks), dim3(256), 0, s, R);
+    else hipLaunchKernelGGL((k_vn_rows_grouped<9, 12>), dim3(blocks), dim3(256), 0, s, R);
+  }
+  DDMI_CHECK_HIP(hipGetLastError());
 }
 void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, const VnRowsArgs& rows_in,
                      hipStream_t s, const VnPoseTiles* pp) {

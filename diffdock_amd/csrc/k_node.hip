@@ -1,0 +1,163 @@
+// Fused node update of an interaction layer (round 6): for a tile of 16 target nodes
+//   X_out[s] = BatchNorm(mean over ALL incoming messages of s) + pad(X_in[s])          (k_reduce_bn: torch_scatter mean over the joint
+//                                                                                        edge list, e3nn BatchNorm, residual --
+//                                                                                        models/tensor_layers.py:220-229,327-332)
+//   P_g[s] = W1s_g . X_out[s][:ns],   Q_g[s] = W1d_g . X_out[s][:ns] + b1_g              (the per-node terms of the NEXT layer's first
+//                                                                                        Linear on [edge_attr | x_target | x_gather],
+//                                                                                        models/tensor_layers.py:140,211, models/layers.py:10-17)
+// in one kernel: the node row is still in the workgroup when the next layer's first-Linear terms are taken from it, so the
+// k_gemm_nt_batch launch at the head of every layer (and its dependency level) disappears.  The reduction keeps k_reduce_bn's
+// summation tree (four partial sums by row index mod 4 per group, (s0 + s1) + (s2 + s3)): X_out is bit-identical to the unfused
+// path; P / Q come off the 16x16x4 f32 MFMA with the k index permuted for 16-byte weight loads -- equal to the GEMM's up to the
+// order of a 48-term fp32 sum.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace ddmi {
+
+typedef float vf4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nu_load4(const float* p) {
+  const vf4n v = DDMI_NT_LOAD(reinterpret_cast<const vf4n*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nu_add(float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+
+constexpr int NU_TILE = 16;
+
+template <int NSQ>   // ns = 16 * NSQ
+__global__ __launch_bounds__(256) void k_node_update(NodeUpdateArgs a) {
+  constexpr int NS = 16 * NSQ, XST = NS + 4;
+  __shared__ float xs[NU_TILE][XST];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = DDMI_UNIFORM(tid >> 6);
+  const int n0 = a.nbase + (int)blockIdx.x * NU_TILE, n_end = a.nbase + a.ncount;
+  const bool live = 4 * lane < a.D_out;      // columns past D_out inside the XS-wide row are never used
+  // ---- phase 1: wave w reduces the tile's nodes w, w + 4, w + 8, w + 12
+  for (int q = 0; q < NU_TILE / 4; ++q) {
+    const int slot = wave + 4 * q, s = n0 + slot;
+    if (s >= n_end) {
+      if (4 * lane < NS) *reinterpret_cast<float4*>(&xs[slot][4 * lane]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    float4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;
+    for (int g = 0; g < a.n_groups; ++g) {
+      const ReduceGroup G = a.groups[g];
+      const int sl = s - G.tbase;
+      if (sl < 0 || sl >= G.tcount) continue;
+      const int b = G.toff[sl], e = G.toff[sl + 1];
+      cnt += e - b;
+      const float* __restrict__ mp = G.msg + 4 * lane;
+      if (G.live) {   // pre-reduced group: only the flagged rows hold (partial) sums; the row of ordinal o goes to partial sum o mod 4
+        int ord = 0;
+        for (int base = b; base < e; base += 64) {
+          const int rr = base + lane;
+          unsigned long long mask = __ballot(rr < e && G.live[rr] != 0);
+          while (mask) {
+            int rows[4], which[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              rows[i] = -1; which[i] = 0;
+              if (mask) { rows[i] = base + __builtin_ctzll(mask); mask &= mask - 1; which[i] = ord++ & 3; }
+            }
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (live && rows[i] >= 0) ? nu_load4(mp + (size_t)rows[i] * XS) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // (which[i] is wave-uniform; four consecutive ordinals hit four different partial sums)
+              if (rows[i] < 0) continue;
+              if (which[i] == 0) nu_add(acc[0], v[i]);
+              else if (which[i] == 1) nu_add(acc[1], v[i]);
+              else if (which[i] == 2) nu_add(acc[2], v[i]);
+              else nu_add(acc[3], v[i]);
+            }
+          }
+        }
+      } else if (live) {
+        int r = b;
+        for (; r + 8 <= e; r += 8) {   // rows r + i -> partial sum i mod 4, in increasing row order per partial sum
+          float4 v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = nu_load4(mp + (size_t)(r + i) * XS);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) nu_add(acc[i & 3], v[i]);
+        }
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = r + i < e ? nu_load4(mp + (size_t)(r + i) * XS) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (r + i < e) nu_add(acc[i & 3], v[i]);
+      }
+    }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * lane < XS) {
+      float sum[4] = {(acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y),
+                      (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)};
+      float ov[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * lane + i;
+        float v = 0.f;
+        if (c < a.D_out) {
+          v = cnt > 0 ? sum[i] / (float)cnt : 0.f;
+          if (a.bn_scale) v = (v - a.bn_mean[c]) * a.bn_scale[c] + a.bn_bias[c];
+          if (a.residual && c < a.D_in) v += a.X_in[(size_t)s * XS + c];
+        }
+        ov[i] = v;
+      }
+      o = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      *reinterpret_cast<float4*>(a.X_out + (size_t)s * XS + 4 * lane) = o;
+      if (4 * lane < NS) *reinterpret_cast<float4*>(&xs[slot][4 * lane]) = o;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: the next layer's first-Linear terms of the tile: out_t[16 nodes][H] = xs[16][ns] . W_t^T (+ bias_t), 16 hidden units
+  // per MFMA column block.  Lane (lr, lq) supplies k = 16 jj + 4 lq + i in step (jj, i) for both operands, so its weight
+  // fragments are whole 16-byte pieces of a weight row.
+  const int lr = lane & 15, lq = lane >> 4;
+  const int nb_h = a.H / 16, n_tasks = a.n_terms * nb_h;
+  for (int task = wave; task < n_tasks; task += 4) {
+    const int t = task / nb_h, h0 = 16 * (task - t * nb_h);
+    const NodeTerm T = a.term[t];
+    if (n0 + NU_TILE <= T.base || n0 >= T.base + T.count) continue;   // (wave-uniform)
+    float4 bw[NSQ];
+    const float* __restrict__ wrow = T.W + (size_t)(h0 + lr) * a.ldw + 4 * lq;
+#pragma unroll
+    for (int jj = 0; jj < NSQ; ++jj) bw[jj] = *reinterpret_cast<const float4*>(wrow + 16 * jj);
+    const float bias = T.bias ? T.bias[h0 + lr] : 0.f;
+    f32x4 acc = f32x4{bias, bias, bias, bias};
+#pragma unroll
+    for (int jj = 0; jj < NSQ; ++jj) {
+      const float4 xa = *reinterpret_cast<const float4*>(&xs[lr][16 * jj + 4 * lq]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, bw[jj].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, bw[jj].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, bw[jj].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, bw[jj].w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = n0 + 4 * lq + r;
+      if (s >= T.base && s < T.base + T.count && s < n_end) T.out[(size_t)(s - T.base) * a.H + h0 + lr] = acc[r];
+    }
+  }
+}
+
+void launch_node_update(const NodeUpdateArgs& a, hipStream_t s) {
+  if (a.ncount <= 0) return;
+  if (a.ns % 16 != 0 || a.ns > 64 || a.H % 16 != 0 || a.n_terms > NU_TERMS_MAX || a.ldw % 4 != 0)
+    throw Error(DDMI_ERR_ARG, "k_node_update: unsupported width");
+  const dim3 grid((unsigned)cdiv(a.ncount, NU_TILE));
+  switch (a.ns / 16) {
+    case 1: hipLaunchKernelGGL(k_node_update<1>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_node_update<2>, grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(k_node_update<3>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(k_node_update<4>, grid, dim3(256), 0, s, a); break;
+  }
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace ddmi

@@ -83,6 +83,14 @@ struct VnRowsArgs {
 struct VnPoseTiles { const int* node_batch; const int* graph_ptr; int n_graphs; int* nvn_pad; };
 void launch_vn_build(const int* goff, int gcount, int* cnt_tmp, int* voff, int* vn_node, int* vn_e0, const VnRowsArgs& rows,
                      hipStream_t s, const VnPoseTiles* pp = nullptr);
+// the same for several edge groups in two launches (k_vn_lists: count -> scan -> fill, workgroup = group; k_vn_rows_grouped)
+constexpr int VN_GROUPS_MAX = 9;
+struct VnListArgs { const int* goff; int gcount; int* voff; int* vn_node; int* vn_e0;
+                    const int* node_batch; const int* graph_ptr; int n_graphs; int* nvn_pad; };   // node_batch == nullptr: dense lists
+struct VnListsArgs { int n = 0; VnListArgs g[VN_GROUPS_MAX]; };
+struct VnRowsGroupedArgs { int n = 0; int first[VN_GROUPS_MAX + 1] = {}; VnRowsArgs g[VN_GROUPS_MAX]; };
+static_assert(sizeof(VnRowsGroupedArgs) <= 2048 && sizeof(VnListsArgs) <= 2048, "kernel arguments");
+void launch_vn_build_all(const VnListsArgs& lists, const VnRowsArgs* rows /* [lists.n], nvn / vn_node / vn_e0 / goff filled here */, int sh_lmax, hipStream_t s);
 // In-tile pre-reduction of the messages (groups whose 16 virtual nodes of a tile send to the same few targets: lig<-rec, where
 // 16 residues address the <= 32 atoms of one ligand).  Per tile a header of FC_TILE_HDR ints: [0] = 1 when the tile's targets
 // span <= 32 consecutive target rows (else the tile stores one message row per edge as before), [1] = first target row,
@@ -173,6 +181,20 @@ struct ReduceGroup { const int* toff; const float* msg; int tbase, tcount; const
 void launch_reduce_bn(const ReduceGroup* groups_dev, int n_groups, int nbase, int ncount, int D_in, int D_out,
                       const float* bn_mean, const float* bn_scale, const float* bn_bias, int residual,
                       const float* X_in, float* X_out, int out_stride, hipStream_t s);
+
+// Fused node update (k_node.hip): launch_reduce_bn for the rows [nbase, nbase + ncount) of a layer AND, from the finished rows,
+// the per-node terms of the NEXT layer's first Linear: term t writes out_t[s - base_t][H] = W_t[H][ldw-strided rows] . X_out[s][:ns]
+// (+ bias_t) for the nodes s in [base_t, base_t + count_t) -- the P / Q rows k_edge_hidden_mm adds per edge.
+constexpr int NU_TERMS_MAX = 8;
+struct NodeTerm { const float* W; const float* bias; float* out; int base, count; };
+struct NodeUpdateArgs {
+  const ReduceGroup* groups; int n_groups, nbase, ncount, D_in, D_out;
+  const float *bn_mean, *bn_scale, *bn_bias; int residual;
+  const float* X_in; float* X_out;
+  int n_terms; NodeTerm term[NU_TERMS_MAX];
+  int ns, H, ldw;
+};
+void launch_node_update(const NodeUpdateArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- k_graph.hip
 void launch_exclusive_scan(const int* in, int* out, int n, hipStream_t s);  // out[0..n], out[n] = total

@@ -109,9 +109,11 @@ struct Model {
   int fused_ysplit = 0;     // workgroups per 16-virtual-node tile (granule ranges); 0 = spread launches with few tiles over the CUs
   int fused_ysplit_small = 0;   // the same for a small group next to chip-filling ones (ddmi_exec_options.tile_split_small); 0 = automatic
   int eh_grid = 2048;       // workgroups of k_edge_hidden_mm (ddmi_exec_options.hidden_grid)
-  int grouped = 0;          // grouped dispatch of a layer's edge groups (ddmi_exec_options.grouped): 0 = layers whose biggest group has < grouped_below tiles, 1 = never, 2 = always
+  int grouped = 0;          // grouped dispatch of a layer's edge groups (ddmi_exec_options.grouped): 0 / 1 = per-group launches on two streams (default), 2 = grouped wherever supported
   int grouped_split = 0;    // workgroups per tile in grouped launches (exec.grouped_split); 0 = grouped_target / tiles of the layer
-  int grouped_target = 1536, grouped_below = 1 << 30;
+  int grouped_target = 1536;
+  bool node_update = true;  // k_node_update: a layer's node rows and the next layer's per-node first-Linear terms in one kernel (exec.node_update = 1: k_reduce_bn + GEMM launches)
+  bool vn_merge = true;     // virtual-node lists of a layer's groups in two launches (k_vn_lists, k_vn_rows_grouped); exec.vn_build = 1: one chain per group
   bool tile_per_pose = false;   // tiles of 16 virtual nodes never span two graphs (ddmi_exec_options.tile_per_pose): bit-exact shard invariance
   double crop_cutoff = 0.0;  // > 0: receptor cropped to this distance from the ligand in ddmi_forward (crop_beyond)
   DevicePool cpool;

@@ -27,7 +27,7 @@ EDGE_PRODUCTS = {"f32": 0, "bf16x4": 1}   # ddmi_config.edge_product (include/dd
 class ExecOptions(C.Structure):   # ddmi_exec_options (include/ddmi.h): all 0 = defaults
     _fields_ = [(n, C.c_int32) for n in ("streams", "dense_rows", "shared_tiles", "packed_granules", "merged_granule", "pre_reduce",
                                          "hidden_mm", "fc1_batch", "tile_split", "tile_split_small", "hidden_grid", "tp_apply",
-                                         "debug", "tile_per_pose", "layer_overlap", "grouped", "grouped_split")]
+                                         "debug", "tile_per_pose", "layer_overlap", "grouped", "grouped_split", "vn_build", "node_update")]
 
 
 # Harness knobs: libddmi.so reads no environment variable; the test / bench harness selects kernel routes through these
@@ -78,9 +78,11 @@ def exec_options_from_env(base=()) -> ExecOptions:
         if e("DDMI_LAYER_OVERLAP") not in (0, 1, 2):
             raise DdmiError("DDMI_LAYER_OVERLAP: 0 (joined layers), 1 (chip-filling batches) or 2 (always)")
         x.layer_overlap = e("DDMI_LAYER_OVERLAP")
-    if e("DDMI_GROUPED") is not None:           # 0 = the library's size rule (default), 1 = per-group launches, 2 = grouped wherever supported
+    if e("DDMI_NODE_UPDATE") is not None: x.node_update = 0 if e("DDMI_NODE_UPDATE") else 1   # variable = 0: k_reduce_bn + GEMM launches
+    if e("DDMI_VN_BUILD") is not None: x.vn_build = 1 if e("DDMI_VN_BUILD") else 0       # 1 = one list-building chain per group
+    if e("DDMI_GROUPED") is not None:           # 0 / 1 = per-group launches (default), 2 = grouped wherever supported
         if e("DDMI_GROUPED") not in (0, 1, 2):
-            raise DdmiError("DDMI_GROUPED: 0 (size rule), 1 (never) or 2 (always)")
+            raise DdmiError("DDMI_GROUPED: 0 / 1 (per-group launches) or 2 (grouped)")
         x.grouped = e("DDMI_GROUPED")
     if e("DDMI_GROUPED_YS") is not None: x.grouped_split = max(0, min(8, e("DDMI_GROUPED_YS")))
     return x

@@ -67,9 +67,17 @@ typedef struct ddmi_exec_options {
   int32_t grouped;          /* grouped dispatch of an interaction layer (round 6): per layer ONE launch of the per-node first-Linear terms,
                              * ONE of the hidden rows and ONE k_conv_grouped walking the (edge group, tile, granule range) work items of
                              * every edge group, on one stream -- instead of a hidden-row + k_conv_fused launch per group on two streams.
-                             * 0 = the library's size rule, 1 = never (per-group launches), 2 = wherever supported (exact-f32 l <= 1
+                             * 0 / 1 = per-group launches (the default: measured 1-2.4 % faster at 5 / 10 / 40 poses because hidden rows overlap
+                             * the other stream's convolution, profiles/r06_p2_*), 2 = grouped wherever supported (exact-f32 l <= 1
                              * layers with a two-layer edge MLP; others keep the per-group path).  Bit-identical messages either way.   */
   int32_t grouped_split;    /* workgroups per 16-virtual-node tile in grouped launches (granule ranges), 1..8; 0 = automatic           */
+  int32_t vn_build;         /* virtual-node lists + per-edge rows of a layer's edge groups: 0 = two launches for all groups
+                             * (k_vn_lists: count -> scan -> fill with a workgroup per group; k_vn_rows_grouped), 1 = a
+                             * count -> scan -> fill -> rows chain per group (rounds 2-5)                                              */
+  int32_t node_update;      /* 0 = k_node_update: the node update of an interaction layer (mean over all groups' messages, BatchNorm,
+                             * residual) also produces the NEXT layer's per-node first-Linear terms P / Q from the rows it holds --
+                             * no k_gemm_nt_batch launch per layer; 1 = k_reduce_bn + GEMM launches (rounds 1-5).  CG models with
+                             * two-layer edge MLPs; node rows bit-identical, P / Q equal up to the order of an ns-term fp32 sum.          */
 } ddmi_exec_options;
 
 /* Hyper-parameters: the keyword arguments get_model passes to CGModel

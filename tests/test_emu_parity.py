@@ -759,3 +759,53 @@ def test_grouped_dispatch_is_bit_identical(emu_lib):
             for a_, b_ in zip(outs[0], outs[k]):
                 assert torch.equal(a_, b_)
             assert torch.equal(traj[0], traj[k])
+
+
+def test_fused_node_update_matches_separate_launches(emu_lib):
+    """ddmi_exec_options.node_update: k_node_update (a layer's node rows AND the next layer's per-node first-Linear terms P / Q in
+    one kernel, the per-graph sigma terms of every layer from one batched launch) against k_reduce_bn + k_gemm_nt_batch launches:
+    the node tables are the same sums in the same order -- layer 1's table, which no fused P / Q has touched yet, is bit-identical --
+    and the scores agree at rounding level (P / Q take a 48-term fp32 sum in another order) and with the oracle.  With the per-step
+    crop (its own reduce-group list), sidechain rows (the last layer reduces every row), a ragged batch of two complexes, and under
+    the grouped dispatch."""
+    from dataclasses import replace
+    from diffdock_amd.config import DDL_SYNTH
+    from diffdock_amd.synth import make_complex, make_pose_list
+    from diffdock_amd.weights import init_state_dict
+    cfg = replace(DDL_SYNTH, num_conv_layers=3, lm_embedding_type=None, dynamic_max_cross=False, cross_max_distance=80.0, tr_sigma_min=0.1,
+                  tr_sigma_max=0.5, sidechain_pred=True)
+    sd = init_state_dict(cfg, seed=3)
+    g1 = make_complex(seed=4, n_res=19, n_lig=10, lm_dim=0)
+    g2 = make_complex(seed=5, n_res=13, n_lig=7, lm_dim=0)
+    dl = make_pose_list(g1, 2, tr_sigma_max=5.0, seed=6, initial_noise_std_proportion=0.3) + make_pose_list(g2, 1, tr_sigma_max=5.0, seed=7, initial_noise_std_proportion=0.3)
+    sched = get_t_schedule(1)
+    res = {}
+    for key, opts in (("separate", (("node_update", 1),)), ("fused", ()), ("fused_grouped", (("grouped", 2),))):
+        m = make_model(cfg.replace(exec_options=opts), sd, emu_lib)
+        b = HeteroBatch.from_data_list(dl)
+        set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+        m.set_kernel_timing(True)
+        out = [o.clone() for o in m(b)]
+        timers = m.kernel_timings()
+        m.set_kernel_timing(False)
+        x1 = torch.from_numpy(m.debug_buffer("x1").copy())
+        m.set_crop_cutoff(6.0)
+        cropped = [o.clone() for o in m(b)]
+        m.set_crop_cutoff(None)
+        traj = m.sample_batch(HeteroBatch.from_data_list(dl[:2]), 1, (sched, sched, sched), seed=11, sample_ids=[0, 1], no_final_step_noise=True).clone()
+        res[key] = (out, x1, cropped, traj, timers)
+    # launches of the first-Linear GEMMs per forward: per layer and group before, the first layer's batch + the sigma batch now
+    assert res["fused"][4]["conv_fc1_gemms"][1] == 2 and res["fused_grouped"][4]["conv_fc1_gemms"][1] == 2
+    assert res["separate"][4]["conv_fc1_gemms"][1] > 2
+    for key in ("fused", "fused_grouped"):
+        assert torch.equal(res[key][1], res["separate"][1])          # first interaction layer's node table
+        for a_, b_ in zip(res[key][0], res["separate"][0]):
+            assert rel_err(a_, b_) < 1e-5
+        for a_, b_ in zip(res[key][2], res["separate"][2]):
+            assert a_.shape == b_.shape and rel_err(a_, b_) < 1e-5
+        assert (res[key][3] - res["separate"][3]).abs().max() < 1e-4
+    b = HeteroBatch.from_data_list(dl)
+    set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
+    ref = CGModelOracle(cfg, sd, *tables())(b)
+    for o, r in zip(res["fused"][0][:3], ref[:3]):
+        assert rel_err(o, r) < 1e-4

@@ -18,7 +18,7 @@ if [ -n "$BASE" ]; then
   done
   for p in $pids; do wait $p; done
 else
-  for f in k_gemm k_conv k_conv_f32 k_conv_bf k_conv_l2 k_conv_grp k_hidden k_graph k_embed k_readout k_sample; do
+  for f in k_gemm k_conv k_conv_f32 k_conv_bf k_conv_l2 k_conv_grp k_hidden k_node k_graph k_embed k_readout k_sample; do
     cc $@ -x hip -c $f.hip -o build/var_${name}/$f.o &
     pids="$pids $!"
   done
