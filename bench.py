@@ -216,6 +216,7 @@ def main():
     ap.add_argument("--no-serialised-pass", action="store_true",
                     help="skip the extra one-stream pass behind roofline.serialised (kernel-trace profiles: one launch regime only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the extra 5- and 10-pose runs behind the `small_batch` key of the default line")
     ap.add_argument("--lib", default=None, help="path of an alternative libddmi build (kernel A/B experiments)")
     ap.add_argument("--edge-product", default="f32", choices=["f32", "bf16x4"],
                     help="arithmetic of the per-edge product of the interaction layers (ddmi_config.edge_product): f32 = exact fp32 chain "
@@ -236,10 +237,11 @@ def main():
     ap.add_argument("--fixed-center-conv", action="store_true",
                     help="build the model with fixed_center_conv (models/cg_model.py:371-374: the default indexes the ligand table by graph id, "
                          "so a pose's score depends on its position in the batch -- in the reference too)")
-    ap.add_argument("--verify-shards", action="store_true",
-                    help="multi-rank strong runs: after the timed region sample once more with a fixed seed, gather, and let rank 0 compare the "
-                         "gathered poses with the same poses sampled in ONE batch on its own GPU (readiness check of the sharded path; "
-                         "extra key `shard_check`)")
+    ap.add_argument("--verify-shards", dest="verify_shards", action="store_true", default=None,
+                    help="multi-rank strong runs (default ON there): after the timed region sample once more with a fixed seed, gather, and let "
+                         "rank 0 compare the gathered poses with the same blocks sampled on its own GPU and -- fixed_center_conv, a second model "
+                         "handle when the timed model is not -- with all poses in ONE batch (readiness check of the sharded path; key `shard_check`)")
+    ap.add_argument("--no-verify-shards", dest="verify_shards", action="store_false")
     ap.add_argument("--all-atoms", action="store_true",
                     help="secondary workload: the all-atom score model (models/aa_model.py), ~7.5 receptor atoms per residue")
     args = ap.parse_args()
@@ -276,6 +278,8 @@ def main():
     so3_t, tor_t = default_tables()
     S = args.samples or wl["samples"]              # poses per complex
     strong = args.scaling == "strong" and world > 1
+    if args.verify_shards is None:
+        args.verify_shards = strong
     lo, hi = shard_bounds(S, rank, world) if strong else (0, S)
     B = hi - lo                                    # poses of each complex on this rank
     sched = t_schedule(INFERENCE_STEPS)
@@ -412,16 +416,20 @@ def main():
         del wjobs
     shard_check = None
     if strong and args.verify_shards:
-        # readiness check of the sharded path (utils/sampling.py:80,91-93: poses are independent trajectories, noise keyed by global
-        # sample id): every rank's gathered block against the SAME block sampled by rank 0 as its own batch.  (Block by block, not
-        # against one batch of all S poses: with the reference's default centre convolution -- fixed_center_conv off,
-        # models/cg_model.py:371-374 indexes the ligand table by GRAPH id -- a pose's score depends on its position in the batch, in
-        # the reference too, so a batch of 40 and eight batches of 5 are different functions.  --fixed-center-conv removes that
-        # dependency; the one-batch comparison is then reported as well.)
+        # readiness check of the sharded path, behind the timed region (utils/sampling.py:80,91-93: poses are independent trajectories,
+        # noise keyed by global sample id):
+        #  (1) every rank's gathered block against the SAME block sampled by rank 0 as its own batch, with the bench's model;
+        #  (2) the gathered poses against all S poses sampled in ONE batch on rank 0 -- with a model built with fixed_center_conv:
+        #      the reference's default centre convolution (models/cg_model.py:371-374) indexes the ligand table by GRAPH id, so a
+        #      pose's score depends on its position in the batch, in the reference too, and a batch of 40 and eight batches of 5
+        #      are different functions under it (3.5-4 A apart after 20 steps).  When the bench's own model is not "fixed", a second
+        #      handle is.  tile_per_pose (the default here) makes (2) bit-exact.
+        def gathered_blocks(j):
+            return torch.cat([j["gathered"][r][:(shard_bounds(S, r, world)[1] - shard_bounds(S, r, world)[0]) * j["n_lig"]] for r in range(world)])
         one_step(4242)
         torch.cuda.synchronize()
+        worst, blocks = 0.0, []
         if rank == 0:
-            worst, worst_one, blocks = 0.0, None, []
             mdl = jobs[0]["model"]
             for j in jobs:
                 dlf = make_pose_list(j["g"], S, tr_sigma_max=cfg.tr_sigma_max, seed=1000, initial_noise_std_proportion=0.3)
@@ -434,16 +442,56 @@ def main():
                                             sample_ids=list(range(b0, b1)), no_final_step_noise=True, **TEMP).reshape(b1 - b0, j["n_lig"], 3)
                     worst = max(worst, float((got - mine).abs().max()))
                     blocks.append([b0, b1])
-                if cfg.fixed_center_conv:
-                    full = mdl.sample_batch(HeteroBatch.from_data_list(dlf).to(dev), INFERENCE_STEPS, (sched, sched, sched), seed=4242,
-                                            sample_ids=list(range(S)), no_final_step_noise=True, **TEMP).reshape(S, j["n_lig"], 3)
-                    allg = torch.cat([j["gathered"][r][:(shard_bounds(S, r, world)[1] - shard_bounds(S, r, world)[0]) * j["n_lig"]] for r in range(world)])
-                    worst_one = max(worst_one or 0.0, float((allg.reshape(S, j["n_lig"], 3) - full).abs().max()))
                 mdl.invalidate_complex()
+        # (2): every rank samples its block once more with the fixed-centre model, one more all_gather, rank 0 samples the one batch
+        cfg_fix = cfg if cfg.fixed_center_conv else cfg.replace(fixed_center_conv=True)
+        worst_one = 0.0
+        for j in jobs:
+            mfix = j["model"] if cfg.fixed_center_conv else MIScoreModel(cfg_fix, device=str(dev), lib_path=args.lib)
+            if mfix is not j["model"]:
+                mfix.load_state_dict(sd)          # (fixed_center_conv changes no weight)
+                mfix.set_tables(so3_t, tor_t)
+            jf = dict(j, model=mfix, shards=[dict(sh, model=mfix) for sh in j["shards"]])
+            one_step(4242, [jf])
+            torch.cuda.synchronize()
+            if rank == 0:
+                dlf = make_pose_list(j["g"], S, tr_sigma_max=cfg.tr_sigma_max, seed=1000, initial_noise_std_proportion=0.3)
+                full = mfix.sample_batch(HeteroBatch.from_data_list(dlf).to(dev), INFERENCE_STEPS, (sched, sched, sched), seed=4242,
+                                         sample_ids=list(range(S)), no_final_step_noise=True, **TEMP).reshape(S, j["n_lig"], 3)
+                worst_one = max(worst_one, float((gathered_blocks(j).reshape(S, j["n_lig"], 3) - full).abs().max()))
+            mfix.invalidate_complex()
+            j["model"].invalidate_complex()
+        if rank == 0:
             shard_check = {"max_abs_diff_vs_same_block_on_rank0_angstrom": worst, "max_abs_diff_vs_one_batch_angstrom": worst_one,
-                           "blocks": blocks[:world], "tolerance_angstrom": 1e-3, "ok": bool(worst <= 1e-3 and (worst_one is None or worst_one <= 1e-3)),
-                           "note": "20-step final ligand coordinates gathered from the ranks vs the same blocks sampled on rank 0 (and, with "
-                                   "--fixed-center-conv, vs all poses in one batch); per-sample Philox streams keyed by global sample id"}
+                           "one_batch_model": "fixed_center_conv" + ("" if cfg.fixed_center_conv else " (second handle: the timed model keeps the reference default)"),
+                           "blocks": blocks[:world], "tolerance_angstrom": 1e-3, "ok": bool(worst <= 1e-3 and worst_one <= 1e-3),
+                           "note": "20-step final ligand coordinates gathered from the ranks vs (1) the same blocks sampled on rank 0 with the timed "
+                                   "model, (2) all poses in one batch with fixed_center_conv; per-sample Philox streams keyed by global sample id"}
+    small_batch = None
+    if world == 1 and args.config == "configs2" and args.samples is None and not args.all_atoms and not args.no_small_batch:
+        # the batch ONE GPU runs when configs[3] shards the 40 poses over 8 / 4 GPUs: one warm-up + one measured 20-step run each,
+        # outside the timed region of the headline (own model handle; reported so that the driver's record shows the strong-scaling share)
+        small_batch = {}
+        j0 = jobs[0]
+        for nb in (5, 10):
+            dls = make_pose_list(j0["g"], nb, tr_sigma_max=cfg.tr_sigma_max, seed=1000, initial_noise_std_proportion=0.3)
+            mb = new_model()
+            bb = HeteroBatch.from_data_list(dls).to(dev)
+            run = lambda seed: mb.sample_batch(bb, INFERENCE_STEPS, (sched, sched, sched), seed=seed, sample_ids=list(range(nb)), no_final_step_noise=True, **TEMP)
+            run(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(2):
+                run(100 + k)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / 2
+            e_ll, e_lr, e_rr = int(mb.debug_buffer("goff_ll")[-1]), int(mb.debug_buffer("offs_l")[-1]), int(mb.debug_buffer("rr_goff")[-1])
+            fl = sum(w["k_conv_fused"]["flops"] for w in conv_work(cfg, nb * j0["n_lig"], nb * j0["n_res"], e_ll, e_lr, e_rr))
+            small_batch[f"{nb}_poses"] = {"value": nb / dts, "unit": "poses/s", "ms_per_forward": dts / INFERENCE_STEPS * 1e3,
+                                          "roofline_frac_wall": fl * INFERENCE_STEPS / dts / 1e12 / MFMA_F32_PEAK_TFLOPS}
+            del mb, bb
+        small_batch["note"] = ("one GPU's share of BASELINE configs[3] at 8 / 4 GPUs (5 / 10 poses of the same complex), 2 measured 20-step runs each "
+                               "after one warm-up, outside the headline's timed region; roofline_frac_wall as roofline.frac")
     # one more, untimed step with the per-kernel HIP-event timers on: phase table and kernel-level roofline figures
     all_models = [sh["model"] for j in jobs for sh in j["shards"]]
     for mdl in all_models:
@@ -617,6 +665,14 @@ def main():
             cpu = cpu_baseline(cfg, sd, so3_t, tor_t, jobs[len(jobs) // 2]["g"])
             if len(jobs) > 1:
                 cpu["sample"] += " (the middle complex of the mix stands for all nine)"
+            # the reference's OWN python (utils/sampling.sampling + models/cg_model.CGModel under the third-party stand-ins) cannot
+            # travel to the GPU box; it was timed once on the 8-core build container (profiles/r02_cpu_reference_executed.json)
+            rec_path = os.path.join(ROOT, "profiles", "r02_cpu_reference_executed.json")
+            if cpu["kind"] == "port" and os.path.exists(rec_path) and args.config in ("configs2", "configs1"):
+                rec = json.load(open(rec_path))
+                cpu["reference_executed_build_box"] = {"value": rec["poses_per_s"], "unit": "poses/s", "cores": rec["cores"], "kind": "reference",
+                                                       "sample": f"{rec['poses']} poses x {rec['steps']} steps, {rec['wall_s']:.0f} s wall, {rec['host']}",
+                                                       "source": "profiles/r02_cpu_reference_executed.json (recorded, not re-timed in this run)"}
         (n_res0, n_lig0, _) = wl["complexes"][0]
         shape = f"synthetic {n_res0}-residue receptor / {n_lig0}-atom ligand" if len(jobs) == 1 else f"{len(jobs)} synthetic complexes"
         total_poses = (S if strong else world * S) * len(jobs)
@@ -636,11 +692,14 @@ def main():
                                    f"(static 80 A cutoff), low-temperature SDE, random-init weights",
                        "name": args.config, "poses_per_complex": S, "poses_per_gpu": B * len(jobs), "inference_steps": INFERENCE_STEPS,
                        "complexes": len(jobs), "edges": edges[0] if len(edges) == 1 else edges, "tile_per_pose": bool(args.tile_per_pose),
+                       # models/cg_model.py:371-374: the default centre convolution indexes the ligand table by GRAPH id, so a pose's score
+                       # depends on its position in the batch (in the reference too): a sharded run reproduces the one-batch poses only with "fixed"
+                       "center_conv": "fixed" if cfg.fixed_center_conv else "batch-indexed (reference default)",
                        "edges_per_layer": sum(e["lig_lig"] + 2 * e["cross_each_direction"] + e["rec_rec"] for e in edges),
                        "parallelism": ("single GPU" if world == 1 else
                                        f"strong: the {S} poses of a complex sharded in blocks over {world} GPUs, 1 all_gather per complex" if strong else
                                        f"weak: {S} poses per GPU x {world} GPUs (pose-sharded, 1 all_gather per complex)")},
-            "roofline": roof, "roofline_scatter": roof_scatter, "cpu_baseline": cpu, "weak_scaling": weak_extra, "shard_check": shard_check,
+            "roofline": roof, "roofline_scatter": roof_scatter, "cpu_baseline": cpu, "small_batch": small_batch, "weak_scaling": weak_extra, "shard_check": shard_check,
             "phase_ms_per_forward": {k: v[0] / max(n_forwards, 1) for k, v in timings.items()},
         }
         print(json.dumps(out))

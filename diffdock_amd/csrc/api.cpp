@@ -59,7 +59,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
       h->m.grouped = x.grouped;
       h->m.grouped_split = x.grouped_split;
       h->m.vn_merge = x.vn_build == 0;
-      h->m.node_update = x.node_update == 0;
+      h->m.node_update = x.node_update == 1;
     }
     DDMI_CHECK_HIP(hipStreamCreateWithFlags(&h->m.side_stream, hipStreamNonBlocking));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_fork));

@@ -1427,7 +1427,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
       for (const RunGroup* q : {&g_ll, &g_lr, &g_rr, &g_rl}) biggest = std::max(biggest, tiles_of(*q));
       overlapped = biggest >= 256 || m.layer_overlap == 2;
     }
-    // Fused node update (ddmi_exec_options.node_update = 0): k_node_update writes a layer's rows AND the next layer's per-node
+    // Fused node update (ddmi_exec_options.node_update = 1; not the default: -0.9 %, profiles/r06_p5_*): k_node_update writes a layer's rows AND the next layer's per-node
     // first-Linear terms P / Q, so only the first layer launches its GEMMs; the per-graph sigma term of the rec-rec group of every
     // layer comes from one batched launch here.
     bool nu = m.node_update && !overlapped && Lc >= 2 && m.fused_mm && ns % 16 == 0 && ns <= 64 && c.Pg[0] && (int)c.rb_l.size() == Lc;

@@ -165,6 +165,10 @@ __device__ __forceinline__ void eh_body(const EdgeHiddenArgs& a, const int block
         ar = a.arow ? a.arow[e] : e;
         tg = a.tgt[e] - a.tbase;
       }
+#ifdef EHV_SEQATTR   // timing-only variant (garbage scores; run with frozen poses): attribute rows read in gather order -- the upper bound
+                     // of what re-ordering the attribute stores (rec-rec at set_complex, a receptor-major copy of the cross rows) can buy
+      ar = e0 + (live ? el : 16 * rt);
+#endif
       const float* __restrict__ ep = a.ea + (size_t)ar * a.ns + KS * lq;
       const float* __restrict__ prow = a.P + (size_t)tg * H + 4 * lq;
       float4 ae[NSQ], pv[NB];

@@ -25,21 +25,22 @@ __device__ __forceinline__ void nu_add(float4& a, const float4& v) { a.x += v.x;
 
 constexpr int NU_TILE = 16;
 
-template <int NSQ>   // ns = 16 * NSQ
-__global__ __launch_bounds__(256) void k_node_update(NodeUpdateArgs a) {
+template <int NSQ>   // ns = 16 * NSQ; workgroup = 16 nodes x 16 waves
+__global__ __launch_bounds__(1024) void k_node_update(NodeUpdateArgs a) {
   constexpr int NS = 16 * NSQ, XST = NS + 4;
   __shared__ float xs[NU_TILE][XST];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = DDMI_UNIFORM(tid >> 6);
   const int n0 = a.nbase + (int)blockIdx.x * NU_TILE, n_end = a.nbase + a.ncount;
   const bool live = 4 * lane < a.D_out;      // columns past D_out inside the XS-wide row are never used
-  // ---- phase 1: wave w reduces the tile's nodes w, w + 4, w + 8, w + 12
-  for (int q = 0; q < NU_TILE / 4; ++q) {
-    const int slot = wave + 4 * q, s = n0 + slot;
+  // ---- phase 1: wave w reduces node w of the tile (one wave per node: a node's chain group -> offsets -> rows is a dozen dependent
+  // round trips, so the nodes of a tile run side by side; a first form with four nodes per wave took 97 us per launch at 5 poses
+  // against k_reduce_bn's 17, profiles/r06_p3_*)
+  {
+    const int slot = wave, s = n0 + slot;
     if (s >= n_end) {
       if (4 * lane < NS) *reinterpret_cast<float4*>(&xs[slot][4 * lane]) = make_float4(0.f, 0.f, 0.f, 0.f);
-      continue;
-    }
+    } else {
     float4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -113,36 +114,70 @@ __global__ __launch_bounds__(256) void k_node_update(NodeUpdateArgs a) {
       *reinterpret_cast<float4*>(a.X_out + (size_t)s * XS + 4 * lane) = o;
       if (4 * lane < NS) *reinterpret_cast<float4*>(&xs[slot][4 * lane]) = o;
     }
+    }
   }
-  __syncthreads();
   // ---- phase 2: the next layer's first-Linear terms of the tile: out_t[16 nodes][H] = xs[16][ns] . W_t^T (+ bias_t), 16 hidden units
   // per MFMA column block.  Lane (lr, lq) supplies k = 16 jj + 4 lq + i in step (jj, i) for both operands, so its weight
-  // fragments are whole 16-byte pieces of a weight row.
+  // fragments are whole 16-byte pieces of a weight row.  A wave's (term, column block) tasks are known before the barrier: their
+  // weight fragments are requested in front of it (the L2 round trip hides behind the slowest node of the tile), and every task
+  // runs two MFMA chains (even / odd jj... i) so that a dependent f32 MFMA does not wait out its predecessor.
   const int lr = lane & 15, lq = lane >> 4;
   const int nb_h = a.H / 16, n_tasks = a.n_terms * nb_h;
-  for (int task = wave; task < n_tasks; task += 4) {
+  constexpr int NT_MAX = 5;     // tasks per wave kept in registers (8 terms x 9 column blocks / 16 waves = 4.5)
+  float4 bw[NT_MAX][NSQ];
+  float tb[NT_MAX];
+  bool on[NT_MAX];
+#pragma unroll
+  for (int q = 0; q < NT_MAX; ++q) {
+    const int task = wave + NU_TILE * q;
+    on[q] = false; tb[q] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < NSQ; ++jj) bw[q][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (task < n_tasks) {
+      const int t = task / nb_h, h0 = 16 * (task - t * nb_h);
+      const NodeTerm T = a.term[t];
+      on[q] = !(n0 + NU_TILE <= T.base || n0 >= T.base + T.count);   // (wave-uniform)
+      if (on[q]) {
+        const float* __restrict__ wrow = T.W + (size_t)(h0 + lr) * a.ldw + 4 * lq;
+#pragma unroll
+        for (int jj = 0; jj < NSQ; ++jj) bw[q][jj] = *reinterpret_cast<const float4*>(wrow + 16 * jj);
+        tb[q] = T.bias ? T.bias[h0 + lr] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  float4 xa[NSQ];
+#pragma unroll
+  for (int jj = 0; jj < NSQ; ++jj) xa[jj] = *reinterpret_cast<const float4*>(&xs[lr][16 * jj + 4 * lq]);
+  auto run_task = [&](int task, const float4 (&w)[NSQ], float bias) __attribute__((always_inline)) {
     const int t = task / nb_h, h0 = 16 * (task - t * nb_h);
     const NodeTerm T = a.term[t];
-    if (n0 + NU_TILE <= T.base || n0 >= T.base + T.count) continue;   // (wave-uniform)
-    float4 bw[NSQ];
-    const float* __restrict__ wrow = T.W + (size_t)(h0 + lr) * a.ldw + 4 * lq;
-#pragma unroll
-    for (int jj = 0; jj < NSQ; ++jj) bw[jj] = *reinterpret_cast<const float4*>(wrow + 16 * jj);
-    const float bias = T.bias ? T.bias[h0 + lr] : 0.f;
-    f32x4 acc = f32x4{bias, bias, bias, bias};
+    f32x4 acc = f32x4{bias, bias, bias, bias}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int jj = 0; jj < NSQ; ++jj) {
-      const float4 xa = *reinterpret_cast<const float4*>(&xs[lr][16 * jj + 4 * lq]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, bw[jj].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, bw[jj].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, bw[jj].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, bw[jj].w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[jj].x, w[jj].x, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[jj].y, w[jj].y, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[jj].z, w[jj].z, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[jj].w, w[jj].w, acc2, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int s = n0 + 4 * lq + r;
-      if (s >= T.base && s < T.base + T.count && s < n_end) T.out[(size_t)(s - T.base) * a.H + h0 + lr] = acc[r];
+      if (s >= T.base && s < T.base + T.count && s < n_end) T.out[(size_t)(s - T.base) * a.H + h0 + lr] = acc[r] + acc2[r];
     }
+  };
+#pragma unroll
+  for (int q = 0; q < NT_MAX; ++q)
+    if (on[q]) run_task(wave + NU_TILE * q, bw[q], tb[q]);
+  for (int task = wave + NU_TILE * NT_MAX; task < n_tasks; task += NU_TILE) {   // (wider layers: the rest without the prefetch)
+    const int t = task / nb_h, h0 = 16 * (task - t * nb_h);
+    const NodeTerm T = a.term[t];
+    if (n0 + NU_TILE <= T.base || n0 >= T.base + T.count) continue;
+    float4 w[NSQ];
+    const float* __restrict__ wrow = T.W + (size_t)(h0 + lr) * a.ldw + 4 * lq;
+#pragma unroll
+    for (int jj = 0; jj < NSQ; ++jj) w[jj] = *reinterpret_cast<const float4*>(wrow + 16 * jj);
+    run_task(task, w, T.bias ? T.bias[h0 + lr] : 0.f);
   }
 }
 
@@ -152,10 +187,10 @@ void launch_node_update(const NodeUpdateArgs& a, hipStream_t s) {
     throw Error(DDMI_ERR_ARG, "k_node_update: unsupported width");
   const dim3 grid((unsigned)cdiv(a.ncount, NU_TILE));
   switch (a.ns / 16) {
-    case 1: hipLaunchKernelGGL(k_node_update<1>, grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(k_node_update<2>, grid, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(k_node_update<3>, grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL(k_node_update<4>, grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(k_node_update<1>, grid, dim3(64 * NU_TILE), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_node_update<2>, grid, dim3(64 * NU_TILE), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(k_node_update<3>, grid, dim3(64 * NU_TILE), 0, s, a); break;
+    default: hipLaunchKernelGGL(k_node_update<4>, grid, dim3(64 * NU_TILE), 0, s, a); break;
   }
   DDMI_CHECK_HIP(hipGetLastError());
 }

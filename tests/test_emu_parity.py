@@ -762,7 +762,7 @@ def test_grouped_dispatch_is_bit_identical(emu_lib):
 
 
 def test_fused_node_update_matches_separate_launches(emu_lib):
-    """ddmi_exec_options.node_update: k_node_update (a layer's node rows AND the next layer's per-node first-Linear terms P / Q in
+    """ddmi_exec_options.node_update = 1: k_node_update (a layer's node rows AND the next layer's per-node first-Linear terms P / Q in
     one kernel, the per-graph sigma terms of every layer from one batched launch) against k_reduce_bn + k_gemm_nt_batch launches:
     the node tables are the same sums in the same order -- layer 1's table, which no fused P / Q has touched yet, is bit-identical --
     and the scores agree at rounding level (P / Q take a 48-term fp32 sum in another order) and with the oracle.  With the per-step
@@ -780,7 +780,7 @@ def test_fused_node_update_matches_separate_launches(emu_lib):
     dl = make_pose_list(g1, 2, tr_sigma_max=5.0, seed=6, initial_noise_std_proportion=0.3) + make_pose_list(g2, 1, tr_sigma_max=5.0, seed=7, initial_noise_std_proportion=0.3)
     sched = get_t_schedule(1)
     res = {}
-    for key, opts in (("separate", (("node_update", 1),)), ("fused", ()), ("fused_grouped", (("grouped", 2),))):
+    for key, opts in (("separate", ()), ("fused", (("node_update", 1),)), ("fused_grouped", (("node_update", 1), ("grouped", 2)))):
         m = make_model(cfg.replace(exec_options=opts), sd, emu_lib)
         b = HeteroBatch.from_data_list(dl)
         set_time(b, 0.6, 0.6, 0.6, b.num_graphs)

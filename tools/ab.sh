@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   envpart="${v%% -- *}"; extra=""
   if [[ "$v" == *" -- "* ]]; then extra="${v#* -- }"; fi
-  line=$(env $envpart python bench.py --steps 2 --warmup 1 --no-cpu-baseline $extra 2>/tmp/ab.err | tail -1)
+  line=$(env $envpart python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-small-batch $extra 2>/tmp/ab.err | tail -1)
   python - "$v" "$line" >> $out <<'PY'
 import json, sys
 v, line = sys.argv[1], sys.argv[2]

@@ -3,7 +3,7 @@
 # -> diffdock_amd/csrc/build/var_<name>.so   (bench.py --lib that path for an A/B run on the GPU box)
 # Every source is compiled with the flags (-DDDMI_PROFILING=1 switches on the DDMI_ABLATE / DDMI_FREEZE_POSE hooks, =2 also the
 # in-kernel phase clocks of k_conv_fused; none of this exists in the shipped library).
-# BASE=<other variant>: only the k_conv*.hip translation units are compiled with the flags, the other objects are taken from var_<BASE>.
+# BASE=<other variant>: only the k_conv*.hip translation units (or the ones listed in ONLY="k_hidden ...") are compiled with the flags, the other objects are taken from var_<BASE>.
 set -e
 cd "$(dirname "$0")/../diffdock_amd/csrc"
 name=$1; shift
@@ -12,7 +12,7 @@ pids=""
 cc() { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@"; }
 if [ -n "$BASE" ]; then
   cp build/var_${BASE}/*.o build/var_${name}/
-  for f in k_conv k_conv_f32 k_conv_bf k_conv_l2 k_conv_grp; do
+  for f in ${ONLY:-k_conv k_conv_f32 k_conv_bf k_conv_l2 k_conv_grp}; do
     cc $@ -x hip -c $f.hip -o build/var_${name}/$f.o &
     pids="$pids $!"
   done
