@@ -279,7 +279,26 @@ static FusedConvArgs fused_args(Model& m, const ConvW& L, const RunGroup& g, siz
     // one granule per workgroup, 5 poses 94 -> 100 poses/s.  Otherwise the round-2 rule (at most 6 ranges, tiles estimated
     // from nodes + edges / 32): the small lig-lig launch that runs next to the big groups is sensitive to its split -- 4
     // ranges at 40 poses; 5-6 cost the headline 2.5 % (profiles/r03_e27..e37_ab.txt).
-    if (small_layer) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
+    auto round_model = [&](long T) {
+      int pick = 1;
+      double best = 1e30;
+      for (int y = 1; y <= std::min(8, L.n_fgran); ++y) {
+        const double rounds = std::ceil((double)T * y / (double)m.n_cus);
+        const double cost = rounds * ((double)((L.n_fgran + y - 1) / y) + 0.2);
+        if (cost < best - 1e-9) { best = cost; pick = y; }
+      }
+      return pick;
+    };
+    if (small_layer && m.ys_rounds_small && tiles_of(g) >= 32) ys_req = round_model(tiles_of(g));
+    else if (small_layer) ys_req = (int)std::min(8L, std::max(1L, 768 / tiles_of(g)));
+    else if (m.ys_rounds && tiles_of(g) >= m.n_cus) {
+      // Chip-filling group (round 6): one workgroup per CU, so a launch of T x ys work items runs in ceil(T ys / CUs) rounds of
+      // (granules per item + tile prologue ~ 0.2 granules): pick the split with the cheapest schedule.  The old rule gave every
+      // group of >= 256 tiles ONE item per tile: 375 tiles (20 poses) = 1.46 rounds, i.e. two rounds with the second half empty
+      // -- 138.2 poses/s against 145.1 with the last launch of each stream split in four (profiles/r06_p6_b20_ab.txt); 750 tiles
+      // (40 poses) = 2.93 rounds keep one item per tile.
+      ys_req = round_model(tiles_of(g));
+    }
     else ys_req = (int)std::min(6L, std::max(1L, 768 / std::max(1L, ((long)g.gcount + g.ea_rows / 32) / 16)));
     const int ys_small = m.fused_ysplit_small;   // tuning: split of a small group next to big ones
     if (ys_small > 0 && !small_layer && tiles_of(g) < 256) ys_req = ys_small;
@@ -309,7 +328,7 @@ static FusedConvArgs fused_args(Model& m, const ConvW& L, const RunGroup& g, siz
 // layer's batched launch already produced them), virtual-node lists (first use in this forward), hidden rows, fused launch.
 // side: the scratch set of the side stream.
 static void run_group(Model& m, const ConvW& L, const RunGroup& g, size_t gi, bool side, bool mm_all, bool small_layer,
-                      const float* Xin, hipStream_t gs) {
+                      const float* Xin, hipStream_t gs, int ys_force = 0) {
   Cx& c = *m.cx;
   const int ns = m.ns, H = L.H;
   float *HE = side ? c.HE_b : c.HE, *P = side ? c.P_b : c.P, *Q = side ? c.Q_b : c.Q;
@@ -372,7 +391,7 @@ static void run_group(Model& m, const ConvW& L, const RunGroup& g, size_t gi, bo
     PhaseTimer t(m, "k_edge_hidden", gs);
     launch_edge_hidden(nvn, vs.vcap, vs.node, vs.e0, g.goff, g.arow, g.tgt, g.tbase, HE, P, Q, H, L.HKq / 8, Hb, gs, bf ? 1 : 0);
   }
-  const FusedConvArgs f = fused_args(m, L, g, gi, wg, Xin, Hb, rt, small_layer, 0);
+  const FusedConvArgs f = fused_args(m, L, g, gi, wg, Xin, Hb, rt, small_layer, ys_force);
   if (m.timing && m.timing_level >= 2) {   // ddmi_set_kernel_timing(h, 2 | 3): one timing row per edge group / per (layer, edge group)
     const bool per_layer = m.timing_level >= 3;
     const std::string tname = "k_conv_fused:" + (per_layer ? "L" + L.name.substr(L.name.size() - 1) : std::string()) + "g" + std::to_string(gi);
@@ -550,10 +569,36 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
   // "preparation" streams next to the first group's fused launch.  The time with no k_conv_fused dispatch running stayed at
   // 1.87 ms per forward, the fused launches themselves got 4 % slower -- 27-KB k_edge_hidden_mm workgroups scattered over the
   // CUs keep 158-KB fused workgroups from being placed: 139.8 -> 135.7 poses/s on the same box.)
-  for (size_t gi = 0; gi < groups.size(); ++gi) {
+  // issue order of the groups (exec.group_order, A/B knob): bit 0 = the side stream's groups in reverse order (rec<-lig in front of
+  // lig-lig: the short lig-lig items then fill the layer's tail), bit 1 = the main stream's groups in reverse order
+  std::vector<size_t> issue;
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<size_t> part;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      const bool side_g = forked && groups[gi].gbase == 0 && groups[gi].gcount == c.nL;
+      if (side_g == (pass == 1)) part.push_back(gi);
+    }
+    if (forked && ((m.group_order >> (pass == 1 ? 0 : 1)) & 1)) std::reverse(part.begin(), part.end());
+    issue.insert(issue.end(), part.begin(), part.end());
+  }
+  if (!forked || m.group_order == 0) { issue.clear(); for (size_t gi = 0; gi < groups.size(); ++gi) issue.push_back(gi); }
+  for (size_t ii = 0; ii < issue.size(); ++ii) {
+    const size_t gi = issue[ii];
     const RunGroup& g = groups[gi];
     const bool side = forked && g.gbase == 0 && g.gcount == c.nL;
-    run_group(m, L, g, gi, side, mm_all, small_layer, Xin, side ? m.side_stream : s);
+    // exec.tile_split_last: the LAST fused launch of each stream in finer work items -- the launch whose final partial round of
+    // workgroups is the layer's straggler tail (workgroup stamps: 0.46 ms per forward with < 32 of 256 CUs busy, profiles/r06_p2_wg_idle_b40_g1.txt)
+    int ys_last = 0;
+    if (m.fused_ysplit_last > 0 && !small_layer) {
+      bool last_on_stream = true;
+      for (size_t jj = ii + 1; jj < issue.size(); ++jj) {
+        const size_t gj = issue[jj];
+        const bool side_j = forked && groups[gj].gbase == 0 && groups[gj].gcount == c.nL;
+        if (side_j == side) last_on_stream = false;
+      }
+      if (last_on_stream && tiles_of(g) >= 256) ys_last = m.fused_ysplit_last;
+    }
+    run_group(m, L, g, gi, side, mm_all, small_layer, Xin, side ? m.side_stream : s, ys_last);
   }
   if (forked) {
     DDMI_CHECK_HIP(hipEventRecord(m.ev_join, m.side_stream));

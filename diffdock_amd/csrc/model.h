@@ -108,6 +108,11 @@ struct Model {
   bool fused_prered = true; // in-tile pre-reduction of the lig<-rec messages (exec.pre_reduce = 1: one message row per edge)
   int fused_ysplit = 0;     // workgroups per 16-virtual-node tile (granule ranges); 0 = spread launches with few tiles over the CUs
   int fused_ysplit_small = 0;   // the same for a small group next to chip-filling ones (ddmi_exec_options.tile_split_small); 0 = automatic
+  int group_order = 0;          // issue order of a layer's groups on their streams (exec.group_order bits: 1 = side stream reversed, 2 = main stream reversed)
+  bool ys_rounds_small = false; // the round model also for the groups of small layers (exec.tile_split_rule = 2; A/B)
+  bool ys_rounds = true;        // chip-filling groups: granule-range split from the round model (exec.tile_split_rule = 1: one item per tile, rounds 2-5)
+  int n_cus = 256;              // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+  int fused_ysplit_last = 0;    // the same for the last chip-filling launch of each stream in a layer (ddmi_exec_options.tile_split_last); 0 = as the others
   int eh_grid = 2048;       // workgroups of k_edge_hidden_mm (ddmi_exec_options.hidden_grid)
   int grouped = 0;          // grouped dispatch of a layer's edge groups (ddmi_exec_options.grouped): 0 / 1 = per-group launches on two streams (default), 2 = grouped wherever supported
   int grouped_split = 0;    // workgroups per tile in grouped launches (exec.grouped_split); 0 = grouped_target / tiles of the layer

@@ -81,6 +81,12 @@ typedef struct ddmi_exec_options {
                              * removes ran next to the convolution anyway -- 154.0 against 155.3 poses/s at 40 poses, 107.4 / 108.4
                              * at 5, profiles/r06_p5_*).  CG models with two-layer edge MLPs; node rows bit-identical, P / Q equal up
                              * to the order of an ns-term fp32 sum.                                                                      */
+  int32_t tile_split_last;  /* workgroups per tile for the LAST chip-filling k_conv_fused launch of each stream in a layer (its final partial
+                             * round of workgroups is the layer's straggler tail); 0 = as tile_split                                   */
+  int32_t tile_split_rule;  /* automatic tile_split of a chip-filling group: 0 = cheapest schedule of ceil(tiles x split / CUs) rounds of
+                             * (granules per item + prologue) (round 6), 1 = one work item per tile (rounds 2-5)                        */
+  int32_t group_order;      /* issue order of a layer's edge groups on their streams: 0 = [lig-lig, rec<-lig] | [lig<-rec, rec-rec];
+                             * bit 0 = side stream reversed, bit 1 = main stream reversed (A/B knob)                                   */
 } ddmi_exec_options;
 
 /* Hyper-parameters: the keyword arguments get_model passes to CGModel
