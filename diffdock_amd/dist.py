@@ -26,6 +26,11 @@ def gather_poses(local_pos: torch.Tensor, n_total: int, n_atoms: int) -> torch.T
     buf = torch.zeros(cap, n_atoms, 3, device=local_pos.device, dtype=local_pos.dtype)
     buf[:local_pos.shape[0]] = local_pos
     out = [torch.empty_like(buf) for _ in range(world)]
+    if buf.is_cuda:
+        # Drain this rank's loop before the collective is entered.  ddmi_sample only enqueues (two streams, ~16 cross-stream event
+        # waits per forward); a backend that synchronises a helper stream against the tail of that queue from a host thread (gloo's
+        # device-tensor all_gather) stalled those hand-offs for tens of seconds when two processes shared a GPU.
+        torch.cuda.current_stream(buf.device).synchronize()
     dist.all_gather(out, buf)
     parts = []
     for r in range(world):

@@ -196,6 +196,17 @@ def test_errors_are_python_exceptions(emu_lib):
     with pytest.raises(DdmiError):
         m.load_state_dict(bad)                                                  # shape mismatch
     assert set(m.expected_keys()) == set(sd)
+    # a C caller that asks for class families the reference cannot build is refused at ddmi_create, whichever branch of the weight
+    # spec it would take (the checks sit ahead of the early returns of the legacy / confidence branches)
+    import ctypes as C
+    from diffdock_amd import lib as L
+    lib = L.load(emu_lib)
+    for kw in (dict(old=True, depthwise_convolution=True, sh_lmax=2), dict(old=True, sidechain_pred=True, sh_lmax=2),
+               dict(all_atoms=True, depthwise_convolution=True), dict(all_atoms=True, confidence_mode=True, depthwise_convolution=True)):
+        c = L.make_config(cfg.replace(**kw))
+        h = C.c_void_p()
+        assert lib.ddmi_create(C.byref(c), 0, C.byref(h)) != 0, kw
+        assert b"CG models of the new class only" in lib.ddmi_last_error()
 
 
 def test_crop_with_embedding_layers_matches_oracle(emu_lib):

@@ -513,7 +513,9 @@ def test_grouped_dispatch_is_bit_identical_at_full_size():
                 outs.append([o.clone() for o in m(to_gpu(b))[:3]])
             n_launch = m.kernel_timings()["k_conv_fused"][1]
             m.set_kernel_timing(False)
-            assert n_launch == (22 if key == "per_group" else 6), (key, n_launch)
+            # (the grouped kernel is exact-f32 only: under the split-bf16 edge product the layers keep their per-group launches)
+            bf = os.environ.get("DDMI_EDGE_PRODUCT", "f32") != "f32"
+            assert n_launch == (22 if key == "per_group" or bf else 6), (key, n_launch)
             assert all(torch.equal(x, y) for x, y in zip(outs[1], outs[0])), key
             traj = m.sample_batch(to_gpu(HeteroBatch.from_data_list(dl)), 5, (sched, sched, sched), seed=123, sample_ids=list(range(B)),
                                   no_final_step_noise=True, crop_beyond=20.0).clone()
