@@ -3,6 +3,8 @@
 Tolerance: BASELINE.json north_star = 1e-4 relative fp32 on the score outputs (tr / rot / tor); the
 kernels run exact-fp32 MFMA, differences come from re-association only.  Full-size cases use
 size-independent properties: SE(3) equivariance of the scores, batch/shard invariance, determinism."""
+import os
+
 import numpy as np
 import pytest
 import torch
