@@ -1236,8 +1236,7 @@ static void forward_old(Model& m, const float* lig_pos, const float* t_tr, const
   // ligand graph, receptor edge attributes (with sigma, old_cg_model.py:411-413), cross graph with the raw-t cutoff
   launch_lig_radius(lig_pos, c.lig_batch, c.lig_ptr, nL, c.maxNl, cfg.lig_max_radius, c.lig_cap, c.adjrank, c.cnt_g, s);
   launch_ll_count(c.adjrank, c.lig_batch, c.lig_ptr, nL, c.maxNl, c.bg, c.bt, c.cnt_g, c.cnt_t, s);
-  launch_exclusive_scan(c.cnt_g, c.goff_ll, nL, s);
-  launch_exclusive_scan(c.cnt_t, c.toff_ll, nL, s);
+  launch_exclusive_scan2(c.cnt_g, c.goff_ll, nL, c.cnt_t, c.toff_ll, nL, s);
   launch_ll_fill(lig_pos, c.lig_batch, c.lig_ptr, nL, c.maxNl, c.adjrank, c.goff_ll, c.toff_ll, c.bg, c.bt, c.Eb, c.bond_src,
                  c.bond_dst, c.bond_grank, c.bond_trank, cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.ll_tgt, c.ll_tslot,
                  c.ll_featidx, c.ll_batch, c.ll_dist, c.ll_nvec, c.ll_ew, s);
@@ -1257,8 +1256,7 @@ static void forward_old(Model& m, const float* lig_pos, const float* t_tr, const
   }
   launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
                      cfg.cross_max_distance, nullptr, c.pairrank, c.cnt_l, c.cnt_r, s);
-  launch_exclusive_scan(c.cnt_l, c.offs_l, nL, s);
-  launch_exclusive_scan(c.cnt_r, c.offs_r, nR, s);
+  launch_exclusive_scan2(c.cnt_l, c.offs_l, nL, c.cnt_r, c.offs_r, nR, s);
   launch_cross_fill(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, c.pairrank, c.offs_l, c.offs_r,
                     cut_dev, cfg.cross_max_distance, cfg.smooth_edges, c.g1_tgt, c.g1_tslot, c.g3_tgt, c.g3_tslot, c.pbatch,
                     c.pdist, c.pnvec, c.pew, s);
@@ -1348,8 +1346,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
       launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, cs, conf ? 1 : 0);
     launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
                        cfg.cross_max_distance, keep_, c.pairrank, c.cnt_l, c.cnt_r, cs);
-    launch_exclusive_scan(c.cnt_l, c.offs_l, nL, cs);
-    launch_exclusive_scan(c.cnt_r, c.offs_r, nR, cs);
+    launch_exclusive_scan2(c.cnt_l, c.offs_l, nL, c.cnt_r, c.offs_r, nR, cs);
     launch_cross_fill(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, c.pairrank, c.offs_l, c.offs_r,
                       cut_dev, cfg.cross_max_distance, cfg.smooth_edges, c.g1_tgt, c.g1_tslot, c.g3_tgt, c.g3_tslot, c.pbatch,
                       c.pdist, c.pnvec, c.pew, cs);
@@ -1370,8 +1367,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   // ---- ligand graph (bonds + radius graph)
   launch_lig_radius(lig_pos, c.lig_batch, c.lig_ptr, nL, c.maxNl, cfg.lig_max_radius, c.lig_cap, c.adjrank, c.cnt_g, s);
   launch_ll_count(c.adjrank, c.lig_batch, c.lig_ptr, nL, c.maxNl, c.bg, c.bt, c.cnt_g, c.cnt_t, s);
-  launch_exclusive_scan(c.cnt_g, c.goff_ll, nL, s);
-  launch_exclusive_scan(c.cnt_t, c.toff_ll, nL, s);
+  launch_exclusive_scan2(c.cnt_g, c.goff_ll, nL, c.cnt_t, c.toff_ll, nL, s);
   launch_ll_fill(lig_pos, c.lig_batch, c.lig_ptr, nL, c.maxNl, c.adjrank, c.goff_ll, c.toff_ll, c.bg, c.bt, c.Eb, c.bond_src,
                  c.bond_dst, c.bond_grank, c.bond_trank, cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.ll_tgt, c.ll_tslot,
                  c.ll_featidx, c.ll_batch, c.ll_dist, c.ll_nvec, c.ll_ew, s);
@@ -1430,8 +1426,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     launch_add_rowvec(c.X[xi] + (size_t)aB * XS, XS, c.atom_node_base, XS, c.rec_sig, ns, c.atom_batch, nA, c.rec_base_dim, ns, s);
     launch_cross_count(lig_pos, c.atom_pos, c.lig_batch, c.atom_batch, c.lig_ptr, c.atom_ptr, nL, nA, c.maxNa, nullptr,
                        cfg.lig_max_radius, nullptr, c.la_pairrank, c.la_cnt_l, c.la_cnt_a, s);
-    launch_exclusive_scan(c.la_cnt_l, c.la_offs_l, nL, s);
-    launch_exclusive_scan(c.la_cnt_a, c.la_offs_a, nA, s);
+    launch_exclusive_scan2(c.la_cnt_l, c.la_offs_l, nL, c.la_cnt_a, c.la_offs_a, nA, s);
     launch_cross_fill(lig_pos, c.atom_pos, c.atom_batch, c.lig_ptr, c.atom_ptr, nL, nA, c.maxNa, c.la_pairrank, c.la_offs_l,
                       c.la_offs_a, nullptr, cfg.lig_max_radius, cfg.smooth_edges, c.la1_tgt, c.la1_tslot, c.la3_tgt, c.la3_tslot,
                       c.la_pbatch, c.la_dist, c.la_nvec, c.la_ew, s, aB);

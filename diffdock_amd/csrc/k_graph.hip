@@ -45,6 +45,34 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const int* __restrict__
   for (int i = lo; i < hi; ++i) { const int v = in[i]; out[i] = run; run += v; }
   if (t == 1023) out[n] = part[1023];
 }
+// two independent scans in one launch (gather- and target-side degree counts of a graph build: one dependency level instead of two)
+__global__ __launch_bounds__(1024) void k_exclusive_scan2(const int* __restrict__ in0, int* __restrict__ out0, int n0,
+                                                          const int* __restrict__ in1, int* __restrict__ out1, int n1) {
+  __shared__ int part[1024];
+  const int* __restrict__ in = blockIdx.x == 0 ? in0 : in1;
+  int* __restrict__ out = blockIdx.x == 0 ? out0 : out1;
+  const int n = blockIdx.x == 0 ? n0 : n1;
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(t * per, n), hi = min(lo + per, n);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += in[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int i = lo; i < hi; ++i) { const int v = in[i]; out[i] = run; run += v; }
+  if (t == 1023) out[n] = part[1023];
+}
+void launch_exclusive_scan2(const int* in0, int* out0, int n0, const int* in1, int* out1, int n1, hipStream_t s) {
+  hipLaunchKernelGGL(k_exclusive_scan2, dim3(2), dim3(1024), 0, s, in0, out0, n0, in1, out1, n1);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
 void launch_exclusive_scan(const int* in, int* out, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, in, out, n);
   DDMI_CHECK_HIP(hipGetLastError());

@@ -198,6 +198,7 @@ void launch_node_update(const NodeUpdateArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- k_graph.hip
 void launch_exclusive_scan(const int* in, int* out, int n, hipStream_t s);  // out[0..n], out[n] = total
+void launch_exclusive_scan2(const int* in0, int* out0, int n0, const int* in1, int* out1, int n1, hipStream_t s);   // two scans, one launch
 void launch_lig_radius(const float* pos, const int* batch, const int* ptr, int nL, int maxNl, float r, int cap,
                        int* adjrank, int* cnt_g, hipStream_t s);
 void launch_ll_count(const int* adjrank, const int* batch, const int* ptr, int nL, int maxNl, const int* bg,
