@@ -944,10 +944,38 @@ void set_complex(Model& m, const ddmi_complex& cc, hipStream_t s) {
     const bool lig_v[9] = {false, false, true, true, false, false, false, true, false};
     const char* names[9] = {"vn_off_cross", "vn_off_rr", "vn_off_ll", "vn_off_rl", "vn_off_la", "vn_off_ra", "vn_off_aa",
                             "vn_off_al", "vn_off_ar"};
+    // Tight capacities (round 6, exec.list_caps = 1; NOT the default: neutral at 5-20 poses, -1.8 % at 40, profiles/r06_p12_*): the grids of k_conv_fused / k_vn_rows cover the CAPACITY of a list, and a workgroup whose tile does
+    // not exist still has to be placed on a CU with 125-158 KB of free LDS before it can exit -- the generic bound
+    // nodes + edges / 32 is twice the live count for the all-pairs cross graph (a residue's <= n_lig edges are ONE virtual node).
+    // Per gather node the largest possible degree is known on the host: the other side's node count of its graph for the dynamic
+    // pair graphs, the exact degree for the static relations (a crop only removes edges), neighbour cap + bonds for lig-lig.
+    long tight[9];
+    for (int i = 0; i < 9; ++i) tight[i] = -1;
+    auto vn_of = [](long deg) { return (deg + 31) / 32; };
+    auto exact = [&](const std::vector<int>& off) { long n = 0; for (size_t d = 0; d + 1 < off.size(); ++d) n += vn_of(off[d + 1] - off[d]); return n; };
+    tight[0] = tight[3] = 0;
+    for (int b = 0; b < B; ++b) {
+      const long nl = c.lig_ptr_h[b + 1] - c.lig_ptr_h[b], nr = c.rec_ptr_h[b + 1] - c.rec_ptr_h[b];
+      tight[0] += nr * vn_of(nl);     // lig<-rec: gather = residue, at most one edge to every ligand atom of its graph
+      tight[3] += nl * vn_of(nr);     // rec<-lig: gather = ligand atom
+    }
+    tight[1] = exact(goff);           // rec-rec (static; the per-step crop compacts it)
+    tight[2] = 0;
+    for (int d = 0; d < nL; ++d) tight[2] += vn_of((long)c.lig_cap + bg[d]);   // lig-lig: <= lig_cap radius neighbours + its bonds
+    if (cfg.all_atoms) {
+      tight[4] = tight[7] = 0;
+      for (int b = 0; b < B; ++b) {
+        const long nl = c.lig_ptr_h[b + 1] - c.lig_ptr_h[b], na = atom_ptr_h[b + 1] - atom_ptr_h[b];
+        tight[4] += na * vn_of(nl);   // lig<-atom: gather = receptor atom
+        tight[7] += nl * vn_of(na);   // atom<-lig: gather = ligand atom
+      }
+      tight[5] = exact(h_ra.goff); tight[6] = exact(h_aa.goff); tight[8] = exact(h_ar.goff);
+    }
     int vmax = 0, vmax_b = 0;
     for (int i = 0; i < (cfg.all_atoms ? 9 : 4); ++i) {
       Cx::VnSet& vs = c.vn[i];
       vs.vcap = gn_v[i] + ecap_v[i] / 32 + 2;   // a gather node with deg edges: ceil(deg / 32) <= deg / 32 + 1 virtual nodes
+      if (m.tight_caps && tight[i] >= 0) vs.vcap = (int)std::min<long>(vs.vcap, tight[i] + 2);
       if (m.tile_per_pose) {                    // every graph padded to whole 16-node tiles
         vs.vcap += 16 * B;
         vs.nvn_pad = dalloc<int>(m, i == 0 ? "vn_count_cross" : nullptr, {1}, true);

@@ -87,6 +87,11 @@ typedef struct ddmi_exec_options {
                              * (granules per item + prologue) (round 6), 1 = one work item per tile (rounds 2-5)                        */
   int32_t group_order;      /* issue order of a layer's edge groups on their streams: 0 = [lig-lig, rec<-lig] | [lig<-rec, rec-rec];
                              * bit 0 = side stream reversed, bit 1 = main stream reversed (A/B knob)                                   */
+  int32_t list_caps;        /* capacity of the virtual-node lists (= grid size of k_conv_fused): 0 = nodes + edges / 32 (up to 2 x the live
+                             * count), 1 = per-node degree bounds (one virtual node per residue of an all-pairs cross graph: half the
+                             * workgroups of the lig<-rec and rec-rec launches never exist) -- neutral at 5-20 poses, 1.8 % SLOWER at 40
+                             * (153.1 against 155.9 poses/s: the empty workgroups pace the dispatch between the two streams,
+                             * profiles/r06_p12_*), hence not the default                                                               */
 } ddmi_exec_options;
 
 /* Hyper-parameters: the keyword arguments get_model passes to CGModel
