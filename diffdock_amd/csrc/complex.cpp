@@ -501,7 +501,7 @@ void run_conv(Model& m, const ConvW& L, const std::vector<RunGroup>& groups, con
     a.groups = rg_dev; a.n_groups = n_rg; a.nbase = nbase; a.ncount = ncount; a.D_in = L.D_in; a.D_out = L.D_out;
     a.bn_mean = L.has_bn ? L.bn_mean : nullptr; a.bn_scale = L.has_bn ? L.bn_scale : nullptr; a.bn_bias = L.has_bn ? L.bn_bias : nullptr;
     a.residual = L.residual ? 1 : 0; a.X_in = Xin; a.X_out = Xout;
-    a.ns = ns; a.H = Lnext->H; a.ldw = Lnext->n_edge;
+    a.ns = ns; a.H = Lnext->H; a.ldw = Lnext->n_edge; a.wpn = m.node_update_wpn;
     for (size_t gi = 0; gi < gnext->size(); ++gi) {
       const RunGroup& g = (*gnext)[gi];
       const int wg = std::min<int>((int)gi, Lnext->G - 1);

@@ -193,6 +193,7 @@ struct NodeUpdateArgs {
   const float* X_in; float* X_out;
   int n_terms; NodeTerm term[NU_TERMS_MAX];
   int ns, H, ldw;
+  int wpn;   // waves per node: 0 = by node count, 1 = sixteen nodes per workgroup, 4 = four nodes per workgroup (k_reduce_bn's row deal)
 };
 void launch_node_update(const NodeUpdateArgs& a, hipStream_t s);
 

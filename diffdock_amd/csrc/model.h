@@ -118,6 +118,7 @@ struct Model {
   int grouped = 0;          // grouped dispatch of a layer's edge groups (ddmi_exec_options.grouped): 0 / 1 = per-group launches on two streams (default), 2 = grouped wherever supported
   int grouped_split = 0;    // workgroups per tile in grouped launches (exec.grouped_split); 0 = grouped_target / tiles of the layer
   int grouped_target = 1536;
+  int node_update_wpn = 0;  // k_node_update: waves per node, 0 = by node count (exec.node_update = 2 / 3 force sixteen / four nodes per workgroup)
   bool node_update = false; // exec.node_update = 1: k_node_update -- a layer's node rows and the next layer's per-node first-Linear terms in one kernel (default: k_reduce_bn + GEMM launches)
   bool vn_merge = true;     // virtual-node lists of a layer's groups in two launches (k_vn_lists, k_vn_rows_grouped); exec.vn_build = 1: one chain per group
   bool tile_per_pose = false;   // tiles of 16 virtual nodes never span two graphs (ddmi_exec_options.tile_per_pose): bit-exact shard invariance

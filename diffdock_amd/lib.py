@@ -82,7 +82,7 @@ def exec_options_from_env(base=()) -> ExecOptions:
         if e("DDMI_LAYER_OVERLAP") not in (0, 1, 2):
             raise DdmiError("DDMI_LAYER_OVERLAP: 0 (joined layers), 1 (chip-filling batches) or 2 (always)")
         x.layer_overlap = e("DDMI_LAYER_OVERLAP")
-    if e("DDMI_NODE_UPDATE") is not None: x.node_update = 1 if e("DDMI_NODE_UPDATE") else 0   # 1 = fused node update (k_node_update)
+    if e("DDMI_NODE_UPDATE") is not None: x.node_update = max(0, min(3, e("DDMI_NODE_UPDATE")))   # 1 = fused node update (k_node_update); 2 / 3 = workgroup shape forced
     if e("DDMI_VN_BUILD") is not None: x.vn_build = 1 if e("DDMI_VN_BUILD") else 0       # 1 = one list-building chain per group
     if e("DDMI_GROUPED") is not None:           # 0 / 1 = per-group launches (default), 2 = grouped wherever supported
         if e("DDMI_GROUPED") not in (0, 1, 2):

@@ -74,7 +74,7 @@ typedef struct ddmi_exec_options {
   int32_t vn_build;         /* virtual-node lists + per-edge rows of a layer's edge groups: 0 = two launches for all groups
                              * (k_vn_lists: count -> scan -> fill with a workgroup per group; k_vn_rows_grouped), 1 = a
                              * count -> scan -> fill -> rows chain per group (rounds 2-5)                                              */
-  int32_t node_update;      /* 1 = k_node_update: the node update of an interaction layer (mean over all groups' messages, BatchNorm,
+  int32_t node_update;      /* 1 (2 / 3: workgroup shape forced to sixteen / four nodes) = k_node_update: the node update of an interaction layer (mean over all groups' messages, BatchNorm,
                              * residual) also produces the NEXT layer's per-node first-Linear terms P / Q from the rows it holds --
                              * no k_gemm_nt_batch launch per layer; 0 = k_reduce_bn + GEMM launches (the default: the fused kernel's
                              * 16-node workgroups stream the message rows at 0.57 instead of 0.40 ms per forward and the GEMMs it

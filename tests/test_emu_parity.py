@@ -791,7 +791,9 @@ def test_fused_node_update_matches_separate_launches(emu_lib):
     dl = make_pose_list(g1, 2, tr_sigma_max=5.0, seed=6, initial_noise_std_proportion=0.3) + make_pose_list(g2, 1, tr_sigma_max=5.0, seed=7, initial_noise_std_proportion=0.3)
     sched = get_t_schedule(1)
     res = {}
-    for key, opts in (("separate", ()), ("fused", (("node_update", 1),))):     # (fused + grouped dispatch: GPU route test)
+    # (fused = four waves per node at this size; fused16 = the sixteen-nodes-per-workgroup shape of chip-filling batches; fused + grouped
+    # dispatch: GPU route test)
+    for key, opts in (("separate", ()), ("fused", (("node_update", 1),)), ("fused16", (("node_update", 2),))):
         m = make_model(cfg.replace(exec_options=opts), sd, emu_lib)
         b = HeteroBatch.from_data_list(dl)
         set_time(b, 0.6, 0.6, 0.6, b.num_graphs)
@@ -801,7 +803,7 @@ def test_fused_node_update_matches_separate_launches(emu_lib):
         m.set_kernel_timing(False)
         x1 = torch.from_numpy(m.debug_buffer("x1").copy())
         cropped, traj = None, None
-        if True:
+        if key != "fused16":
             m.set_crop_cutoff(6.0)
             cropped = [o.clone() for o in m(b)]
             m.set_crop_cutoff(None)
@@ -810,7 +812,8 @@ def test_fused_node_update_matches_separate_launches(emu_lib):
     # launches of the first-Linear GEMMs per forward: per layer and group before, the first layer's batch + the sigma batch now
     assert res["fused"][4]["conv_fc1_gemms"][1] == 2
     assert res["separate"][4]["conv_fc1_gemms"][1] > 2
-    for key in ("fused",):
+    assert torch.equal(res["fused16"][0][0], res["fused"][0][0]) and torch.equal(res["fused16"][0][2], res["fused"][0][2])   # same sums, same MFMA chains
+    for key in ("fused", "fused16"):
         assert torch.equal(res[key][1], res["separate"][1])          # first interaction layer's node table
         for a_, b_ in zip(res[key][0], res["separate"][0]):
             assert rel_err(a_, b_) < 1e-5
