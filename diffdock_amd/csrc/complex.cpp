@@ -1185,13 +1185,16 @@ static void score_readouts(Model& m, const float* XL, const float* lig_pos, cons
   }
   // ---- translation / rotation heads (cg_model.py:368-395)
   const ConvW& F = m.final_conv;
-  launch_center_edges(lig_pos, c.lig_batch, c.lig_ptr, B, nL, c.c_dist, c.c_nvec, s);
-  launch_edge_mlp(mlp_args(m.center_edge, ns, nL, nullptr, c.c_dist, m.off_center, m.D, m.coeff_center, 0, c.center_gvec,
-                           c.lig_batch, c.c_ea), s);
-  launch_gather_cols(c.c_attr, F.n_edge, 0, c.c_ea, ns, nullptr, nL, ns, nullptr, s);
+  // (round 6: centre vectors + harmonics + the node scalars of the attribute row in ONE launch, the edge MLP writes its ns columns
+  // straight into the attribute row: 4 launches instead of 7 in front of the GEMMs)
   // fixed_center_conv: scalars of the atom; otherwise the reference indexes the ligand table by GRAPH id (cg_model.py:371-374)
-  launch_gather_cols(c.c_attr, F.n_edge, ns, XL, XS, cfg.fixed_center_conv ? c.c_xrow : c.lig_batch, nL, ns, nullptr, s);
-  launch_sh_rows(c.c_nvec, 1.f, nL, cfg.sh_lmax, c.c_sh, F.sh_dim, s);
+  launch_center_prep(lig_pos, c.lig_batch, c.lig_ptr, nL, cfg.sh_lmax, XL, cfg.fixed_center_conv ? c.c_xrow : c.lig_batch, ns, c.c_dist,
+                     c.c_nvec, c.c_sh, F.sh_dim, c.c_attr, F.n_edge, s);
+  {
+    EdgeMlpArgs ea = mlp_args(m.center_edge, ns, nL, nullptr, c.c_dist, m.off_center, m.D, m.coeff_center, 0, c.center_gvec, c.lig_batch, c.c_attr);
+    ea.ldo = F.n_edge;
+    launch_edge_mlp(ea, s);
+  }
   run_direct_conv(m, F, c.c_attr, nL, c.c_hid, c.c_W, c.c_xrow, XL, c.c_sh, nullptr, nullptr, 0, c.c_out, s);
   launch_segment_mean_bn(c.c_out, F.D_out, c.lig_ptr, nullptr, 0, B, F.D_out, F.has_bn ? F.bn_mean : nullptr,
                          F.has_bn ? F.bn_scale : nullptr, F.has_bn ? F.bn_bias : nullptr, c.gp, F.D_out, s);
@@ -1214,12 +1217,13 @@ static void score_readouts(Model& m, const float* XL, const float* lig_pos, cons
     if (fork) s = m.side_stream;
     launch_tor_radius(lig_pos, c.lig_ptr, c.tor_u, c.tor_v, c.tor_batch, c.nT, cfg.lig_max_radius, c.tor_cap,
                       cfg.smooth_edges ? cfg.lig_max_radius : 0.f, c.t_cnt, c.t_atom, c.t_dist, c.t_nvec, c.t_ew, c.t_bond_nvec, s);
-    launch_edge_mlp(mlp_args(m.final_edge, ns, c.Et, nullptr, c.t_dist, m.off_lig, m.D, m.coeff_lig, 0, m.final_edge.b0,
-                             nullptr, c.t_ea), s);
-    launch_gather_cols(c.t_attr, T.n_edge, 0, c.t_ea, ns, nullptr, c.Et, ns, nullptr, s);
-    launch_gather_cols(c.t_attr, T.n_edge, ns, XL, XS, c.t_atom, c.Et, ns, nullptr, s);
-    launch_gather_cols(c.t_attr, T.n_edge, 2 * ns, XL, XS, c.tor_eu, c.Et, ns, c.tor_ev, s);
-    launch_tor_sh(c.t_nvec, c.t_bond_nvec, c.nT, c.tor_cap, cfg.sh_lmax, m.tor_T, m.tor_ds, m.tor_dts, c.t_sh, s);
+    {   // (round 6: edge MLP straight into the attribute rows; the two node-scalar column blocks + the bond harmonics in one launch)
+      EdgeMlpArgs ea = mlp_args(m.final_edge, ns, c.Et, nullptr, c.t_dist, m.off_lig, m.D, m.coeff_lig, 0, m.final_edge.b0, nullptr, c.t_attr);
+      ea.ldo = T.n_edge;
+      launch_edge_mlp(ea, s);
+    }
+    launch_tor_prep(c.t_nvec, c.t_bond_nvec, c.nT, c.tor_cap, cfg.sh_lmax, m.tor_T, m.tor_ds, m.tor_dts, c.t_sh, XL, c.t_atom, c.tor_eu,
+                    c.tor_ev, ns, c.t_attr, T.n_edge, s);
     run_direct_conv(m, T, c.t_attr, c.Et, c.t_hid, c.t_W, c.t_atom, XL, c.t_sh, c.t_ew, c.t_cnt, c.tor_cap, c.t_out, s);
     launch_segment_mean_bn(c.t_out, T.D_out, nullptr, c.t_cnt, c.tor_cap, c.nT, T.D_out, T.has_bn ? T.bn_mean : nullptr,
                            T.has_bn ? T.bn_scale : nullptr, T.has_bn ? T.bn_bias : nullptr, c.t_feat, T.D_out, s);
@@ -1675,18 +1679,26 @@ void sample(Model& m, float* lig_pos, const ddmi_sample_cfg& sc, hipStream_t s) 
     Model& m; double saved;
     ~CropGuard() { m.crop_cutoff = saved; }
   } crop_guard{m, m.crop_cutoff};
-  if (!c.s_t) c.s_t = m.cpool.alloc<float>((size_t)3 * B);
+  if (!c.s_t) c.s_t = m.cpool.alloc<float>((size_t)3 * B * STEP_TIMES_MAX);
   const long long* ids_dev = upload_sample_ids(m, sc.sample_ids, s);
+  const bool times_once = steps <= STEP_TIMES_MAX;   // set_time of every step in ONE launch in front of the loop (one launch less per forward)
+  if (times_once) {
+    StepTimes st{};
+    st.steps = steps;
+    for (int k = 0; k < steps; ++k) { st.t[3 * k] = (float)sc.tr_schedule[k]; st.t[3 * k + 1] = (float)sc.rot_schedule[k]; st.t[3 * k + 2] = (float)sc.tor_schedule[k]; }
+    launch_fill_times_all(c.s_t, B, st, s);
+  }
   for (int k = 0; k < steps; ++k) {
     const double t_tr = sc.tr_schedule[k], t_rot = sc.rot_schedule[k], t_tor = sc.tor_schedule[k];
     const double s_tr = std::pow((double)cfg.tr_sigma_min, 1 - t_tr) * std::pow((double)cfg.tr_sigma_max, t_tr);
-    launch_fill_times(c.s_t, B, (float)t_tr, (float)t_rot, (float)t_tor, s);   // set_time for this step
+    float* tk = times_once ? c.s_t + (size_t)k * 3 * B : c.s_t;
+    if (!times_once) launch_fill_times(tk, B, (float)t_tr, (float)t_rot, (float)t_tor, s);   // set_time for this step
     m.crop_cutoff = sc.use_crop ? s_tr * 3.0 + sc.crop_beyond : 0.0;   // sampling.py:107
     // (Measured and dropped in round 4, profiles/r04_e7_ab.txt: the forward captured once as a HIP graph -- every launch argument
     // of a forward is the same in every step -- and replayed per step.  A dependent-kernel boundary costs the same inside a graph
     // as between eager launches on this stack, and the replay's fixed cost is not hidden: 146.3 -> 145.4 poses/s at 40 poses,
     // 102.2 -> 100.5 at 5.)
-    forward(m, lig_pos, c.s_t, c.s_t + B, c.s_t + 2 * B, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
+    forward(m, lig_pos, tk, tk + B, tk + 2 * B, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, s);
     perturb_step(m, c.s_tr, c.s_rot, torsion ? c.s_tor : nullptr, sc, k, ids_dev, s);
 #ifdef DDMI_PROFILING   // timing-only ablation builds produce garbage scores: DDMI_FREEZE_POSE keeps the graphs fixed (never in the shipped library)
     static const bool freeze = getenv("DDMI_FREEZE_POSE") != nullptr;

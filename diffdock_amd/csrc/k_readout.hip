@@ -46,6 +46,42 @@ void launch_center_edges(const float* pos, const int* batch, const int* ptr, int
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
+// centre convolution, everything per ligand atom that does not need the edge MLP (cg_model.py:368-376): vector to the graph's
+// centroid, its harmonics, and columns [ns, 2 ns) of the attribute row = the scalars of node xrow[a]
+__global__ __launch_bounds__(64) void k_center_prep(const float* __restrict__ pos, const int* __restrict__ batch, const int* __restrict__ ptr,
+                                                   int nL, int lmax, const float* __restrict__ X, const int* __restrict__ xrow, int ns,
+                                                   float* __restrict__ dist, float* __restrict__ nvec, float* __restrict__ sh, int lds_,
+                                                   float* __restrict__ attr, int lda) {
+  const int a = blockIdx.x;           // one wave per atom: lane 0 the geometry, all lanes the scalar columns
+  if (a >= nL) return;
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    const int b = batch[a], lo = ptr[b], hi = ptr[b + 1];
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    for (int i = lo; i < hi; ++i) { cx += pos[3 * i]; cy += pos[3 * i + 1]; cz += pos[3 * i + 2]; }
+    const float n = (float)(hi - lo);
+    cx /= n; cy /= n; cz /= n;
+    const float vx = pos[3 * a] - cx, vy = pos[3 * a + 1] - cy, vz = pos[3 * a + 2] - cz;
+    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float inv = 1.f / fmaxf(d, 1e-12f);
+    dist[a] = d;
+    const float ux = vx * inv, uy = vy * inv, uz = vz * inv;
+    nvec[3 * a] = ux; nvec[3 * a + 1] = uy; nvec[3 * a + 2] = uz;
+    float v[9];
+    sh_from_unit(ux, uy, uz, lmax, v);
+    const int nsh = (lmax + 1) * (lmax + 1);
+    for (int j = 0; j < nsh; ++j) sh[(size_t)a * lds_ + j] = v[j];
+  }
+  const float* __restrict__ xr = X + (size_t)xrow[a] * XS;
+  for (int c = lane; c < ns; c += 64) attr[(size_t)a * lda + ns + c] = xr[c];
+}
+void launch_center_prep(const float* pos, const int* batch, const int* ptr, int nL, int lmax, const float* X, const int* xrow, int ns,
+                        float* dist, float* nvec, float* sh, int lds_, float* attr, int lda, hipStream_t s) {
+  if (nL <= 0) return;
+  hipLaunchKernelGGL(k_center_prep, dim3(nL), dim3(64), 0, s, pos, batch, ptr, nL, lmax, X, xrow, ns, dist, nvec, sh, lds_, attr, lda);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 __global__ void k_sh_rows(const float* __restrict__ nvec, float sgn, int E, int lmax, float* __restrict__ sh, int lds_) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
@@ -82,6 +118,38 @@ void launch_tor_sh(const float* edge_nvec, const float* bond_nvec, int nT, int c
                    int dts, float* out, hipStream_t s) {
   if (nT <= 0) return;
   hipLaunchKernelGGL(k_tor_sh, dim3(cdiv(nT * cap, 64)), dim3(64), 0, s, edge_nvec, bond_nvec, nT, cap, lmax, T, ds, dts, out);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
+// torsion read-out, everything per (bond, neighbour) pair that does not need the edge MLP (cg_model.py:404-416): the FullTensorProduct
+// harmonics of k_tor_sh and columns [ns, 3 ns) of the attribute row = scalars of the neighbour atom | sum of the bond's two atoms
+__global__ __launch_bounds__(64) void k_tor_prep(const float* __restrict__ edge_nvec, const float* __restrict__ bond_nvec, int nT, int cap, int lmax,
+                                                const float* __restrict__ T, int ds, int dts, float* __restrict__ out,
+                                                const float* __restrict__ X, const int* __restrict__ atom, const int* __restrict__ eu,
+                                                const int* __restrict__ ev, int ns, float* __restrict__ attr, int lda) {
+  const int e = blockIdx.x;           // one wave per pair: lanes over the output harmonics, then over the scalar columns
+  if (e >= nT * cap) return;
+  const int t = e / cap, lane = threadIdx.x;
+  float se[9], sb9[9];
+  sh_from_unit(edge_nvec[3 * e], edge_nvec[3 * e + 1], edge_nvec[3 * e + 2], lmax, se);
+  sh_from_unit(bond_nvec[3 * t], bond_nvec[3 * t + 1], bond_nvec[3 * t + 2], 2, sb9);
+  const float* sb = sb9 + 4;  // the 2e block
+  for (int k = lane; k < dts; k += 64) {   // (same sum order as k_tor_sh)
+    float acc = 0.f;
+    for (int i = 0; i < ds; ++i)
+      for (int j = 0; j < 5; ++j) acc = fmaf(T[(i * 5 + j) * dts + k], se[i] * sb[j], acc);
+    out[(size_t)e * dts + k] = acc;
+  }
+  const float* __restrict__ xa = X + (size_t)atom[e] * XS;
+  const float* __restrict__ xu = X + (size_t)eu[e] * XS;
+  const float* __restrict__ xv = X + (size_t)ev[e] * XS;
+  float* __restrict__ row = attr + (size_t)e * lda;
+  for (int c = lane; c < ns; c += 64) { row[ns + c] = xa[c]; row[2 * ns + c] = xu[c] + xv[c]; }
+}
+void launch_tor_prep(const float* edge_nvec, const float* bond_nvec, int nT, int cap, int lmax, const float* T, int ds, int dts, float* out,
+                     const float* X, const int* atom, const int* eu, const int* ev, int ns, float* attr, int lda, hipStream_t s) {
+  if (nT <= 0) return;
+  hipLaunchKernelGGL(k_tor_prep, dim3(nT * cap), dim3(64), 0, s, edge_nvec, bond_nvec, nT, cap, lmax, T, ds, dts, out, X, atom, eu, ev, ns, attr, lda);
   DDMI_CHECK_HIP(hipGetLastError());
 }
 

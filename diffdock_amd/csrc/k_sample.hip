@@ -128,6 +128,18 @@ __global__ void k_fill_times(float* __restrict__ t, int B, float t_tr, float t_r
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) { t[i] = t_tr; t[B + i] = t_rot; t[2 * B + i] = t_tor; }
 }
+// set_time of EVERY step of a sampling loop in one launch: t[k][3][B] (the times are host scalars: they ride in the kernel arguments)
+__global__ void k_fill_times_all(float* __restrict__ t, int B, StepTimes st) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (i < B) {
+    float* __restrict__ tk = t + (size_t)k * 3 * B;
+    tk[i] = st.t[3 * k]; tk[B + i] = st.t[3 * k + 1]; tk[2 * B + i] = st.t[3 * k + 2];
+  }
+}
+void launch_fill_times_all(float* t, int B, const StepTimes& st, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill_times_all, dim3(cdiv(B, 256), st.steps), dim3(256), 0, s, t, B, st);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
 void launch_fill_times(float* t, int B, float t_tr, float t_rot, float t_tor, hipStream_t s) {
   hipLaunchKernelGGL(k_fill_times, dim3(cdiv(B, 256)), dim3(256), 0, s, t, B, t_tr, t_rot, t_tor);
   DDMI_CHECK_HIP(hipGetLastError());

@@ -253,6 +253,11 @@ void launch_concat_rec_input(const float* rec_x, int ldx, const float* emb, int 
                              hipStream_t s);
 
 // ---------------------------------------------------------------- k_readout.hip
+// read-out prep kernels (round 6): everything of a read-out chain that does not depend on its edge MLP, in one launch
+void launch_center_prep(const float* pos, const int* batch, const int* ptr, int nL, int lmax, const float* X, const int* xrow, int ns,
+                        float* dist, float* nvec, float* sh, int lds_, float* attr, int lda, hipStream_t s);
+void launch_tor_prep(const float* edge_nvec, const float* bond_nvec, int nT, int cap, int lmax, const float* T, int ds, int dts, float* out,
+                     const float* X, const int* atom, const int* eu, const int* ev, int ns, float* attr, int lda, hipStream_t s);
 void launch_center_edges(const float* pos, const int* batch, const int* ptr, int B, int nL, float* dist, float* nvec,
                          hipStream_t s);
 void launch_sh_rows(const float* nvec, float sgn, int E, int lmax, float* sh, int lds, hipStream_t s);
@@ -318,6 +323,9 @@ void launch_perturb(const PerturbArgs& a, hipStream_t s);
 void launch_debug_philox(const unsigned* ctr, const unsigned* key, int n, unsigned* out, hipStream_t s);
 void launch_debug_normal(unsigned long long seed, long long sample0, int n_samples, int step, int n_comp, float* out, hipStream_t s);
 // t[0..B) = t_tr, t[B..2B) = t_rot, t[2B..3B) = t_tor: the per-graph time vectors of one step (set_time, utils/diffusion_utils.py:35-57)
+constexpr int STEP_TIMES_MAX = 64;
+struct StepTimes { int steps; float t[3 * STEP_TIMES_MAX]; };   // (t_tr, t_rot, t_tor) of every step
+void launch_fill_times_all(float* t /* [steps][3][B] */, int B, const StepTimes& st, hipStream_t s);
 void launch_fill_times(float* t, int B, float t_tr, float t_rot, float t_tor, hipStream_t s);
 void launch_modify_conformer(float* pos, int B, int Nl, int R, const int* rot_u, const int* rot_v,
                              const unsigned char* mask_rotate, const float* tr, const float* rot, const float* tor,
