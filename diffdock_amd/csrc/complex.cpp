@@ -198,14 +198,18 @@ static void ensure_vn_all(Model& m, const std::vector<RunGroup>& groups, hipStre
       a.graph_ptr = lig ? c.lig_ptr : atom ? c.atom_ptr : c.rec_ptr;
       a.n_graphs = c.B; a.nvn_pad = vs.nvn_pad;
     }
-    rows[LA.n++] = vn_rows_args(m, g);
-    if (g.vn == 0 && c.prered) prered_g = &g;
+    rows[LA.n] = vn_rows_args(m, g);
+    if (g.vn == 0 && c.prered) {
+      prered_g = &g;
+      if (m.cfg.sh_lmax <= 1) { rows[LA.n].tile_hdr = vs.tile_hdr; rows[LA.n].live = vs.live; }   // headers from the rows' own launch
+    }
+    ++LA.n;
     vn_mark_built(c, g);
   }
   if (LA.n == 0) return;
   PhaseTimer t(m, "vn_build", gs);
   launch_vn_build_all(LA, rows, m.cfg.sh_lmax, gs);
-  if (prered_g) {
+  if (prered_g && m.cfg.sh_lmax > 1) {
     Cx::VnSet& vs = c.vn[0];
     launch_vn_tiles(vs.nvn_pad ? vs.nvn_pad : vs.voff + prered_g->gcount, vs.vcap, vs.rows, vs.ne, vs.tile_hdr, vs.live, gs);
   }

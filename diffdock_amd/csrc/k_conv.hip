@@ -61,11 +61,11 @@ __global__ void k_vn_fill_pp(const int* __restrict__ goff, const int* __restrict
 // row r -> [spherical harmonics (SHD) | edge weight | message row | pad] at stride ES, zero rows behind the node's last edge
 // and for the dead virtual nodes of the last 16-node tile; vn_ne[v] = edges of the virtual node.  The tile prologue of
 // k_conv_fused then is one coalesced copy instead of the chain vn_e0 -> arow -> nvec / weight / slot.
-template <int SHD, int ES>
+template <int SHD, int ES, int VPB>   // VPB virtual nodes per workgroup: 8, or 16 = one tile (then the workgroup also writes the tile's pre-reduction header)
 __device__ __forceinline__ void vn_rows_body(const VnRowsArgs& a, const int block) {
-  const int v = block * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
+  const int v = block * VPB + (threadIdx.x >> 5), r = threadIdx.x & 31;
   const int nvn = *a.nvn;
-  if (v >= ((nvn + 15) & ~15)) return;   // whole 16-node tiles (FC_VN)
+  if (v >= ((nvn + 15) & ~15)) return;   // whole 16-node tiles (FC_VN); workgroup-uniform for VPB = 16
   int ne = 0, e0 = 0;
   if (v < nvn) { e0 = a.vn_e0[v]; ne = min(32, a.goff[a.vn_node[v] + 1] - e0); }
   float sh[9] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -95,18 +95,44 @@ __device__ __forceinline__ void vn_rows_body(const VnRowsArgs& a, const int bloc
     reinterpret_cast<int*>(er)[SHD + 3] = tg;
   }
   if (r == 0) a.vn_ne[v] = ne;
+  if constexpr (VPB == 16 && SHD == 4) {
+    // tile header + live flags of the in-tile pre-reduction (k_vn_tiles' logic on the rows this workgroup has just produced: thread
+    // = edge row e = 32 * (virtual node in the tile) + row, the key k_vn_tiles uses)
+    if (a.tile_hdr) {   // (workgroup-uniform)
+      __shared__ int smin, smax, key[FC_TILE_NT], sts[512];
+      const int tid = threadIdx.x;
+      sts[tid] = ts;
+      if (tid == 0) { smin = 0x7fffffff; smax = -0x7fffffff; }
+      if (tid < FC_TILE_NT) key[tid] = 0x7fffffff;
+      __syncthreads();
+      const bool ok = v < nvn && r < ne;
+      if (ok) { atomicMin(&smin, tg); atomicMax(&smax, tg); }
+      __syncthreads();
+      const int t0 = smin, nt = smax - smin + 1;
+      const bool pre = smin <= smax && nt <= FC_TILE_NT;
+      if (pre && ok) atomicMin(&key[tg - t0], tid);
+      __syncthreads();
+      if (ok) a.live[ts] = (!pre || key[tg - t0] == tid) ? 1 : 0;
+      int* __restrict__ h = a.tile_hdr + (size_t)block * FC_TILE_HDR;
+      if (tid < FC_TILE_NT) {
+        const int k = key[tid];
+        h[4 + tid] = (pre && k != 0x7fffffff) ? sts[k] : -1;   // the representative's message row
+      }
+      if (tid == 0) { h[0] = pre ? 1 : 0; h[1] = t0; h[2] = pre ? nt : 0; h[3] = 0; }
+    }
+  }
 }
 template <int SHD, int ES>
-__global__ __launch_bounds__(256) void k_vn_rows(VnRowsArgs a) { vn_rows_body<SHD, ES>(a, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void k_vn_rows(VnRowsArgs a) { vn_rows_body<SHD, ES, 8>(a, (int)blockIdx.x); }
 // the per-edge rows of several edge groups in one launch (grouped dispatch): workgroups [first[g], first[g + 1]) serve group g
 template <int SHD, int ES>
-__global__ __launch_bounds__(256) void k_vn_rows_grouped(VnRowsGroupedArgs G) {
+__global__ __launch_bounds__(512) void k_vn_rows_grouped(VnRowsGroupedArgs G) {   // workgroup = one tile of 16 virtual nodes
   const int b = (int)blockIdx.x;
   int g = 0;
 #pragma unroll
   for (int i = 1; i < VN_GROUPS_MAX; ++i)
     if (i < G.n && b >= G.first[i]) g = i;
-  vn_rows_body<SHD, ES>(G.g[g], b - G.first[g]);
+  vn_rows_body<SHD, ES, 16>(G.g[g], b - G.first[g]);
 }
 
 // Virtual-node lists of several edge groups in ONE launch (round 6): workgroup = edge group; count -> scan -> fill in one pass
@@ -174,12 +200,12 @@ void launch_vn_build_all(const VnListsArgs& L, const VnRowsArgs* rows, int sh_lm
     r.vn_node = L.g[i].vn_node; r.vn_e0 = L.g[i].vn_e0; r.goff = L.g[i].goff;
     R.first[R.n] = blocks;
     R.g[R.n++] = r;
-    blocks += cdiv(round_up(r.vcap, 16), 8);
+    blocks += round_up(r.vcap, 16) / 16;
   }
   R.first[R.n] = blocks;
   if (blocks > 0) {
-    if (sh_lmax <= 1) hipLaunchKernelGGL((k_vn_rows_grouped<4, 8>), dim3(blocks), dim3(256), 0, s, R);
-    else hipLaunchKernelGGL((k_vn_rows_grouped<9, 12>), dim3(blocks), dim3(256), 0, s, R);
+    if (sh_lmax <= 1) hipLaunchKernelGGL((k_vn_rows_grouped<4, 8>), dim3(blocks), dim3(512), 0, s, R);
+    else hipLaunchKernelGGL((k_vn_rows_grouped<9, 12>), dim3(blocks), dim3(512), 0, s, R);
   }
   DDMI_CHECK_HIP(hipGetLastError());
 }

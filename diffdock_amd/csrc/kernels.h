@@ -78,6 +78,7 @@ struct VnRowsArgs {
   const int* arow; const float* nvec; const float* ew; const int* tslot; float sgn; int sh_lmax;
   const int* tgt; int tbase;           // target node of every edge (first node id of the target range)
   int vcap; float* rows; int* vn_ne;   // rows == nullptr: lists only
+  int* tile_hdr = nullptr; unsigned char* live = nullptr;   // k_vn_rows_grouped: also the tile headers / live flags of the in-tile pre-reduction (launch_vn_tiles)
 };
 // tile_per_pose: pad every graph of the batch to whole 16-node tiles (k_vn_fill_pp); nullptr = dense lists
 struct VnPoseTiles { const int* node_batch; const int* graph_ptr; int n_graphs; int* nvn_pad; };
