@@ -75,6 +75,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_fork));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_join));
     DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_cross));
+    DDMI_CHECK_HIP(hipEventCreate(&h->m.ev_terms));
     *out = h;
   });
 }
@@ -83,7 +84,7 @@ void ddmi_destroy(ddmi_model* h) {
   if (!h) return;
   Model& m = h->m;
   if (m.side_stream) { (void)hipStreamSynchronize(m.side_stream); (void)hipStreamDestroy(m.side_stream); }
-  for (hipEvent_t e : {m.ev_fork, m.ev_join, m.ev_cross}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {m.ev_fork, m.ev_join, m.ev_cross, m.ev_terms}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : m.ev_pipe) (void)hipEventDestroy(e);
   delete h;
 }

@@ -1352,6 +1352,34 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
   ++c.epoch;
   PhaseTimer t_fwd(m, "forward_total", s);
   std::unique_ptr<PhaseTimer> t_phase(new PhaseTimer(m, "embed_and_graphs", s));
+  // ---- cross graph (cg_model.py:539-562): its pair search needs only the ligand positions and t, so without a per-step crop it runs on
+  // the side stream from the very start of the forward (round 6: next to the time terms; rounds 2-5 forked behind them), its edge
+  // MLP -- which needs the per-graph time term -- behind an event; the ligand node encoder and the receptor rows of the first table
+  // (time terms only) follow it there, so the main stream goes from the time terms straight to the ligand graph.
+  const bool crop = m.crop_cutoff > 0.0;
+  DDMI_REQUIRE(!(crop && cfg.all_atoms), DDMI_ERR_ARG, "crop_beyond is not implemented for the all-atom model (aa_model.py:365-367)");
+  const float* cut_dev = cfg.dynamic_max_cross ? c.cutoff : nullptr;
+  auto cross_pairs = [&](hipStream_t cs, const int* keep_) {
+    if (cfg.dynamic_max_cross)   // cutoff_b = 3 * tr_sigma_b + 20 (cg_model.py:321-322)
+      launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, cs, conf ? 1 : 0);
+    launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
+                       cfg.cross_max_distance, keep_, c.pairrank, c.cnt_l, c.cnt_r, cs);
+    launch_exclusive_scan2(c.cnt_l, c.offs_l, nL, c.cnt_r, c.offs_r, nR, cs);
+    launch_cross_fill(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, c.pairrank, c.offs_l, c.offs_r,
+                      cut_dev, cfg.cross_max_distance, cfg.smooth_edges, c.g1_tgt, c.g1_tslot, c.g3_tgt, c.g3_tslot, c.pbatch,
+                      c.pdist, c.pnvec, c.pew, cs);
+  };
+  auto cross_attr = [&](hipStream_t cs) {
+    launch_edge_mlp(mlp_args(m.cross_edge, ns, c.Elr_cap, c.offs_l + nL, c.pdist, m.off_cross, m.Dc, m.coeff_cross, sd,
+                             c.cross_gvec, c.pbatch, c.cross_ea), cs);
+  };
+  auto cross_graph = [&](hipStream_t cs, const int* keep_) { cross_pairs(cs, keep_); cross_attr(cs); };
+  const bool early_cross = m.two_streams && m.side_stream && !crop;
+  if (early_cross) {
+    DDMI_CHECK_HIP(hipEventRecord(m.ev_fork, s));
+    DDMI_CHECK_HIP(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0));
+    cross_pairs(m.side_stream, nullptr);
+  }
   // ---- per-graph time terms
   launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, cfg.embedding_type, c.temb, s);
   {   // the per-graph terms of the time embedding: independent tiny GEMMs, one launch (+ the second layer of rec_sigma)
@@ -1372,34 +1400,25 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     launch_gemm_batch(gb, s);
     gemm(c.hidB, ns, m.rec_sigma.W3, ns, m.rec_sigma.b3, c.rec_sig, ns, B, ns, ns, 0, s);
   }
-  // ---- cross graph (cg_model.py:539-562): needs only the ligand positions and the time terms, so without a per-step crop it
-  // is built on the side stream while the ligand graph is built on this one (each chain is ~8 small launches)
-  const bool crop = m.crop_cutoff > 0.0;
-  DDMI_REQUIRE(!(crop && cfg.all_atoms), DDMI_ERR_ARG, "crop_beyond is not implemented for the all-atom model (aa_model.py:365-367)");
-  const float* cut_dev = cfg.dynamic_max_cross ? c.cutoff : nullptr;
-  auto cross_graph = [&](hipStream_t cs, const int* keep_) {
-    if (cfg.dynamic_max_cross)   // cutoff_b = 3 * tr_sigma_b + 20 (cg_model.py:321-322)
-      launch_cross_cutoff(t_tr, B, cfg.tr_sigma_min, cfg.tr_sigma_max, c.cutoff, cs, conf ? 1 : 0);
-    launch_cross_count(lig_pos, c.rec_pos, c.lig_batch, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, cut_dev,
-                       cfg.cross_max_distance, keep_, c.pairrank, c.cnt_l, c.cnt_r, cs);
-    launch_exclusive_scan2(c.cnt_l, c.offs_l, nL, c.cnt_r, c.offs_r, nR, cs);
-    launch_cross_fill(lig_pos, c.rec_pos, c.rec_batch, c.lig_ptr, c.rec_ptr, nL, nR, c.maxNr, c.pairrank, c.offs_l, c.offs_r,
-                      cut_dev, cfg.cross_max_distance, cfg.smooth_edges, c.g1_tgt, c.g1_tslot, c.g3_tgt, c.g3_tslot, c.pbatch,
-                      c.pdist, c.pnvec, c.pew, cs);
-    launch_edge_mlp(mlp_args(m.cross_edge, ns, c.Elr_cap, c.offs_l + nL, c.pdist, m.off_cross, m.Dc, m.coeff_cross, sd,
-                             c.cross_gvec, c.pbatch, c.cross_ea), cs);
-  };
-  const bool early_cross = m.two_streams && m.side_stream && !crop;
-  if (early_cross) {
-    DDMI_CHECK_HIP(hipEventRecord(m.ev_fork, s));
-    DDMI_CHECK_HIP(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0));
-    cross_graph(m.side_stream, nullptr);
-    DDMI_CHECK_HIP(hipEventRecord(m.ev_cross, m.side_stream));
-  }
   // ---- node tables: ligand rows [0,nL), receptor rows [nL, nL+nR)
   float* X0 = c.X[0];
-  launch_lig_node_embed(c.lig_x, nL, m.lig_emb, m.lig_emb_off, 16, ns, c.embsum, s);
-  gemm(c.embsum, ns, m.lig_enc.W0, ns + sd, nullptr, X0, XS, nL, ns, ns, 0, s, nullptr, c.ligsig, c.lig_batch, ns);
+  // (no embedding layers, no all-atom rows to add: the first table is complete once the encoder rows are in -- side stream)
+  const bool nodes_on_side = early_cross && m.lig_emb_layers.empty() && m.rec_emb_layers.empty();
+  auto lig_nodes = [&](hipStream_t ns_) {
+    launch_lig_node_embed(c.lig_x, nL, m.lig_emb, m.lig_emb_off, 16, ns, c.embsum, ns_);
+    gemm(c.embsum, ns, m.lig_enc.W0, ns + sd, nullptr, X0, XS, nL, ns, ns, 0, ns_, nullptr, c.ligsig, c.lig_batch, ns);
+  };
+  if (early_cross) {
+    DDMI_CHECK_HIP(hipEventRecord(m.ev_terms, s));
+    DDMI_CHECK_HIP(hipStreamWaitEvent(m.side_stream, m.ev_terms, 0));
+    cross_attr(m.side_stream);
+    if (nodes_on_side) {
+      lig_nodes(m.side_stream);
+      launch_add_rowvec(c.X[0] + (size_t)nL * XS, XS, c.rec_node_base, XS, c.rec_sig, ns, c.rec_batch, nR, c.rec_base_dim, ns, m.side_stream);
+    }
+    DDMI_CHECK_HIP(hipEventRecord(m.ev_cross, m.side_stream));
+  }
+  if (!nodes_on_side) lig_nodes(s);
   // ---- ligand graph (bonds + radius graph)
   launch_lig_radius(lig_pos, c.lig_batch, c.lig_ptr, nL, c.maxNl, cfg.lig_max_radius, c.lig_cap, c.adjrank, c.cnt_g, s);
   launch_ll_count(c.adjrank, c.lig_batch, c.lig_ptr, nL, c.maxNl, c.bg, c.bt, c.cnt_g, c.cnt_t, s);
@@ -1439,7 +1458,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
       run_conv(m, m.rec_emb_layers[i], {g_rr0}, c.rg_rr_crop, 1, c.X[i], c.X[i + 1], nL, nR, s);
     launch_add_rowvec(c.X[xi] + (size_t)nL * XS, XS, c.X[xi] + (size_t)nL * XS, XS, c.rec_sig, ns, c.rec_batch, nR,
                       c.rec_base_dim, ns, s);
-  } else {
+  } else if (!nodes_on_side) {
     launch_add_rowvec(c.X[xi] + (size_t)nL * XS, XS, c.rec_node_base, XS, c.rec_sig, ns, c.rec_batch, nR, c.rec_base_dim, ns, s);
   }
   if (early_cross) DDMI_CHECK_HIP(hipStreamWaitEvent(s, m.ev_cross, 0));

@@ -94,7 +94,7 @@ struct Model {
   // ---- complex + workspace
   bool has_complex = false;
   hipStream_t side_stream = nullptr;   // ligand-gather edge groups run here, concurrently with the receptor-gather ones
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cross = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cross = nullptr, ev_terms = nullptr;
   bool two_streams = true;
   int layer_overlap = 0;               // 0 joined layers (run_conv), 1 overlapped layer boundaries for chip-filling batches, 2 for every batch
   std::vector<hipEvent_t> ev_pipe;     // run_conv_layers_overlapped: [layer][group launch done / node rows written]
