@@ -41,7 +41,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
       in(x.hidden_mm, 1, "hidden_mm"); in(x.fc1_batch, 1, "fc1_batch"); in(x.tile_split, 8, "tile_split");
       in(x.tile_split_small, 8, "tile_split_small"); in(x.hidden_grid, 1 << 20, "hidden_grid"); in(x.tp_apply, 3, "tp_apply");
       in(x.tile_per_pose, 1, "tile_per_pose"); in(x.layer_overlap, 2, "layer_overlap");
-      in(x.grouped, 2, "grouped"); in(x.grouped_split, 8, "grouped_split"); in(x.vn_build, 1, "vn_build"); in(x.node_update, 3, "node_update"); in(x.tile_split_last, 8, "tile_split_last"); in(x.tile_split_rule, 2, "tile_split_rule"); in(x.group_order, 3, "group_order"); in(x.list_caps, 1, "list_caps");
+      in(x.grouped, 2, "grouped"); in(x.grouped_split, 8, "grouped_split"); in(x.vn_build, 1, "vn_build"); in(x.node_update, 3, "node_update"); in(x.tile_split_last, 8, "tile_split_last"); in(x.tile_split_rule, 2, "tile_split_rule"); in(x.group_order, 3, "group_order"); in(x.list_caps, 1, "list_caps"); in(x.time_terms, 1, "time_terms");
       h->m.two_streams = x.streams == 0;
       h->m.fused_dense = x.dense_rows == 0 ? 1 : x.dense_rows == 1 ? 0 : 2;
       h->m.fused_shared = x.shared_tiles == 0 ? 1 : x.shared_tiles == 1 ? 0 : 2;
@@ -66,6 +66,7 @@ int ddmi_create(const ddmi_config* cfg, int device, ddmi_model** out) {
       h->m.ys_rounds_small = x.tile_split_rule == 2;
       h->m.group_order = x.group_order;
       h->m.tight_caps = x.list_caps == 1;
+      h->m.time_terms_fused = x.time_terms == 1;
       {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus >= 16) h->m.n_cus = cus;

@@ -1381,6 +1381,26 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     cross_pairs(m.side_stream, nullptr);
   }
   // ---- per-graph time terms
+  if (m.time_terms_fused && sd / 2 <= 128 && ns <= 128) {   // one launch: embedding, every linear term of it, rec_sigma's second layer
+    TimeTermsArgs ta{};
+    ta.t = t_tr; ta.B = B; ta.freq = m.time_freq; ta.half = sd / 2; ta.scale = cfg.embedding_scale; ta.fourier = cfg.embedding_type; ta.temb = c.temb;
+    ta.ns = ns;
+    auto add = [&](const float* W, int ldw, const float* bias, float* C, int act) {
+      auto& x = ta.term[ta.n++];
+      x.W = W; x.ldw = ldw; x.bias = bias; x.C = C; x.act = act;
+    };
+    add(m.rec_sigma.W0, sd, m.rec_sigma.b0, c.hidB, 1);
+    add(m.lig_enc.W0 + ns, ns + sd, m.lig_enc.b0, c.ligsig, 0);
+    add(m.lig_edge.W0 + m.nf, m.lig_edge.in, m.lig_edge.b0, c.ll_gvec, 0);
+    add(m.cross_edge.W0, m.cross_edge.in, m.cross_edge.b0, c.cross_gvec, 0);
+    if (!conf) {
+      add(m.center_edge.W0 + m.D, m.center_edge.in, m.center_edge.b0, c.center_gvec, 0);
+      add(m.tr_final.W0 + 1, 1 + sd, m.tr_final.b0, c.tr_sig, 0);
+      add(m.rot_final.W0 + 1, 1 + sd, m.rot_final.b0, c.rot_sig, 0);
+    }
+    ta.hid_term = 0; ta.W3 = m.rec_sigma.W3; ta.b3 = m.rec_sigma.b3; ta.out3 = c.rec_sig;
+    launch_time_terms(ta, s);
+  } else {
   launch_time_embedding(t_tr, B, m.time_freq, sd / 2, cfg.embedding_scale, cfg.embedding_type, c.temb, s);
   {   // the per-graph terms of the time embedding: independent tiny GEMMs, one launch (+ the second layer of rec_sigma)
     GemmBatch gb;
@@ -1399,6 +1419,7 @@ void forward(Model& m, const float* lig_pos, const float* t_tr, const float* t_r
     }
     launch_gemm_batch(gb, s);
     gemm(c.hidB, ns, m.rec_sigma.W3, ns, m.rec_sigma.b3, c.rec_sig, ns, B, ns, ns, 0, s);
+  }
   }
   // ---- node tables: ligand rows [0,nL), receptor rows [nL, nL+nR)
   float* X0 = c.X[0];

@@ -33,6 +33,56 @@ void launch_time_embedding(const float* t, int B, const float* freq, int half, f
   DDMI_CHECK_HIP(hipGetLastError());
 }
 
+// Time embedding + every per-graph linear term of it + the two-layer rec_sigma MLP in ONE launch (round 6; workgroup = graph): the
+// head of a forward was k_time_embedding -> k_gemm_nt_batch -> k_gemm_nt, three dependent launches of B rows each
+// (cg_model.py:298-301,312-322: timestep_emb_func, lig / rec node sigma terms, the sigma columns of the edge embeddings and read-outs).
+__global__ __launch_bounds__(128) void k_time_terms(TimeTermsArgs a) {
+  __shared__ float temb[256], hid[128];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float pi = 3.14159274101257324f;   // float32(np.pi)
+  for (int k = tid; k < a.half; k += 128) {
+#ifdef DDMI_HIPEMU
+    volatile float ts = a.fourier ? a.t[b] * a.freq[k] : a.scale * a.t[b];
+    volatile float p2 = a.fourier ? ts * 2.f : ts * a.freq[k];
+    volatile float ph = a.fourier ? p2 * pi : p2;
+#else
+    const float ts = a.fourier ? __fmul_rn(a.t[b], a.freq[k]) : __fmul_rn(a.scale, a.t[b]);
+    const float p2 = a.fourier ? __fmul_rn(ts, 2.f) : __fmul_rn(ts, a.freq[k]);
+    const float ph = a.fourier ? __fmul_rn(p2, pi) : p2;
+#endif
+    const float sv = sinf(ph), cv = cosf(ph);
+    temb[k] = sv; temb[a.half + k] = cv;
+    a.temb[(size_t)b * 2 * a.half + k] = sv;
+    a.temb[(size_t)b * 2 * a.half + a.half + k] = cv;
+  }
+  __syncthreads();
+  const int sd = 2 * a.half;
+  for (int idx = tid; idx < a.n * a.ns; idx += 128) {
+    const int q = idx / a.ns, col = idx - q * a.ns;
+    const float* __restrict__ w = a.term[q].W + (size_t)col * a.term[q].ldw;
+    float acc = 0.f;
+    for (int k = 0; k < sd; ++k) acc = fmaf(temb[k], w[k], acc);
+    if (a.term[q].bias) acc += a.term[q].bias[col];
+    if (a.term[q].act) acc = fmaxf(acc, 0.f);
+    a.term[q].C[(size_t)b * a.ns + col] = acc;
+    if (q == a.hid_term) hid[col] = acc;
+  }
+  __syncthreads();
+  if (a.W3)
+    for (int col = tid; col < a.ns; col += 128) {
+      const float* __restrict__ w = a.W3 + (size_t)col * a.ns;
+      float acc = 0.f;
+      for (int k = 0; k < a.ns; ++k) acc = fmaf(hid[k], w[k], acc);
+      a.out3[(size_t)b * a.ns + col] = acc + (a.b3 ? a.b3[col] : 0.f);
+    }
+}
+void launch_time_terms(const TimeTermsArgs& a, hipStream_t s) {
+  if (a.B <= 0) return;
+  if (a.half > 128 || a.ns > 128 || a.n > TIME_TERMS_MAX) throw Error(DDMI_ERR_ARG, "k_time_terms: unsupported width");
+  hipLaunchKernelGGL(k_time_terms, dim3(a.B), dim3(128), 0, s, a);
+  DDMI_CHECK_HIP(hipGetLastError());
+}
+
 __global__ void k_lig_node_embed(const int* __restrict__ x, int nL, const float* __restrict__ emb,
                                  const int* __restrict__ emb_off, int n_feat, int ns, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

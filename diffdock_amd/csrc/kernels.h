@@ -229,6 +229,14 @@ void launch_tor_radius(const float* pos, const int* ptr, const int* tor_u, const
 
 // ---------------------------------------------------------------- k_embed.hip
 void launch_time_embedding(const float* t, int B, const float* freq, int half, float scale, int fourier, float* out, hipStream_t s);
+constexpr int TIME_TERMS_MAX = 8;
+struct TimeTermsArgs {
+  const float* t; int B; const float* freq; int half; float scale; int fourier; float* temb;   // launch_time_embedding's arguments
+  int ns, n;                                                                                   // n linear terms temb[sd] -> [ns]
+  struct { const float* W; int ldw; const float* bias; float* C; int act; } term[TIME_TERMS_MAX];
+  int hid_term; const float* W3; const float* b3; float* out3;   // out3 = W3 . term[hid_term] + b3 (second layer of rec_sigma); W3 == nullptr: none
+};
+void launch_time_terms(const TimeTermsArgs& a, hipStream_t s);
 void launch_lig_node_embed(const int* x, int nL, const float* emb, const int* emb_off, int n_feat, int ns, float* out,
                            hipStream_t s);
 void launch_add_rowvec(float* X, int ldx, const float* base, int ldb, const float* vec, int ldv, const int* idx, int rows,

@@ -109,6 +109,7 @@ struct Model {
   int fused_ysplit = 0;     // workgroups per 16-virtual-node tile (granule ranges); 0 = spread launches with few tiles over the CUs
   int fused_ysplit_small = 0;   // the same for a small group next to chip-filling ones (ddmi_exec_options.tile_split_small); 0 = automatic
   bool tight_caps = false;      // exec.list_caps = 1: virtual-node list capacities from per-node degree bounds (default: nodes + edges / 32)
+  bool time_terms_fused = false; // exec.time_terms = 1: time embedding + its per-graph linear terms + rec_sigma's second layer in one launch (k_time_terms)
   int group_order = 0;          // issue order of a layer's groups on their streams (exec.group_order bits: 1 = side stream reversed, 2 = main stream reversed)
   bool ys_rounds_small = false; // the round model also for the groups of small layers (exec.tile_split_rule = 2; A/B)
   bool ys_rounds = true;        // chip-filling groups: granule-range split from the round model (exec.tile_split_rule = 1: one item per tile, rounds 2-5)

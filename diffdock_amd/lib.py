@@ -27,7 +27,7 @@ EDGE_PRODUCTS = {"f32": 0, "bf16x4": 1}   # ddmi_config.edge_product (include/dd
 class ExecOptions(C.Structure):   # ddmi_exec_options (include/ddmi.h): all 0 = defaults
     _fields_ = [(n, C.c_int32) for n in ("streams", "dense_rows", "shared_tiles", "packed_granules", "merged_granule", "pre_reduce",
                                          "hidden_mm", "fc1_batch", "tile_split", "tile_split_small", "hidden_grid", "tp_apply",
-                                         "debug", "tile_per_pose", "layer_overlap", "grouped", "grouped_split", "vn_build", "node_update", "tile_split_last", "tile_split_rule", "group_order", "list_caps")]
+                                         "debug", "tile_per_pose", "layer_overlap", "grouped", "grouped_split", "vn_build", "node_update", "tile_split_last", "tile_split_rule", "group_order", "list_caps", "time_terms")]
 
 
 # Harness knobs: libddmi.so reads no environment variable; the test / bench harness selects kernel routes through these
@@ -65,6 +65,7 @@ def exec_options_from_env(base=()) -> ExecOptions:
                        ("DDMI_FUSED_MM", "hidden_mm"), ("DDMI_FC1_BATCH", "fc1_batch")):
         if e(var) is not None: setattr(x, field, 0 if e(var) != 0 else 1)     # variable = 0 switches the default route OFF
     if e("DDMI_FUSED_YS") is not None: x.tile_split = max(0, e("DDMI_FUSED_YS"))
+    if e("DDMI_TIME_TERMS") is not None: x.time_terms = 1 if e("DDMI_TIME_TERMS") else 0   # 1 = k_time_terms (one launch)
     if e("DDMI_LIST_CAPS") is not None: x.list_caps = 1 if e("DDMI_LIST_CAPS") else 0      # 1 = tight list capacities (per-node degree bounds)
     if e("DDMI_GROUP_ORDER") is not None: x.group_order = max(0, min(3, e("DDMI_GROUP_ORDER")))
     if e("DDMI_YS_RULE") is not None: x.tile_split_rule = max(0, min(2, e("DDMI_YS_RULE")))   # 1 = one work item per tile for chip-filling groups, 2 = round model for small layers too

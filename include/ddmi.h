@@ -92,6 +92,9 @@ typedef struct ddmi_exec_options {
                              * workgroups of the lig<-rec and rec-rec launches never exist) -- neutral at 5-20 poses, 1.8 % SLOWER at 40
                              * (153.1 against 155.9 poses/s: the empty workgroups pace the dispatch between the two streams,
                              * profiles/r06_p12_*), hence not the default                                                               */
+  int32_t time_terms;       /* 1 = k_time_terms: time embedding, its per-graph linear terms and rec_sigma's second layer in one launch
+                             * (measured neutral once the cross-graph search runs beside them: profiles/r06_p18_*), 0 = k_time_embedding
+                             * -> k_gemm_nt_batch -> k_gemm_nt (the default)                                                           */
 } ddmi_exec_options;
 
 /* Hyper-parameters: the keyword arguments get_model passes to CGModel

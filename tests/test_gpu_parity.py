@@ -128,7 +128,7 @@ def width48_case():
                                  {"DDMI_FUSED_SHARED": "0"}, {"DDMI_FUSED_SHARED": "2", "DDMI_FUSED_DENSE": "2"}, {"DDMI_FC1_BATCH": "0"}, {"DDMI_FUSED_TRI": "0"}, {"DDMI_FUSED_PRERED": "0"},
                                  {"DDMI_GROUPED": "1"}, {"DDMI_GROUPED": "2"}, {"DDMI_GROUPED": "2", "DDMI_GROUPED_YS": "3"},
                                  {"DDMI_GROUPED": "2", "DDMI_FUSED_PRERED": "0", "DDMI_FUSED_SHARED": "0"},
-                                 {"DDMI_NODE_UPDATE": "1"}, {"DDMI_VN_BUILD": "1"}, {"DDMI_LIST_CAPS": "1"}, {"DDMI_YS_RULE": "1"}, {"DDMI_GROUP_ORDER": "3", "DDMI_FUSED_YS_LAST": "2"}, {"DDMI_NODE_UPDATE": "1", "DDMI_VN_BUILD": "1", "DDMI_GROUPED": "2"}],
+                                 {"DDMI_NODE_UPDATE": "1"}, {"DDMI_VN_BUILD": "1"}, {"DDMI_LIST_CAPS": "1"}, {"DDMI_YS_RULE": "1"}, {"DDMI_TIME_TERMS": "1"}, {"DDMI_GROUP_ORDER": "3", "DDMI_FUSED_YS_LAST": "2"}, {"DDMI_NODE_UPDATE": "1", "DDMI_VN_BUILD": "1", "DDMI_GROUPED": "2"}],
                          ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
 def test_selectable_kernel_paths_agree_on_the_gpu(env, width48_case, monkeypatch):
     """Every selectable route of an edge group (classic instead of packed granules for the 10-channel vector blocks,
